@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/sec of one full JPD-SE `Pix2PixHDTrainer.step`
+(G fwd/bwd + batched 2-scale PatchGAN + 2x VGG19 + both Adam updates) at 1024x512.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json metric / configs[3] at N GPUs): script-default
+GlobalGenerator ngf=64, 4 downsamples, 9 ResnetBlocks; 39 input channels; num_D=2; LSGAN +
+D-feature-matching + VGG19 + L1; batch 4 per GPU (weak scaling), bf16 MFMA inputs with fp32
+accumulation, fp32 master weights/Adam; synthetic Cityscapes-shaped inputs resident in HBM.
+One JSON line on rank 0.  `roofline`: the ResnetBlock 3x3 implicit-GEMM kernel (N=1024,
+K=9216), algorithmic FLOPs / hipEvent-measured kernel time inside the timed region, against the
+2.5 PFLOP/s dense bf16 MFMA peak.  `cpu_baseline`: the torch-CPU oracle stepping the same
+network on the host cores (bounded sample; a reported baseline, not the target).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'jpd-se_amd')):
+  if _p not in sys.path:
+    sys.path.insert(0, _p)
+
+import torch
+import torch.distributed as dist
+
+# algorithmic GFLOP per image of the train step (2*MAC; G fwd+dgrad+wgrad,
+# D(fake) & D(real) fwd+dgrad+wgrad, D(fake) for G fwd+dgrad, VGG(fake) fwd+dgrad, VGG(real) fwd)
+F_ALG_GFLOP = {('global', 1024, 512): 4592.5, ('local', 1024, 512): 2803.2,
+               ('global', 512, 256): 1154.3, ('global', 256, 128): 291.7,
+               ('global', 2048, 1024): 18322.1, ('local', 2048, 1024): 11164.5}
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}     # MI355X_MICROARCH.md, dense
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=8)
+  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--width', type=int, default=1024)
+  ap.add_argument('--height', type=int, default=512)
+  ap.add_argument('--batch', type=int, default=4, help='images per GPU')
+  ap.add_argument('--netG', default='global', choices=['global', 'local'])
+  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  return ap.parse_args()
+
+
+def make_opt(args, device_index):
+  from oracle.ctu_cpu.model import default_opt     # only the opt namespace (field list), no compute
+  kw = dict(gpu_ids=[device_index], print_losses=False, compute_dtype=args.dtype, use_compressed=True,
+            netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch)
+  return default_opt(**kw)
+
+
+def cpu_baseline(args):
+  """The oracle (a port: kind 'port') on this box's host cores: one 512x256 step, then -- if that
+  took < 10 s -- one 1024x512 step, batch 1, fp32; the larger one that ran is reported."""
+  from oracle.ctu_cpu import model as omodel
+  cores = torch.get_num_threads()
+  opt = omodel.default_opt(netG=args.netG, ngf=64 if args.netG == 'global' else 32, use_compressed=True)
+  torch.manual_seed(1234)
+  ora = omodel.OracleTrainer(opt)
+  t0 = time.time()
+  ora.step(omodel.synthetic_batch(1, 256, 512, seed=1))
+  t_small = time.time() - t0
+  sample, secs = '1 step, batch 1, 512x256, fp32 torch-CPU oracle', t_small
+  if t_small < 10.0:
+    t0 = time.time()
+    ora.step(omodel.synthetic_batch(1, 512, 1024, seed=2))
+    secs = time.time() - t0
+    sample = '1 step, batch 1, 1024x512, fp32 torch-CPU oracle (after one 512x256 step)'
+  return dict(value=round(1.0 / secs, 5), unit='images/sec', cores=cores, kind='port', sample=sample)
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world > 1:
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', local_rank))
+  else:
+    torch.cuda.set_device(0)
+  assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+  dev_index = local_rank if world > 1 else 0
+  dev = torch.device('cuda', dev_index)
+
+  import jpdse_hip
+  from jpdse_hip import lib, check
+  from ctu.trainers import get_trainer
+  from oracle.ctu_cpu.model import synthetic_batch
+  jpdse_hip.require_gpu(dev_index)
+
+  torch.manual_seed(1234)            # identical replicas; enable_data_parallel also broadcasts rank 0
+  opt = make_opt(args, dev_index)
+  trainer = get_trainer(opt)(opt, 'train')
+
+  # synthetic Cityscapes-shaped batch, seeded per rank, resident in HBM before the clock starts
+  xd = synthetic_batch(args.batch, args.height, args.width, seed=1234 + rank)
+  xd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in xd.items()}
+
+  def barrier():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    trainer.step(xd)
+  # time the ResnetBlock 3x3 GEMM (forward and its data-gradient: same kernel, N=1024, K=9216)
+  L = lib()
+  check(L.jpdse_prof_select(1, 1024, 9216, 64 * max(args.steps, 1)), 'prof_select')
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    trainer.step(xd)
+  barrier()
+  elapsed = time.perf_counter() - t0
+  ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+  check(L.jpdse_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), 'prof_collect')
+  check(L.jpdse_prof_select(0, 0, 0, 0), 'prof_select off')
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  if rank == 0:
+    images = args.batch * world * args.steps
+    value = images / elapsed
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    roof = None
+    if n.value > 0 and ms.value > 0:
+      achieved = fl.value / (ms.value * 1e-3) / 1e12
+      roof = dict(bound='mfma', kernel='gemm_fwd_kernel (ResnetBlock 3x3 conv fwd+dgrad, N=1024 K=9216)',
+                  achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4),
+                  traffic=None, launches_per_step=n.value / args.steps,
+                  avg_launch_ms=round(ms.value / n.value, 4),
+                  flops_per_launch=fl.value / n.value)
+    f_alg = F_ALG_GFLOP.get((args.netG, args.width, args.height))
+    out = {
+        'metric': 'training images/sec at 1024x512 (G+D+VGG step)' if (args.width, args.height) == (1024, 512)
+                  else 'training images/sec at %dx%d (G+D+VGG step)' % (args.width, args.height),
+        'value': round(value, 4), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+        'data': 'synthetic',
+        'config': {'workload': 'JPD-SE train step %dx%d, netG=%s ngf=%d (39-ch input), num_D=2, VGG19+feat+L1, '
+                               'Adam x2, batch %d/GPU' % (args.width, args.height, args.netG, opt.ngf, args.batch),
+                   'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                   'step_mfma_frac': (round(f_alg * value / 1e3 / peak, 4) if f_alg else None),
+                   'f_alg_gflop_per_image': f_alg},
+        'roofline': roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline(args)
+    else:
+      out['cpu_baseline'] = None
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,222 @@
+/*
+ * jpdse.h -- C ABI of libjpdse_hip.so: the MI355X (gfx950) kernels behind the JPD-SE
+ * training hot path.
+ *
+ * The reference (SenseBrain/JPD-SE) is pure Python on torch.nn -> cuDNN and has no FFI of
+ * its own; each entry point below replaces the torch.nn call sites cited next to it
+ * (paths relative to the reference root, `networks.py` =
+ * ctu/models/pix2pixHD_networks/networks.py, `model.py` = ctu/models/pix2pixHD_model.py).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative JPDSE_E* code; the message is
+ *     available from jpdse_last_error() (thread local);
+ *   - nothing here allocates, frees, synchronises or throws: all buffers are caller-owned
+ *     device memory, borrowed for the duration of the enqueue on `stream` (hipStream_t
+ *     passed as void*);
+ *   - activations are NHWC, channel count stored rounded up to a multiple of 8
+ *     (JPDSE_CPAD): storage channels >= logical channels, the padding lanes are zero;
+ *   - filters are passed as fp32 "master" tensors in KRSC order (= the memory order of a
+ *     torch OIHW tensor in channels_last format; for ConvTranspose2d's IOHW weight the same
+ *     memory order is [Cin][R][S][Cout]) and packed per step into compute-dtype GEMM panels;
+ *   - dtype: JPDSE_F32 computes on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains),
+ *     JPDSE_BF16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; statistics, loss
+ *     reductions, weight gradients, Adam state are always fp32.
+ */
+#ifndef JPDSE_H_
+#define JPDSE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JPDSE_ABI_VERSION 1
+
+enum { JPDSE_F32 = 0, JPDSE_BF16 = 1 };
+enum { JPDSE_PAD_ZERO = 0, JPDSE_PAD_REFLECT = 1 };
+enum { JPDSE_ACT_NONE = 0, JPDSE_ACT_RELU = 1, JPDSE_ACT_LRELU = 2, JPDSE_ACT_TANH = 3 };
+enum {
+  JPDSE_OK = 0,
+  JPDSE_EINVAL = -1,      /* bad descriptor / null pointer / unsupported combination */
+  JPDSE_EWORKSPACE = -2,  /* workspace smaller than *_workspace_size() */
+  JPDSE_ELAUNCH = -3,     /* hipLaunchKernel / runtime error (message carries hipGetErrorString) */
+  JPDSE_EARCH = -4        /* device is not gfx950 */
+};
+
+#define JPDSE_CPAD(c) (((c) + 7) & ~7)
+
+/* ---- library ------------------------------------------------------------------------ */
+int jpdse_version(void);
+const char* jpdse_last_error(void);
+/* 0 when device `device` is gfx950; JPDSE_EARCH otherwise (no reference counterpart). */
+int jpdse_arch_check(int device);
+
+/* Kernel timer used by bench.py's roofline figure (no reference counterpart): after
+ * jpdse_prof_select(1, Ks, kdim, max) every implicit-GEMM launch with CPAD(out channels) == Ks
+ * and GEMM reduction length == kdim is bracketed by hipEvents on its own stream;
+ * jpdse_prof_collect waits for them and returns the summed kernel time, the summed algorithmic
+ * FLOPs (2*M*Ks*kdim per launch) and the number of launches, then resets the log.
+ * Not thread safe; select with enable = 0 to switch it off. */
+int jpdse_prof_select(int32_t enable, int32_t Ks, int64_t kdim, int32_t max_launches);
+int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
+
+/* ---- convolution family ------------------------------------------------------------- */
+/* One descriptor covers nn.Conv2d as used by:
+ *   ReflectionPad2d(3)+Conv2d 7x7            networks.py:210,246,160,175
+ *   Conv2d 3x3 stride 2 pad 1                networks.py:215,162
+ *   ReflectionPad2d(1)+Conv2d 3x3 (ResBlock) networks.py:275,283,291,298
+ *   Conv2d 4x4 stride 2|1 pad 2 (PatchGAN)   networks.py:430,437,444,449
+ *   VGG19 Conv2d 3x3 pad 1 + ReLU            networks.py:477-492
+ * and, with the roles of fwd/dgrad swapped by the caller, nn.ConvTranspose2d 3x3 stride 2
+ * pad 1 output_padding 1 (networks.py:244,170): convT.forward == dgrad of the Conv2d with
+ * K=Cin_T, C=Cout_T; convT.dgrad == that Conv2d's fwd; convT.wgrad == its wgrad with
+ * (x, dy) = (dy_T, x_T).  jpdse_convT_* below are exactly those aliases. */
+typedef struct jpdse_conv_desc {
+  int32_t dtype;      /* JPDSE_F32 | JPDSE_BF16: activations and packed filters */
+  int32_t N, H, W, C; /* input  [N,H,W,CPAD(C)] */
+  int32_t K;          /* output channels; output is [N,OH,OW,CPAD(K)] */
+  int32_t R, S;       /* filter height, width */
+  int32_t stride;     /* 1 | 2 */
+  int32_t pad;        /* symmetric padding */
+  int32_t pad_mode;   /* JPDSE_PAD_ZERO | JPDSE_PAD_REFLECT (reflect requires stride 1) */
+  int32_t act;        /* fwd epilogue after bias: JPDSE_ACT_* */
+  float slope;        /* LeakyReLU negative slope */
+} jpdse_conv_desc;
+
+int jpdse_conv_out_shape(const jpdse_conv_desc* d, int32_t* OH, int32_t* OW);
+/* Introspection of the host-side plan (no device work; callable without a GPU).  Writes 54
+ * int32: {Cs,Ks,Hp,Wp,OH,OW,Lk_fwd,n_phases,PT,PB,PL,PR,DH,DW} then for each of 4 stride
+ * phases of the data gradient {qh,qw,Uh,Uw,i0h,cnth,i0w,cntw,Lk,pack_offset_bytes}. */
+int jpdse_conv_plan_query(const jpdse_conv_desc* d, int32_t* out, int32_t n);
+/* bytes of the packed forward / data-gradient filter panels */
+size_t jpdse_conv_fwd_pack_size(const jpdse_conv_desc* d);
+size_t jpdse_conv_dgrad_pack_size(const jpdse_conv_desc* d);
+/* master fp32 KRSC -> compute-dtype panels (either output pointer may be NULL to skip) */
+int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w_krsc, void* fwd_pack,
+                            void* dgrad_pack, void* stream);
+/* workspace needed by fwd / dgrad / wgrad (max over the three) */
+size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d);
+/* y = act(conv(pad(x)) + bias); bias may be NULL (convs feeding an affine-less
+ * InstanceNorm: the bias is cancelled exactly by the mean subtraction). */
+int jpdse_conv_fwd(const jpdse_conv_desc* d, const void* x, const void* fwd_pack,
+                   const float* bias, void* y, void* ws, size_t ws_bytes, void* stream);
+/* dx = d(loss)/d(x) given dy = d(loss)/d(pre-activation output) */
+int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, void* dx,
+                     void* ws, size_t ws_bytes, void* stream);
+/* dw (fp32, KRSC master layout) = d(loss)/d(w); overwritten (beta = 0) */
+int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw_krsc,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* nn.ConvTranspose2d aliases: `d` describes the *underlying* Conv2d (its input is the
+ * transposed conv's OUTPUT: N,H,W,C = output geometry, K = transposed conv's Cin). */
+int jpdse_convT_fwd(const jpdse_conv_desc* d, const void* x, const void* dgrad_pack, void* y,
+                    void* ws, size_t ws_bytes, void* stream);
+int jpdse_convT_dgrad(const jpdse_conv_desc* d, const void* dy, const void* fwd_pack, void* dx,
+                      void* ws, size_t ws_bytes, void* stream);
+int jpdse_convT_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---- InstanceNorm2d(affine=False, eps) fused with activation / residual --------------- */
+/* networks.py:31 (norm), :204,:216,:229,:245 (ReLU), :438,:446 (LeakyReLU 0.2),
+ * :304 (x + conv_block(x): residual added after the second norm of a ResnetBlock). */
+typedef struct jpdse_inorm_desc {
+  int32_t dtype;
+  int32_t N, H, W, C;
+  int32_t act;          /* NONE | RELU | LRELU */
+  float slope;
+  float eps;            /* 1e-5 */
+  int32_t has_residual; /* y = act(norm(x)) + residual */
+} jpdse_inorm_desc;
+size_t jpdse_inorm_workspace_size(const jpdse_inorm_desc* d);
+/* stats: fp32 [N][CPAD(C)][2] = (mean, rstd), kept for backward */
+int jpdse_inorm_fwd(const jpdse_inorm_desc* d, const void* x, const void* residual, void* y,
+                    float* stats, void* ws, size_t ws_bytes, void* stream);
+/* dx from (x, stats, dy); the residual branch's gradient is dy itself */
+int jpdse_inorm_bwd(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy,
+                    void* dx, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- pooling ------------------------------------------------------------------------ */
+/* nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)  networks.py:180,387 */
+int jpdse_avgpool3s2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x,
+                         void* y, void* stream);
+int jpdse_avgpool3s2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* dy,
+                         void* dx, void* stream);
+/* nn.MaxPool2d(2,2) inside VGG19 features (networks.py:477) */
+int jpdse_maxpool2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x,
+                       void* y, void* stream);
+int jpdse_maxpool2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x,
+                       const void* dy, void* dx, void* stream);
+
+/* ---- elementwise pieces of the loss graph ----------------------------------------------- */
+/* dz = dy * act'(.) evaluated from the activation OUTPUT y (ReLU, LeakyReLU, Tanh backward) */
+int jpdse_act_bwd(int32_t dtype, int64_t n, int32_t act, float slope, const void* y, const void* dy,
+                  void* dz, void* stream);
+/* out = a + b (gradient fan-in where autograd would add) */
+int jpdse_add(int32_t dtype, int64_t n, const void* a, const void* b, void* out, void* stream);
+/* out[c] = sum over pixels of dy[p][c]  (bias gradients), fp32 [CPAD(C)] */
+size_t jpdse_channel_sum_workspace_size(int64_t npix, int32_t C);
+int jpdse_channel_sum(int32_t dtype, int64_t npix, int32_t C, const void* dy, float* out, void* ws,
+                      size_t ws_bytes, void* stream);
+/* dst[p][dst_c0 + i] = src[p][src_c0 + i], i < nch: torch.cat along channels
+ * (model.py:455,595,733) and its backward (slice). */
+int jpdse_channel_copy(int32_t dtype, int64_t npix, const void* src, int32_t src_cs, int32_t src_c0,
+                       void* dst, int32_t dst_cs, int32_t dst_c0, int32_t nch, void* stream);
+/* fill n elements with zero */
+int jpdse_zero(int32_t dtype, int64_t n, void* p, void* stream);
+
+/* ---- API-boundary layout conversion ---------------------------------------------------- */
+/* fp32 NCHW (the x_dict tensors of ctu_dataset.py:124-128) -> NHWC compute dtype, C padded */
+int jpdse_nchw_to_nhwc(int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W, const float* src,
+                       void* dst, void* stream);
+int jpdse_nhwc_to_nchw(int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W, const void* src,
+                       float* dst, void* stream);
+/* One-hot scatter of the label map + 4-neighbour instance-edge map, written to channels
+ * [0, num_labels] of an NHWC tensor with `cs` storage channels (model.py:375-394,774-783).
+ * label: fp32 [N,1,H,W] integer-valued; instance: int64 [N,1,H,W]. */
+int jpdse_onehot_edge(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t num_labels,
+                      const float* label, const int64_t* instance, void* dst, int32_t cs,
+                      void* stream);
+
+/* ---- losses ------------------------------------------------------------------------- */
+/* All reductions are fp32 and deterministic (two-stage).  `count` is the LOGICAL element
+ * count the mean divides by (padding lanes are zero in both operands).
+ * out[0] = mean |a-b|  (nn.L1Loss: networks.py:131, model.py:207,218) */
+size_t jpdse_loss_workspace_size(int64_t n);
+int jpdse_l1_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out,
+                 void* ws, size_t ws_bytes, void* stream);
+/* da = scale * (*gout) * sign(a-b) / count ; gout is a DEVICE scalar (no host sync) */
+int jpdse_l1_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b,
+                 const float* gout, float scale, void* da, void* stream);
+/* out[0] = mean (a-b)^2 (nn.MSELoss distortion: model.py:219-220) */
+int jpdse_mse_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out,
+                  void* ws, size_t ws_bytes, void* stream);
+int jpdse_mse_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b,
+                  const float* gout, float scale, void* da, void* stream);
+/* LSGAN: out[0] = mean over the LOGICAL channel 0 of (x - target)^2 (networks.py:90,112-119).
+ * x is the 1-channel PatchGAN map stored with `cs` channels. */
+int jpdse_mse_const_fwd(int32_t dtype, int64_t npix, int32_t cs, float target, const void* x,
+                        float* out, void* ws, size_t ws_bytes, void* stream);
+int jpdse_mse_const_bwd(int32_t dtype, int64_t npix, int32_t cs, float target, const void* x,
+                        const float* gout, float scale, void* dx, void* stream);
+
+/* ---- optimizer ---------------------------------------------------------------------- */
+/* torch.optim.Adam (model.py:275,279) over a table of tensors, one launch.  `table` is a
+ * device array of jpdse_adam_entry; bias corrections are computed from `step` (1-based). */
+typedef struct jpdse_adam_entry {
+  float* p;       /* parameter (fp32 master) */
+  const float* g; /* gradient */
+  float* m;       /* exp_avg */
+  float* v;       /* exp_avg_sq */
+  int64_t n;      /* elements */
+  int64_t block0; /* first 1024-element block of this tensor in the launch */
+} jpdse_adam_entry;
+int jpdse_adam_step(const jpdse_adam_entry* table, int32_t n_entries, int64_t total_blocks,
+                    float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPDSE_H_ */

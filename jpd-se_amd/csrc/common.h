@@ -1,0 +1,100 @@
+// Shared host/device helpers for libjpdse_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/jpdse.h"
+
+namespace jpdse {
+
+// ---- error plumbing ---------------------------------------------------------------------
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define JPDSE_REQUIRE(cond, ...)                              \
+  do {                                                        \
+    if (!(cond)) return ::jpdse::set_error(JPDSE_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cpad(int c) { return (c + 7) & ~7; }
+static inline size_t esize(int dtype) { return dtype == JPDSE_BF16 ? 2 : 4; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device scalar types ------------------------------------------------------------------
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserving
+  return __builtin_bit_cast(bf16_t, h);
+}
+
+template <typename T> struct ElemOps;
+template <> struct ElemOps<float> {
+  static constexpr int kDtype = JPDSE_F32;
+  static constexpr int kVec = 4;  // elements per 16-byte vector
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemOps<bf16_t> {
+  static constexpr int kDtype = JPDSE_BF16;
+  static constexpr int kVec = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte vector of T unpacked to floats and back
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ static __forceinline__ void store(float* p, const float (&v)[4]) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(t[i] << 16);
+      v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      t[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = t;
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// grid-stride launch geometry for HBM-bound kernels: <= 256 CUs x 8 blocks
+static inline int ew_blocks(int64_t work_items, int threads = 256) {
+  int64_t b = (work_items + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+}  // namespace jpdse

@@ -1,0 +1,1099 @@
+// Implicit-GEMM convolution family for gfx950 (MI355X): forward, data-gradient and
+// weight-gradient of every nn.Conv2d / nn.ConvTranspose2d on the JPD-SE hot path
+// (reference call sites: include/jpdse.h "convolution family").
+//
+// Formulation ("row-run"): the input is materially padded to NHWC [N,Hp,Wp,Cs]; for an
+// output pixel m=(n,oh,ow) and filter row r the S*Cs input values under that filter row are
+// ONE contiguous run in memory (consecutive s are consecutive pixels).  So
+//     A[m][(r,j)] = X[rowbase(m) + r*in_sr + j],   j in [0, Lk),  Lk = roundup(S*Cs, BKE)
+// and the filter is packed as B[k][(r,j)] with zeros where j >= S*Cs or c >= C.  One kernel
+// then serves every (R,S,stride,pad mode) and, through the output addressing
+// (out_base/out_sh/out_sw), the stride-2 sub-pixel phases of dgrad / ConvTranspose2d.
+//
+// MFMA: bf16 -> v_mfma_f32_32x32x16_bf16, fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32 fma
+// chain).  LDS tiles are [rows][64 B] with the 16-byte slot index XOR-swizzled by
+// (row>>3)&3 so that both the 16-B staging writes and the ds_read_b128 fragment reads are
+// bank-conflict free (MI355X_MICROARCH.md, LDS: b128 reads are served in 16-lane groups
+// over 64 banks).
+#include "common.h"
+
+#include <vector>
+
+namespace jpdse {
+
+// =========================================================================================
+// kernel arguments
+// =========================================================================================
+struct GemmFwdArgs {
+  const void* A;
+  const void* B;
+  const float* bias;
+  void* Y;
+  int M, OH, OW;
+  int Kout, Ks;
+  int R, cpr;  // filter rows, 64-byte chunks per filter row
+  int b_rows;
+  long long b_row_stride;  // elements
+  long long in_sn, in_sh, in_sw, in_sr, in_base;
+  long long out_sn, out_sh, out_sw, out_base;
+  int act;
+  float slope;
+};
+
+struct GemmWgradArgs {
+  const void* X;
+  const void* DY;
+  float* DW;
+  int M, OH, OW;
+  int K, Ks;  // dy logical / storage channels
+  int C, Cs;  // x  logical / storage channels
+  int R, S;
+  int run;    // S*Cs
+  int col_tiles_per_r;
+  long long in_sn, in_sh, in_sw, in_sr, in_base;
+  long long dy_sn, dy_sh, dy_sw, dy_base;
+  int chunks_total;
+  int chunks_per_split;
+  int atomic;
+};
+
+__device__ __forceinline__ int swz(int row, int slot) { return (row << 6) + (((slot ^ (row >> 3)) & 3) << 4); }
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  if (act == JPDSE_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == JPDSE_ACT_LRELU) return v > 0.f ? v : v * slope;
+  if (act == JPDSE_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// ---- MFMA over one 64-byte K chunk --------------------------------------------------------
+template <typename T, int TM, int TN> struct MmaChunk;
+
+template <int TM, int TN> struct MmaChunk<bf16_t, TM, TN> {
+  __device__ static __forceinline__ void run(const char* As, const char* Bs, const int (&a_rd)[TM][2],
+                                             const int (&b_rd)[TN][2], f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      s16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(As + a_rd[i][u]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(Bs + b_rd[j][u]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+
+template <int TM, int TN> struct MmaChunk<float, TM, TN> {
+  __device__ static __forceinline__ void run(const char* As, const char* Bs, const int (&a_rd)[TM][2],
+                                             const int (&b_rd)[TN][2], f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + a_rd[i][u]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + b_rd[j][u]);
+      // lanes 0-31 carry k = 4*(2u)+q, lanes 32-63 k = 4*(2u+1)+q: any k permutation is
+      // legal as long as A and B agree.
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+
+template <int TM, int TN, int BMW, int BNW>
+__device__ __forceinline__ void frag_offsets(int lane, int wm, int wn, int (&a_rd)[TM][2], int (&b_rd)[TN][2]) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = wm * BMW + i * 32 + r;
+    a_rd[i][0] = swz(row, h);
+    a_rd[i][1] = swz(row, 2 + h);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * BNW + j * 32 + r;
+    b_rd[j][0] = swz(row, h);
+    b_rd[j][1] = swz(row, 2 + h);
+  }
+}
+
+// =========================================================================================
+// forward / dgrad GEMM:  Y[m][k] = act( sum_{r,j} A[m][(r,j)] * B[k][(r,j)] + bias[k] )
+// =========================================================================================
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AV = (BM * 4 + NT - 1) / NT, BV = (BN * 4 + NT - 1) / NT;
+  constexpr int ES = sizeof(T);
+  static_assert((BM * 4) % NT == 0 || BM * 4 < NT, "A tile / threads");
+  static_assert((BN * 4) % NT == 0 || BN * 4 < NT, "B tile / threads");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const As = smem;                // [2][BM*64]
+  char* const Bs = smem + 2 * BM * 64;  // [2][BN*64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const char* a_ptr[AV];
+  int a_lds[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    int v = tid + i * NT;
+    v = v < BM * 4 ? v : BM * 4 - 1;  // surplus threads duplicate the last vector
+    const int row = v >> 2, slot = v & 3;
+    int m = m0 + row;
+    m = m < a.M ? m : a.M - 1;
+    const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
+    const long long off = a.in_base + n * a.in_sn + oh * a.in_sh + ow * a.in_sw;
+    a_ptr[i] = reinterpret_cast<const char*>(a.A) + off * ES + slot * 16;
+    a_lds[i] = swz(row, slot);
+  }
+  const char* b_ptr[BV];
+  int b_lds[BV];
+#pragma unroll
+  for (int i = 0; i < BV; ++i) {
+    int v = tid + i * NT;
+    v = v < BN * 4 ? v : BN * 4 - 1;
+    const int row = v >> 2, slot = v & 3;
+    int br = n0 + row;
+    br = br < a.b_rows ? br : a.b_rows - 1;
+    b_ptr[i] = reinterpret_cast<const char*>(a.B) + (long long)br * a.b_row_stride * ES + slot * 16;
+    b_lds[i] = swz(row, slot);
+  }
+
+  int a_rd[TM][2], b_rd[TN][2];
+  frag_offsets<TM, TN, BM / WM, BN / WN>(lane, wm, wn, a_rd, b_rd);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int T_total = a.R * a.cpr;
+  const long long a_row_bytes = a.in_sr * ES;
+  u32x4 areg[AV], breg[BV];
+  // chunk 0
+  {
+#pragma unroll
+    for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4*>(a_ptr[i]);
+#pragma unroll
+    for (int i = 0; i < BV; ++i) breg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i]);
+#pragma unroll
+    for (int i = 0; i < AV; ++i) *reinterpret_cast<u32x4*>(As + a_lds[i]) = areg[i];
+#pragma unroll
+    for (int i = 0; i < BV; ++i) *reinterpret_cast<u32x4*>(Bs + b_lds[i]) = breg[i];
+  }
+  __syncthreads();
+  int r = 0, jc = 0;
+  for (int t = 0; t < T_total; ++t) {
+    const int cur = t & 1;
+    const bool more = (t + 1) < T_total;
+    if (more) {
+      if (++jc == a.cpr) { jc = 0; ++r; }
+      const long long a_off = (long long)r * a_row_bytes + (long long)jc * 64;
+      const long long b_off = (long long)(t + 1) * 64;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + a_off);
+#pragma unroll
+      for (int i = 0; i < BV; ++i) breg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + b_off);
+    }
+    MmaChunk<T, TM, TN>::run(As + cur * BM * 64, Bs + cur * BN * 64, a_rd, b_rd, acc);
+    if (more) {
+      char* const An = As + (cur ^ 1) * BM * 64;
+      char* const Bn = Bs + (cur ^ 1) * BN * 64;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) *reinterpret_cast<u32x4*>(An + a_lds[i]) = areg[i];
+#pragma unroll
+      for (int i = 0; i < BV; ++i) *reinterpret_cast<u32x4*>(Bn + b_lds[i]) = breg[i];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation, NHWC store through the output addressing -------------
+  long long* const row_off = reinterpret_cast<long long*>(smem);
+  for (int row = tid; row < BM; row += NT) {
+    const int m = m0 + row;
+    long long off = -1;
+    if (m < a.M) {
+      const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
+      off = a.out_base + n * a.out_sn + oh * a.out_sh + ow * a.out_sw;
+    }
+    row_off[row] = off;
+  }
+  __syncthreads();
+  T* const Y = reinterpret_cast<T*>(a.Y);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+    if (col >= a.Ks) continue;
+    const bool live = col < a.Kout;
+    const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const long long off = row_off[row];
+        if (off < 0) continue;
+        float v = live ? apply_act(acc[i][j][e] + bv, a.act, a.slope) : 0.f;
+        ElemOps<T>::st(Y + off + col, v);
+      }
+    }
+  }
+}
+
+// =========================================================================================
+// weight-gradient GEMM: DW[k][(r,j)] = sum_m DY[m][k] * X[rowbase(m) + r*in_sr + j]
+// Both operands are transposed while being staged (pixels become the 64-byte K rows).
+// =========================================================================================
+template <typename T> struct WgStage;
+
+// bf16: one item = 2 adjacent pixels x 8 channels -> 8 packed (p, p+1) dwords
+template <> struct WgStage<bf16_t> {
+  static constexpr int PIX = 32;
+  template <int ROWS> static constexpr int items() { return (ROWS / 8) * 16; }
+  struct Regs { u32x4 lo, hi; };
+  template <int ROWS>
+  __device__ static __forceinline__ void decode(int id, int& cg, int& pp) { cg = id % (ROWS / 8); pp = id / (ROWS / 8); }
+  __device__ static __forceinline__ void write(char* lds, int cg, int pp, const Regs& rg) {
+    const int slot = pp >> 2, within = (pp & 3) << 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t lo = rg.lo[e], hi = rg.hi[e];
+      const uint32_t w0 = (lo & 0xffffu) | (hi << 16);
+      const uint32_t w1 = (lo >> 16) | (hi & 0xffff0000u);
+      const int row0 = cg * 8 + 2 * e, row1 = row0 + 1;
+      *reinterpret_cast<uint32_t*>(lds + swz(row0, slot) + within) = w0;
+      *reinterpret_cast<uint32_t*>(lds + swz(row1, slot) + within) = w1;
+    }
+  }
+};
+
+// fp32: one item = 1 pixel x 4 channels -> 4 dwords
+template <> struct WgStage<float> {
+  static constexpr int PIX = 16;
+  template <int ROWS> static constexpr int items() { return (ROWS / 4) * 16; }
+  struct Regs { u32x4 lo; };
+  template <int ROWS>
+  __device__ static __forceinline__ void decode(int id, int& cg, int& pp) { cg = id % (ROWS / 4); pp = id / (ROWS / 4); }
+  __device__ static __forceinline__ void write(char* lds, int cg, int pp, const Regs& rg) {
+    const int slot = pp >> 2, within = (pp & 3) << 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      *reinterpret_cast<uint32_t*>(lds + swz(cg * 4 + e, slot) + within) = rg.lo[e];
+  }
+};
+
+struct PixCursor {
+  int n, oh, ow;
+  __device__ __forceinline__ void init(int m, int OH, int OW) {
+    ow = m % OW;
+    const int t = m / OW;
+    oh = t % OH;
+    n = t / OH;
+  }
+  __device__ __forceinline__ void advance(int d, int OH, int OW) {
+    ow += d;
+    while (ow >= OW) {
+      ow -= OW;
+      if (++oh == OH) { oh = 0; ++n; }
+    }
+  }
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_kernel(const GemmWgradArgs a) {
+  using ST = WgStage<T>;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int ES = sizeof(T);
+  constexpr int PIX = ST::PIX;
+  constexpr int PSTEP = (ES == 2) ? 2 : 1;  // pixels per item
+  constexpr int CW = 16 / ES;               // channels per item
+  constexpr int AI = (ST::template items<BM>() + NT - 1) / NT;
+  constexpr int BI = (ST::template items<BN>() + NT - 1) / NT;
+  static_assert(ST::template items<BM>() % NT == 0 || ST::template items<BM>() < NT, "A items");
+  static_assert(ST::template items<BN>() % NT == 0 || ST::template items<BN>() < NT, "B items");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const As = smem;
+  char* const Bs = smem + 2 * BM * 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  // blockIdx.x -> (k tile, r, column tile)
+  const int ct = blockIdx.x % a.col_tiles_per_r;
+  const int t1 = blockIdx.x / a.col_tiles_per_r;
+  const int r = t1 % a.R;
+  const int kt = t1 / a.R;
+  const int k0 = kt * BM, j0 = ct * BN;
+  const int c_begin = blockIdx.y * a.chunks_per_split;
+  int c_end = c_begin + a.chunks_per_split;
+  c_end = c_end < a.chunks_total ? c_end : a.chunks_total;
+
+  // per-item state
+  bool a_on[AI], b_on[BI];
+  int a_cg[AI], a_pp[AI], b_cg[BI], b_pp[BI];
+  PixCursor a_cur[AI][PSTEP], b_cur[BI][PSTEP];
+  int a_m[AI], b_m[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int id = tid + i * NT;
+    a_on[i] = id < ST::template items<BM>();
+    ST::template decode<BM>(a_on[i] ? id : 0, a_cg[i], a_pp[i]);
+    a_m[i] = c_begin * PIX + a_pp[i] * PSTEP;
+#pragma unroll
+    for (int p = 0; p < PSTEP; ++p) {
+      int m = a_m[i] + p;
+      a_cur[i][p].init(m < a.M ? m : a.M - 1, a.OH, a.OW);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int id = tid + i * NT;
+    b_on[i] = id < ST::template items<BN>();
+    ST::template decode<BN>(b_on[i] ? id : 0, b_cg[i], b_pp[i]);
+    b_m[i] = c_begin * PIX + b_pp[i] * PSTEP;
+#pragma unroll
+    for (int p = 0; p < PSTEP; ++p) {
+      int m = b_m[i] + p;
+      b_cur[i][p].init(m < a.M ? m : a.M - 1, a.OH, a.OW);
+    }
+  }
+  // channel offsets (clamped so that every 16-byte load stays inside its pixel / run slack)
+  int a_ch[AI], b_col[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    int ch = k0 + a_cg[i] * CW;
+    a_ch[i] = ch < a.Ks ? ch : a.Ks - CW;  // rows >= Ks are never stored
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) b_col[i] = j0 + b_cg[i] * CW;
+
+  int a_rd[TM][2], b_rd[TN][2];
+  frag_offsets<TM, TN, BM / WM, BN / WN>(lane, wm, wn, a_rd, b_rd);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const T* const DY = reinterpret_cast<const T*>(a.DY);
+  const T* const X = reinterpret_cast<const T*>(a.X);
+  typename ST::Regs areg[AI], breg[BI];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      if (!a_on[i]) continue;
+#pragma unroll
+      for (int p = 0; p < PSTEP; ++p) {
+        const PixCursor& c = a_cur[i][p];
+        const long long off = a.dy_base + c.n * a.dy_sn + c.oh * a.dy_sh + c.ow * a.dy_sw + a_ch[i];
+        u32x4 v = *reinterpret_cast<const u32x4*>(DY + off);
+        if (a_m[i] + p >= a.M) v = zero4;  // pixels past the end contribute nothing
+        if (p == 0) areg[i].lo = v;
+        else reinterpret_cast<u32x4*>(&areg[i])[PSTEP - 1] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      if (!b_on[i]) continue;
+#pragma unroll
+      for (int p = 0; p < PSTEP; ++p) {
+        const PixCursor& c = b_cur[i][p];
+        const long long off = a.in_base + c.n * a.in_sn + c.oh * a.in_sh + c.ow * a.in_sw +
+                              (long long)r * a.in_sr + b_col[i];
+        u32x4 v = *reinterpret_cast<const u32x4*>(X + off);
+        if (p == 0) breg[i].lo = v;
+        else reinterpret_cast<u32x4*>(&breg[i])[PSTEP - 1] = v;
+      }
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      a_m[i] += PIX;
+#pragma unroll
+      for (int p = 0; p < PSTEP; ++p)
+        if (a_m[i] + p < a.M) a_cur[i][p].advance(PIX, a.OH, a.OW);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      b_m[i] += PIX;
+#pragma unroll
+      for (int p = 0; p < PSTEP; ++p)
+        if (b_m[i] + p < a.M) b_cur[i][p].advance(PIX, a.OH, a.OW);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      if (a_on[i]) ST::write(As + buf * BM * 64, a_cg[i], a_pp[i], areg[i]);
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      if (b_on[i]) ST::write(Bs + buf * BN * 64, b_cg[i], b_pp[i], breg[i]);
+  };
+
+  if (c_begin < c_end) {
+    load_chunk();
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    const int cur = (c - c_begin) & 1;
+    const bool more = (c + 1) < c_end;
+    if (more) {
+      advance();
+      load_chunk();
+    }
+    MmaChunk<T, TM, TN>::run(As + cur * BM * 64, Bs + cur * BN * 64, a_rd, b_rd, acc);
+    if (more) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: scatter the (k, r, j) tile into the fp32 KRSC master-layout gradient -----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = j0 + wn * (BN / WN) + j * 32 + (lane & 31);
+    if (col >= a.run) continue;
+    const int s = col / a.Cs, cc = col - s * a.Cs;
+    if (cc >= a.C) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = k0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (k >= a.K) continue;
+        float* dst = a.DW + (((long long)k * a.R + r) * a.S + s) * a.C + cc;
+        if (a.atomic) atomicAdd(dst, acc[i][j][e]);
+        else *dst = acc[i][j][e];
+      }
+    }
+  }
+}
+
+// =========================================================================================
+// padding (materialises the padded NHWC input + zeroed slack) and its reflect adjoint
+// =========================================================================================
+template <typename T>
+__global__ void pad_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W, int Cs,
+                           int pt, int pl, int Hp, int Wp, int mode, long long total_vec,
+                           long long slack_vec) {
+  constexpr int VE = 16 / sizeof(T);
+  const int cv = Cs / VE;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec + slack_vec;
+       idx += (long long)gridDim.x * blockDim.x) {
+    u32x4 v = zero4;
+    if (idx < total_vec) {
+      const int c = (int)(idx % cv);
+      long long t = idx / cv;
+      const int wp = (int)(t % Wp);
+      t /= Wp;
+      const int hp = (int)(t % Hp);
+      const int n = (int)(t / Hp);
+      int h = hp - pt, w = wp - pl;
+      bool ok = true;
+      if (mode == JPDSE_PAD_REFLECT) {
+        h = h < 0 ? -h : (h >= H ? 2 * (H - 1) - h : h);
+        w = w < 0 ? -w : (w >= W ? 2 * (W - 1) - w : w);
+      } else {
+        ok = (h >= 0) & (h < H) & (w >= 0) & (w < W);
+      }
+      if (ok) v = *reinterpret_cast<const u32x4*>(src + (((long long)n * H + h) * W + w) * Cs + c * VE);
+    }
+    *reinterpret_cast<u32x4*>(dst + idx * VE) = v;
+  }
+}
+
+// dx[h][w] = sum over the padded-domain aliases of (h,w) of dxp (adjoint of ReflectionPad2d(p))
+template <typename T>
+__global__ void reflect_fold_kernel(const T* __restrict__ dxp, T* __restrict__ dx, int N, int H, int W,
+                                    int Cs, int p, long long total_vec) {
+  constexpr int VE = 16 / sizeof(T);
+  const int cv = Cs / VE;
+  const int Hp = H + 2 * p, Wp = W + 2 * p;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv);
+    long long t = idx / cv;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + p;
+    if (h >= 1 && h <= p) hs[nh++] = p - h;
+    if (h <= H - 2 && h >= H - 1 - p) hs[nh++] = p + 2 * (H - 1) - h;
+    ws[nw++] = w + p;
+    if (w >= 1 && w <= p) ws[nw++] = p - w;
+    if (w <= W - 2 && w >= W - 1 - p) ws[nw++] = p + 2 * (W - 1) - w;
+    float accv[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) accv[e] = 0.f;
+    for (int a = 0; a < nh; ++a)
+      for (int b = 0; b < nw; ++b) {
+        float v[VE];
+        Vec16<T>::load(dxp + (((long long)n * Hp + hs[a]) * Wp + ws[b]) * Cs + c * VE, v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) accv[e] += v[e];
+      }
+    Vec16<T>::store(dx + idx * VE, accv);
+  }
+}
+
+// =========================================================================================
+// filter packing: fp32 KRSC master -> compute-dtype GEMM panels
+// =========================================================================================
+template <typename T>
+__global__ void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int Ks, int C, int Cs,
+                                int R, int S, int Lk, long long total) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % Lk);
+    long long t = idx / Lk;
+    const int r = (int)(t % R);
+    const int k = (int)(t / R);
+    const int s = j / Cs, c = j - s * Cs;
+    float v = 0.f;
+    if (k < K && s < S && c < C) v = w[(((long long)k * R + r) * S + s) * C + c];
+    ElemOps<T>::st(out + idx, v);
+  }
+}
+
+// one stride phase of the data-gradient panel: rows = input channels c, K-dim = (u', w', k)
+template <typename T>
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int Ks, int C, int Cs,
+                                  int R, int S, int st, int qh, int qw, int Uh, int Uw, int Lk,
+                                  long long total) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % Lk);
+    long long t = idx / Lk;
+    const int up = (int)(t % Uh);
+    const int c = (int)(t / Uh);
+    const int wp = j / Ks, k = j - wp * Ks;
+    float v = 0.f;
+    if (c < C && k < K && wp < Uw) {
+      const int r = qh + st * (Uh - 1 - up), s = qw + st * (Uw - 1 - wp);
+      v = w[(((long long)k * R + r) * S + s) * C + c];
+    }
+    ElemOps<T>::st(out + idx, v);
+  }
+}
+
+// =========================================================================================
+// host side: planning and launch
+// =========================================================================================
+static constexpr size_t kSlackBytes = 2048;  // readable, zeroed tail after every padded tensor
+
+static inline int bke(int dtype) { return dtype == JPDSE_BF16 ? 32 : 16; }  // elements per 64-byte chunk
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static int validate(const jpdse_conv_desc* d) {
+  JPDSE_REQUIRE(d != nullptr, "conv: null descriptor");
+  JPDSE_REQUIRE(d->dtype == JPDSE_F32 || d->dtype == JPDSE_BF16, "conv: bad dtype %d", d->dtype);
+  JPDSE_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0, "conv: non-positive shape");
+  JPDSE_REQUIRE(d->R > 0 && d->S > 0 && d->R <= 16 && d->S <= 16, "conv: filter %dx%d unsupported", d->R, d->S);
+  JPDSE_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d unsupported", d->stride);
+  JPDSE_REQUIRE(d->R >= d->stride && d->S >= d->stride, "conv: filter smaller than stride");
+  JPDSE_REQUIRE(d->pad >= 0, "conv: negative pad");
+  JPDSE_REQUIRE(d->pad_mode == JPDSE_PAD_ZERO || d->pad_mode == JPDSE_PAD_REFLECT, "conv: bad pad mode");
+  if (d->pad_mode == JPDSE_PAD_REFLECT) {
+    JPDSE_REQUIRE(d->stride == 1, "conv: reflect padding requires stride 1");
+    JPDSE_REQUIRE(d->pad < d->H && d->pad < d->W, "conv: reflect pad %d >= image dim", d->pad);
+  }
+  JPDSE_REQUIRE(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "conv: image smaller than filter");
+  return JPDSE_OK;
+}
+
+struct Phase {
+  int qh, qw, Uh, Uw;
+  int i0h, cnth, i0w, cntw;
+  int Lk;
+  size_t pack_off;  // bytes
+};
+
+struct ConvPlan {
+  int ES, BKE;
+  int Cs, Ks, Hp, Wp, OH, OW;
+  int Lk_fwd;
+  // dgrad
+  int nph;
+  Phase ph[4];
+  int PT, PB, PL, PR;  // zero padding of dy
+  int DH, DW;          // padded dy dims
+  size_t dgrad_pack_bytes;
+  size_t xpad_bytes, dypad_bytes, dxp_bytes;
+};
+
+static void phase_axis(int st, int q, int Rf, int lo, int hi, int& U, int& i0, int& cnt) {
+  U = (Rf - q + st - 1) / st;
+  auto ceil_div = [](int a, int b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); };
+  i0 = ceil_div(lo - q, st);
+  const int i1 = ceil_div(hi - q, st);
+  cnt = i1 - i0;
+  if (cnt < 0) cnt = 0;
+}
+
+static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
+  p->ES = (int)esize(d->dtype);
+  p->BKE = bke(d->dtype);
+  p->Cs = cpad(d->C);
+  p->Ks = cpad(d->K);
+  p->Hp = d->H + 2 * d->pad;
+  p->Wp = d->W + 2 * d->pad;
+  p->OH = (p->Hp - d->R) / d->stride + 1;
+  p->OW = (p->Wp - d->S) / d->stride + 1;
+  p->Lk_fwd = round_up(d->S * p->Cs, p->BKE);
+  const int st = d->stride;
+  const bool refl = d->pad_mode == JPDSE_PAD_REFLECT;
+  const int lo_h = refl ? 0 : d->pad, hi_h = refl ? p->Hp : d->pad + d->H;
+  const int lo_w = refl ? 0 : d->pad, hi_w = refl ? p->Wp : d->pad + d->W;
+  p->nph = 0;
+  int min_h = 0, max_h = p->OH - 1, min_w = 0, max_w = p->OW - 1;
+  size_t off = 0;
+  for (int qh = 0; qh < st; ++qh)
+    for (int qw = 0; qw < st; ++qw) {
+      Phase& f = p->ph[p->nph++];
+      f.qh = qh;
+      f.qw = qw;
+      phase_axis(st, qh, d->R, lo_h, hi_h, f.Uh, f.i0h, f.cnth);
+      phase_axis(st, qw, d->S, lo_w, hi_w, f.Uw, f.i0w, f.cntw);
+      f.Lk = round_up(f.Uw * p->Ks, p->BKE);
+      f.pack_off = off;
+      off += (size_t)p->Cs * f.Uh * f.Lk * p->ES;
+      off = align_up(off, 256);
+      if (f.cnth > 0 && f.cntw > 0) {
+        min_h = min_h < f.i0h - (f.Uh - 1) ? min_h : f.i0h - (f.Uh - 1);
+        max_h = max_h > f.i0h + f.cnth - 1 ? max_h : f.i0h + f.cnth - 1;
+        min_w = min_w < f.i0w - (f.Uw - 1) ? min_w : f.i0w - (f.Uw - 1);
+        max_w = max_w > f.i0w + f.cntw - 1 ? max_w : f.i0w + f.cntw - 1;
+      }
+    }
+  p->dgrad_pack_bytes = off;
+  p->PT = -min_h;
+  p->PB = max_h - (p->OH - 1);
+  p->PL = -min_w;
+  p->PR = max_w - (p->OW - 1);
+  p->DH = p->OH + p->PT + p->PB;
+  p->DW = p->OW + p->PL + p->PR;
+  p->xpad_bytes = align_up((size_t)d->N * p->Hp * p->Wp * p->Cs * p->ES + kSlackBytes, 256);
+  p->dypad_bytes = align_up((size_t)d->N * p->DH * p->DW * p->Ks * p->ES + kSlackBytes, 256);
+  p->dxp_bytes = refl ? align_up((size_t)d->N * p->Hp * p->Wp * p->Cs * p->ES, 256) : 0;
+}
+
+template <typename T>
+static int launch_pad(const void* src, void* dst, int N, int H, int W, int Cs, int pt, int pb, int pl, int pr,
+                      int mode, hipStream_t s) {
+  const int Hp = H + pt + pb, Wp = W + pl + pr;
+  const int VE = 16 / (int)sizeof(T);
+  const long long total_vec = (long long)N * Hp * Wp * (Cs / VE);
+  const long long slack_vec = kSlackBytes / 16;
+  hipLaunchKernelGGL((pad_kernel<T>), dim3(ew_blocks(total_vec + slack_vec)), dim3(256), 0, s,
+                     reinterpret_cast<const T*>(src), reinterpret_cast<T*>(dst), N, H, W, Cs, pt, pl, Hp, Wp,
+                     mode, total_vec, slack_vec);
+  return check_launch("pad_kernel");
+}
+
+// ---- in-library kernel timer (bench.py "roofline"): hipEvent pairs around the GEMM launches whose
+// (N, K) signature was selected, recorded on the stream the kernel runs on.
+struct GemmProf {
+  bool on = false;
+  int Ks = 0;
+  long long kdim = 0;
+  int used = 0;
+  std::vector<hipEvent_t> ev;   // 2 per launch
+  std::vector<double> flops;
+};
+static GemmProf g_prof;
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_fwd_cfg(const GemmFwdArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Ks + BN - 1) / BN;
+  const size_t lds = 2 * (BM + BN) * 64;
+  const long long kdim = (long long)a.R * a.cpr * (64 / (int)sizeof(T));
+  const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
+                     (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  hipLaunchKernelGGL((gemm_fwd_kernel<T, BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a);
+  if (timed) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
+    g_prof.flops[g_prof.used] = 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
+    ++g_prof.used;
+  }
+  return check_launch("gemm_fwd_kernel");
+}
+
+template <typename T>
+static int launch_fwd(const GemmFwdArgs& a, hipStream_t s) {
+  if (a.M <= 0) return JPDSE_OK;
+  if (a.Ks > 64) return launch_fwd_cfg<T, 128, 128, 2, 2>(a, s);
+  if (a.Ks > 32) return launch_fwd_cfg<T, 128, 64, 2, 2>(a, s);
+  return launch_fwd_cfg<T, 256, 32, 4, 1>(a, s);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_wgrad_cfg(GemmWgradArgs a, hipStream_t s) {
+  const int PIX = WgStage<T>::PIX;
+  a.col_tiles_per_r = (a.run + BN - 1) / BN;
+  a.chunks_total = (a.M + PIX - 1) / PIX;
+  const int tiles = ((a.K + BM - 1) / BM) * a.R * a.col_tiles_per_r;
+  int splits = 1;
+  if (tiles < 512) {
+    splits = (768 + tiles - 1) / tiles;
+    const int max_splits = (a.chunks_total + 7) / 8;  // >= 8 chunks of work per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  a.chunks_per_split = (a.chunks_total + splits - 1) / splits;
+  splits = (a.chunks_total + a.chunks_per_split - 1) / a.chunks_per_split;
+  a.atomic = splits > 1;
+  if (a.atomic) {
+    hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), s);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
+  }
+  const size_t lds = 2 * (BM + BN) * 64;
+  hipLaunchKernelGGL((gemm_wgrad_kernel<T, BM, BN, WM, WN>), dim3(tiles, splits), dim3(64 * WM * WN), lds, s, a);
+  return check_launch("gemm_wgrad_kernel");
+}
+
+template <typename T>
+static int launch_wgrad(const GemmWgradArgs& a, hipStream_t s) {
+  if (a.K > 64) return launch_wgrad_cfg<T, 128, 128, 2, 2>(a, s);
+  if (a.K > 32) return launch_wgrad_cfg<T, 64, 128, 2, 2>(a, s);
+  return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, s);
+}
+
+template <typename T>
+static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
+                      const float* bias, void* y, void* ws, hipStream_t s) {
+  // always staged through the workspace: the GEMM loaders rely on the zeroed slack behind it
+  if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+    return rc;
+  const void* xin = ws;
+  GemmFwdArgs a = {};
+  a.A = xin;
+  a.B = pack;
+  a.bias = bias;
+  a.Y = y;
+  a.M = d->N * p.OH * p.OW;
+  a.OH = p.OH;
+  a.OW = p.OW;
+  a.Kout = d->K;
+  a.Ks = p.Ks;
+  a.R = d->R;
+  a.cpr = p.Lk_fwd / p.BKE;
+  a.b_rows = p.Ks;
+  a.b_row_stride = (long long)d->R * p.Lk_fwd;
+  a.in_sn = (long long)p.Hp * p.Wp * p.Cs;
+  a.in_sh = (long long)d->stride * p.Wp * p.Cs;
+  a.in_sw = (long long)d->stride * p.Cs;
+  a.in_sr = (long long)p.Wp * p.Cs;
+  a.in_base = 0;
+  a.out_sn = (long long)p.OH * p.OW * p.Ks;
+  a.out_sh = (long long)p.OW * p.Ks;
+  a.out_sw = p.Ks;
+  a.out_base = 0;
+  a.act = d->act;
+  a.slope = d->slope;
+  return launch_fwd<T>(a, s);
+}
+
+template <typename T>
+static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx,
+                        void* ws, hipStream_t s) {
+  char* wsb = reinterpret_cast<char*>(ws);
+  void* dyp = wsb;
+  void* dxp = wsb + p.dypad_bytes;
+  const bool refl = d->pad_mode == JPDSE_PAD_REFLECT;
+  int rc = launch_pad<T>(dy, dyp, d->N, p.OH, p.OW, p.Ks, p.PT, p.PB, p.PL, p.PR, JPDSE_PAD_ZERO, s);
+  if (rc) return rc;
+  const int st = d->stride;
+  for (int i = 0; i < p.nph; ++i) {
+    const Phase& f = p.ph[i];
+    if (f.cnth <= 0 || f.cntw <= 0) continue;
+    GemmFwdArgs a = {};
+    a.A = dyp;
+    a.B = reinterpret_cast<const char*>(pack) + f.pack_off;
+    a.bias = nullptr;
+    a.M = d->N * f.cnth * f.cntw;
+    a.OH = f.cnth;
+    a.OW = f.cntw;
+    a.Kout = d->C;
+    a.Ks = p.Cs;
+    a.R = f.Uh;
+    a.cpr = f.Lk / p.BKE;
+    a.b_rows = p.Cs;
+    a.b_row_stride = (long long)f.Uh * f.Lk;
+    a.in_sn = (long long)p.DH * p.DW * p.Ks;
+    a.in_sh = (long long)p.DW * p.Ks;
+    a.in_sw = p.Ks;
+    a.in_sr = (long long)p.DW * p.Ks;
+    a.in_base = ((long long)(f.i0h + p.PT - (f.Uh - 1)) * p.DW + (f.i0w + p.PL - (f.Uw - 1))) * p.Ks;
+    if (refl) {
+      a.Y = dxp;
+      a.out_sn = (long long)p.Hp * p.Wp * p.Cs;
+      a.out_sh = (long long)st * p.Wp * p.Cs;
+      a.out_sw = (long long)st * p.Cs;
+      a.out_base = ((long long)(st * f.i0h + f.qh) * p.Wp + (st * f.i0w + f.qw)) * p.Cs;
+    } else {
+      a.Y = dx;
+      a.out_sn = (long long)d->H * d->W * p.Cs;
+      a.out_sh = (long long)st * d->W * p.Cs;
+      a.out_sw = (long long)st * p.Cs;
+      a.out_base = ((long long)(st * f.i0h + f.qh - d->pad) * d->W + (st * f.i0w + f.qw - d->pad)) * p.Cs;
+    }
+    a.act = JPDSE_ACT_NONE;
+    a.slope = 0.f;
+    rc = launch_fwd<T>(a, s);
+    if (rc) return rc;
+  }
+  if (refl) {
+    const int VE = 16 / (int)sizeof(T);
+    const long long total_vec = (long long)d->N * d->H * d->W * (p.Cs / VE);
+    hipLaunchKernelGGL((reflect_fold_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s,
+                       reinterpret_cast<const T*>(dxp), reinterpret_cast<T*>(dx), d->N, d->H, d->W, p.Cs, d->pad,
+                       total_vec);
+    rc = check_launch("reflect_fold_kernel");
+  }
+  return rc;
+}
+
+template <typename T>
+static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* dy, float* dw,
+                        void* ws, hipStream_t s) {
+  // always staged through the workspace: the GEMM loaders rely on the zeroed slack behind it
+  if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+    return rc;
+  const void* xin = ws;
+  GemmWgradArgs a = {};
+  a.X = xin;
+  a.DY = dy;
+  a.DW = dw;
+  a.M = d->N * p.OH * p.OW;
+  a.OH = p.OH;
+  a.OW = p.OW;
+  a.K = d->K;
+  a.Ks = p.Ks;
+  a.C = d->C;
+  a.Cs = p.Cs;
+  a.R = d->R;
+  a.S = d->S;
+  a.run = d->S * p.Cs;
+  a.in_sn = (long long)p.Hp * p.Wp * p.Cs;
+  a.in_sh = (long long)d->stride * p.Wp * p.Cs;
+  a.in_sw = (long long)d->stride * p.Cs;
+  a.in_sr = (long long)p.Wp * p.Cs;
+  a.in_base = 0;
+  a.dy_sn = (long long)p.OH * p.OW * p.Ks;
+  a.dy_sh = (long long)p.OW * p.Ks;
+  a.dy_sw = p.Ks;
+  a.dy_base = 0;
+  return launch_wgrad<T>(a, s);
+}
+
+}  // namespace jpdse
+
+using namespace jpdse;
+
+extern "C" {
+
+int jpdse_conv_out_shape(const jpdse_conv_desc* d, int32_t* OH, int32_t* OW) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(OH && OW, "conv_out_shape: null output");
+  ConvPlan p;
+  make_plan(d, &p);
+  *OH = p.OH;
+  *OW = p.OW;
+  return JPDSE_OK;
+}
+
+int jpdse_prof_select(int32_t enable, int32_t Ks, int64_t kdim, int32_t max_launches) {
+  g_prof.on = false;
+  g_prof.used = 0;
+  if (!enable) return JPDSE_OK;
+  JPDSE_REQUIRE(Ks > 0 && kdim > 0 && max_launches > 0, "prof_select: bad selection");
+  while ((int)g_prof.ev.size() < 2 * max_launches) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return set_error(JPDSE_ELAUNCH, "prof_select: hipEventCreate failed");
+    g_prof.ev.push_back(e);
+  }
+  g_prof.flops.assign(max_launches, 0.0);
+  g_prof.Ks = Ks;
+  g_prof.kdim = kdim;
+  g_prof.on = true;
+  return JPDSE_OK;
+}
+
+int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
+  JPDSE_REQUIRE(total_ms && total_flops && launches, "prof_collect: null output");
+  double ms = 0.0, fl = 0.0;
+  for (int i = 0; i < g_prof.used; ++i) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess)
+      return set_error(JPDSE_ELAUNCH, "prof_collect: hipEventSynchronize failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+      return set_error(JPDSE_ELAUNCH, "prof_collect: hipEventElapsedTime failed");
+    ms += t;
+    fl += g_prof.flops[i];
+  }
+  *total_ms = ms;
+  *total_flops = fl;
+  *launches = g_prof.used;
+  g_prof.used = 0;
+  return JPDSE_OK;
+}
+
+int jpdse_conv_plan_query(const jpdse_conv_desc* d, int32_t* out, int32_t n) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(out != nullptr && n >= 14 + 4 * 10, "conv_plan_query: need room for 54 int32");
+  ConvPlan p;
+  make_plan(d, &p);
+  int32_t head[14] = {p.Cs, p.Ks, p.Hp, p.Wp, p.OH, p.OW, p.Lk_fwd, p.nph, p.PT, p.PB, p.PL, p.PR, p.DH, p.DW};
+  for (int i = 0; i < 14; ++i) out[i] = head[i];
+  for (int i = 0; i < 4; ++i) {
+    int32_t* o = out + 14 + i * 10;
+    if (i < p.nph) {
+      const Phase& f = p.ph[i];
+      int32_t v[10] = {f.qh, f.qw, f.Uh, f.Uw, f.i0h, f.cnth, f.i0w, f.cntw, f.Lk, (int32_t)f.pack_off};
+      for (int j = 0; j < 10; ++j) o[j] = v[j];
+    } else {
+      for (int j = 0; j < 10; ++j) o[j] = 0;
+    }
+  }
+  return JPDSE_OK;
+}
+
+size_t jpdse_conv_fwd_pack_size(const jpdse_conv_desc* d) {
+  if (validate(d)) return 0;
+  ConvPlan p;
+  make_plan(d, &p);
+  return align_up((size_t)p.Ks * d->R * p.Lk_fwd * p.ES, 256);
+}
+
+size_t jpdse_conv_dgrad_pack_size(const jpdse_conv_desc* d) {
+  if (validate(d)) return 0;
+  ConvPlan p;
+  make_plan(d, &p);
+  return p.dgrad_pack_bytes;
+}
+
+size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
+  if (validate(d)) return 0;
+  ConvPlan p;
+  make_plan(d, &p);
+  const size_t fwd = p.xpad_bytes;
+  const size_t dgrad = p.dypad_bytes + p.dxp_bytes;
+  return fwd > dgrad ? fwd : dgrad;
+}
+
+int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w, void* fwd_pack, void* dgrad_pack,
+                            void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(w != nullptr, "conv_pack_weights: null master weights");
+  ConvPlan p;
+  make_plan(d, &p);
+  hipStream_t s = as_stream(stream);
+  if (fwd_pack) {
+    const long long total = (long long)p.Ks * d->R * p.Lk_fwd;
+    if (d->dtype == JPDSE_BF16)
+      hipLaunchKernelGGL((pack_fwd_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
+                         reinterpret_cast<bf16_t*>(fwd_pack), d->K, p.Ks, d->C, p.Cs, d->R, d->S, p.Lk_fwd, total);
+    else
+      hipLaunchKernelGGL((pack_fwd_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
+                         reinterpret_cast<float*>(fwd_pack), d->K, p.Ks, d->C, p.Cs, d->R, d->S, p.Lk_fwd, total);
+    if (int rc = check_launch("pack_fwd_kernel")) return rc;
+  }
+  if (dgrad_pack) {
+    for (int i = 0; i < p.nph; ++i) {
+      const Phase& f = p.ph[i];
+      const long long total = (long long)p.Cs * f.Uh * f.Lk;
+      if (total == 0) continue;
+      char* out = reinterpret_cast<char*>(dgrad_pack) + f.pack_off;
+      if (d->dtype == JPDSE_BF16)
+        hipLaunchKernelGGL((pack_dgrad_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
+                           reinterpret_cast<bf16_t*>(out), d->K, p.Ks, d->C, p.Cs, d->R, d->S, d->stride, f.qh,
+                           f.qw, f.Uh, f.Uw, f.Lk, total);
+      else
+        hipLaunchKernelGGL((pack_dgrad_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
+                           reinterpret_cast<float*>(out), d->K, p.Ks, d->C, p.Cs, d->R, d->S, d->stride, f.qh, f.qw,
+                           f.Uh, f.Uw, f.Lk, total);
+      if (int rc = check_launch("pack_dgrad_kernel")) return rc;
+    }
+  }
+  return JPDSE_OK;
+}
+
+int jpdse_conv_fwd(const jpdse_conv_desc* d, const void* x, const void* fwd_pack, const float* bias, void* y,
+                   void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(x && fwd_pack && y, "conv_fwd: null pointer");
+  ConvPlan p;
+  make_plan(d, &p);
+  if (ws == nullptr || ws_bytes < p.xpad_bytes)
+    return set_error(JPDSE_EWORKSPACE, "conv_fwd: workspace %zu < %zu", ws_bytes, p.xpad_bytes);
+  return d->dtype == JPDSE_BF16 ? conv_fwd_t<bf16_t>(d, p, x, fwd_pack, bias, y, ws, as_stream(stream))
+                                : conv_fwd_t<float>(d, p, x, fwd_pack, bias, y, ws, as_stream(stream));
+}
+
+int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, void* dx, void* ws,
+                     size_t ws_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(dy && dgrad_pack && dx, "conv_dgrad: null pointer");
+  ConvPlan p;
+  make_plan(d, &p);
+  const size_t need = p.dypad_bytes + p.dxp_bytes;
+  if (ws == nullptr || ws_bytes < need) return set_error(JPDSE_EWORKSPACE, "conv_dgrad: workspace %zu < %zu", ws_bytes, need);
+  return d->dtype == JPDSE_BF16 ? conv_dgrad_t<bf16_t>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream))
+                                : conv_dgrad_t<float>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream));
+}
+
+int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,
+                     void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(x && dy && dw, "conv_wgrad: null pointer");
+  ConvPlan p;
+  make_plan(d, &p);
+  if (ws == nullptr || ws_bytes < p.xpad_bytes)
+    return set_error(JPDSE_EWORKSPACE, "conv_wgrad: workspace %zu < %zu", ws_bytes, p.xpad_bytes);
+  return d->dtype == JPDSE_BF16 ? conv_wgrad_t<bf16_t>(d, p, x, dy, dw, ws, as_stream(stream))
+                                : conv_wgrad_t<float>(d, p, x, dy, dw, ws, as_stream(stream));
+}
+
+// nn.ConvTranspose2d == the data-gradient of the Conv2d described by `d` (see jpdse.h)
+int jpdse_convT_fwd(const jpdse_conv_desc* d, const void* x, const void* dgrad_pack, void* y, void* ws,
+                    size_t ws_bytes, void* stream) {
+  return jpdse_conv_dgrad(d, x, dgrad_pack, y, ws, ws_bytes, stream);
+}
+int jpdse_convT_dgrad(const jpdse_conv_desc* d, const void* dy, const void* fwd_pack, void* dx, void* ws,
+                      size_t ws_bytes, void* stream) {
+  return jpdse_conv_fwd(d, dy, fwd_pack, nullptr, dx, ws, ws_bytes, stream);
+}
+int jpdse_convT_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw, void* ws,
+                      size_t ws_bytes, void* stream) {
+  return jpdse_conv_wgrad(d, dy, x, dw, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

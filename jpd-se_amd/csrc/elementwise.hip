@@ -1,0 +1,729 @@
+// HBM-bound kernels of the JPD-SE train step: pooling, activation backward, gradient fan-in,
+// channel concat/slice, bias-gradient sums, API-boundary layout conversion, the
+// one-hot/edge input builder, loss reductions and fused multi-tensor Adam.
+// Reference call sites are listed per entry point in include/jpdse.h.
+// All kernels move 16-byte vectors per lane along the contiguous NHWC channel axis.
+#include "common.h"
+
+namespace jpdse {
+
+#define GRID_STRIDE(idx, total)                                                         \
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < (total); \
+       idx += (long long)gridDim.x * blockDim.x)
+
+// ---- pooling ------------------------------------------------------------------------------
+template <typename T>
+__global__ void avgpool3s2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int OH, int OW,
+                                      int Cs, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = Cs / VE;
+  GRID_STRIDE(idx, total_vec) {
+    const int c = (int)(idx % cv);
+    long long t = idx / cv;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    int cnt = 0;
+    for (int r = 0; r < 3; ++r) {
+      const int ih = 2 * oh - 1 + r;
+      if (ih < 0 || ih >= H) continue;
+      for (int s = 0; s < 3; ++s) {
+        const int iw = 2 * ow - 1 + s;
+        if (iw < 0 || iw >= W) continue;
+        float v[VE];
+        Vec16<T>::load(x + (((long long)n * H + ih) * W + iw) * Cs + c * VE, v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += v[e];
+        ++cnt;
+      }
+    }
+    const float inv = 1.f / (float)cnt;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] *= inv;
+    Vec16<T>::store(y + idx * VE, acc);
+  }
+}
+
+__device__ __forceinline__ int win_count(int o, int L) {  // valid taps of window o along a length-L axis
+  const int lo = 2 * o - 1, hi = 2 * o + 1;
+  return (hi < L ? hi : L - 1) - (lo > 0 ? lo : 0) + 1;
+}
+
+template <typename T>
+__global__ void avgpool3s2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int OH, int OW,
+                                      int Cs, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = Cs / VE;
+  GRID_STRIDE(idx, total_vec) {
+    const int c = (int)(idx % cv);
+    long long t = idx / cv;
+    const int iw = (int)(t % W);
+    t /= W;
+    const int ih = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    const int oh0 = ih / 2, oh1 = (ih + 1) / 2;  // ceil((ih-1)/2) .. floor((ih+1)/2)
+    const int ow0 = iw / 2, ow1 = (iw + 1) / 2;
+    for (int oh = oh0; oh <= oh1; ++oh) {
+      if (oh >= OH) continue;
+      for (int ow = ow0; ow <= ow1; ++ow) {
+        if (ow >= OW) continue;
+        const float inv = 1.f / (float)(win_count(oh, H) * win_count(ow, W));
+        float v[VE];
+        Vec16<T>::load(dy + (((long long)n * OH + oh) * OW + ow) * Cs + c * VE, v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += v[e] * inv;
+      }
+    }
+    Vec16<T>::store(dx + idx * VE, acc);
+  }
+}
+
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int OH, int OW, int Cs,
+                                    long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = Cs / VE;
+  GRID_STRIDE(idx, total_vec) {
+    const int c = (int)(idx % cv);
+    long long t = idx / cv;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const T* p = x + (((long long)n * H + 2 * oh) * W + 2 * ow) * Cs + c * VE;
+    float a[VE], b[VE], cc[VE], d[VE];
+    Vec16<T>::load(p, a);
+    Vec16<T>::load(p + Cs, b);
+    Vec16<T>::load(p + (long long)W * Cs, cc);
+    Vec16<T>::load(p + (long long)W * Cs + Cs, d);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) a[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(cc[e], d[e]));
+    Vec16<T>::store(y + idx * VE, a);
+  }
+}
+
+// gradient goes to the FIRST maximal element of each window in row-major order (torch semantics)
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int H,
+                                    int W, int OH, int OW, int Cs, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = Cs / VE;
+  GRID_STRIDE(idx, total_vec) {
+    const int c = (int)(idx % cv);
+    long long t = idx / cv;
+    const int iw = (int)(t % W);
+    t /= W;
+    const int ih = (int)(t % H);
+    const int n = (int)(t / H);
+    float out[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) out[e] = 0.f;
+    const int oh = ih >> 1, ow = iw >> 1;
+    if (oh < OH && ow < OW) {
+      const T* p = x + (((long long)n * H + 2 * oh) * W + 2 * ow) * Cs + c * VE;
+      float w[4][VE], g[VE];
+      Vec16<T>::load(p, w[0]);
+      Vec16<T>::load(p + Cs, w[1]);
+      Vec16<T>::load(p + (long long)W * Cs, w[2]);
+      Vec16<T>::load(p + (long long)W * Cs + Cs, w[3]);
+      Vec16<T>::load(dy + (((long long)n * OH + oh) * OW + ow) * Cs + c * VE, g);
+      const int me = (ih & 1) * 2 + (iw & 1);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        int best = 0;
+        float bv = w[0][e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+          if (w[k][e] > bv) { bv = w[k][e]; best = k; }
+        out[e] = (best == me) ? g[e] : 0.f;
+      }
+    }
+    Vec16<T>::store(dx + idx * VE, out);
+  }
+}
+
+// ---- activation backward / add / zero ----------------------------------------------------------
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dz, int act,
+                               float slope, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  GRID_STRIDE(idx, total_vec) {
+    float a[VE], g[VE];
+    Vec16<T>::load(y + idx * VE, a);
+    Vec16<T>::load(dy + idx * VE, g);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      float d = 1.f;
+      if (act == JPDSE_ACT_RELU) d = a[e] > 0.f ? 1.f : 0.f;
+      else if (act == JPDSE_ACT_LRELU) d = a[e] > 0.f ? 1.f : slope;
+      else if (act == JPDSE_ACT_TANH) d = 1.f - a[e] * a[e];
+      g[e] *= d;
+    }
+    Vec16<T>::store(dz + idx * VE, g);
+  }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  GRID_STRIDE(idx, total_vec) {
+    float x[VE], y[VE];
+    Vec16<T>::load(a + idx * VE, x);
+    Vec16<T>::load(b + idx * VE, y);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) x[e] += y[e];
+    Vec16<T>::store(out + idx * VE, x);
+  }
+}
+
+// ---- channel sum / copy ---------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ dy, float* __restrict__ partial,
+                                                         long long npix, int Cs, int TX, int TY, long long pix_per_blk) {
+  constexpr int VE = Vec16<T>::N;
+  __shared__ float red[256 * VE];
+  const int cv = Cs / VE;
+  const int col_blocks = (cv + TX - 1) / TX;
+  const int cb = blockIdx.x % col_blocks;
+  const long long pb = blockIdx.x / col_blocks;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int col = cb * TX + tx;
+  float s[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) s[e] = 0.f;
+  if (col < cv) {
+    const long long p0 = pb * pix_per_blk;
+    long long p1 = p0 + pix_per_blk;
+    p1 = p1 < npix ? p1 : npix;
+    for (long long p = p0 + ty; p < p1; p += TY) {
+      float v[VE];
+      Vec16<T>::load(dy + p * Cs + col * VE, v);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) s[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VE; ++e) red[threadIdx.x * VE + e] = s[e];
+  __syncthreads();
+  if (ty == 0 && col < cv) {
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      float a = 0.f;
+      for (int y = 0; y < TY; ++y) a += red[(y * TX + tx) * VE + e];
+      partial[pb * Cs + col * VE + e] = a;
+    }
+  }
+}
+
+__global__ void channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int Cs, int nblk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cs) return;
+  float a = 0.f;
+  for (int b = 0; b < nblk; ++b) a += partial[(long long)b * Cs + c];
+  out[c] = a;
+}
+
+template <typename T>
+__global__ void channel_copy_kernel(const T* __restrict__ src, int src_cs, int src_c0, T* __restrict__ dst, int dst_cs,
+                                    int dst_c0, int nch, long long total) {
+  GRID_STRIDE(idx, total) {
+    const int i = (int)(idx % nch);
+    const long long p = idx / nch;
+    dst[p * dst_cs + dst_c0 + i] = src[p * src_cs + src_c0 + i];
+  }
+}
+
+// ---- layout conversion ---------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int Cs, long long HW,
+                                    long long total) {
+  // idx enumerates (n, c_storage, pixel) with the pixel fastest: coalesced reads of one plane
+  GRID_STRIDE(idx, total) {
+    const long long p = idx % HW;
+    long long t = idx / HW;
+    const int c = (int)(t % Cs);
+    const long long n = t / Cs;
+    const float v = c < C ? src[(n * C + c) * HW + p] : 0.f;
+    ElemOps<T>::st(dst + (n * HW + p) * Cs + c, v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C, int Cs, long long HW,
+                                    long long total) {
+  GRID_STRIDE(idx, total) {
+    const long long p = idx % HW;
+    long long t = idx / HW;
+    const int c = (int)(t % C);
+    const long long n = t / C;
+    dst[idx] = ElemOps<T>::ld(src + (n * HW + p) * Cs + c);
+  }
+}
+
+template <typename T>
+__global__ void onehot_edge_kernel(const float* __restrict__ label, const long long* __restrict__ inst,
+                                   T* __restrict__ dst, int H, int W, int nlab, int cs, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = cs / VE;
+  GRID_STRIDE(idx, total_vec) {
+    const int c = (int)(idx % cv);
+    const long long pix = idx / cv;  // n*H*W + h*W + w
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    const int lab = (int)(long long)label[pix];
+    float v[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = (c * VE + e == lab && lab < nlab) ? 1.f : 0.f;
+    if (nlab >= c * VE && nlab < c * VE + VE) {
+      const long long me = inst[pix];
+      bool edge = false;
+      if (w > 0) edge |= inst[pix - 1] != me;
+      if (w < W - 1) edge |= inst[pix + 1] != me;
+      if (h > 0) edge |= inst[pix - W] != me;
+      if (h < H - 1) edge |= inst[pix + W] != me;
+      v[nlab - c * VE] = edge ? 1.f : 0.f;
+    }
+    Vec16<T>::store(dst + idx * VE, v);
+  }
+}
+
+// ---- loss reductions (deterministic two-stage) --------------------------------------------------
+enum { RED_L1 = 0, RED_MSE = 1, RED_MSE_CONST = 2 };
+static constexpr int kRedBlocks = 1024;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0) t = red[0] + red[1] + red[2] + red[3];
+  return t;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                          float target, int cs, float* __restrict__ partial,
+                                                          long long total) {
+  constexpr int VE = Vec16<T>::N;
+  __shared__ float red[4];
+  float acc = 0.f;
+  if (MODE == RED_MSE_CONST) {
+    GRID_STRIDE(idx, total) {  // one logical channel (0) per pixel
+      const float d = ElemOps<T>::ld(a + idx * cs) - target;
+      acc += d * d;
+    }
+  } else {
+    GRID_STRIDE(idx, total) {
+      float x[VE], y[VE];
+      Vec16<T>::load(a + idx * VE, x);
+      Vec16<T>::load(b + idx * VE, y);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float d = x[e] - y[e];
+        acc += (MODE == RED_L1) ? fabsf(d) : d * d;
+      }
+    }
+  }
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ partial, int n, float inv_count,
+                                                        float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = t * inv_count;
+}
+
+template <typename T, int MODE>
+__global__ void loss_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, float target, int cs,
+                                const float* __restrict__ gout, float scale, T* __restrict__ da, long long total) {
+  constexpr int VE = Vec16<T>::N;
+  const float g = gout[0] * scale;
+  if (MODE == RED_MSE_CONST) {
+    GRID_STRIDE(idx, total) {  // idx over pixel*cs elements; only channel 0 carries gradient
+      const long long p = idx / cs;
+      const int c = (int)(idx - p * cs);
+      float v = 0.f;
+      if (c == 0) v = 2.f * (ElemOps<T>::ld(a + idx) - target) * g;
+      ElemOps<T>::st(da + idx, v);
+    }
+  } else {
+    GRID_STRIDE(idx, total) {
+      float x[VE], y[VE];
+      Vec16<T>::load(a + idx * VE, x);
+      Vec16<T>::load(b + idx * VE, y);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float d = x[e] - y[e];
+        if (MODE == RED_L1) x[e] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+        else x[e] = 2.f * d * g;
+      }
+      Vec16<T>::store(da + idx * VE, x);
+    }
+  }
+}
+
+// ---- Adam ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(const jpdse_adam_entry* __restrict__ table, int n_entries,
+                                                  float lr_over_bc1, float beta1, float beta2, float eps,
+                                                  float inv_sqrt_bc2, float grad_scale) {
+  // locate the tensor owning this 1024-element block
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = n_entries - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block0 <= blk) lo = mid;
+    else hi = mid - 1;
+  }
+  const jpdse_adam_entry e = table[lo];
+  const long long base = (blk - e.block0) * 1024 + threadIdx.x * 4;
+  if (base >= e.n) return;
+  if (base + 4 <= e.n && (((uintptr_t)(e.p + base) | (uintptr_t)(e.g + base) | (uintptr_t)(e.m + base) |
+                           (uintptr_t)(e.v + base)) & 15) == 0) {
+    f32x4 p = *reinterpret_cast<const f32x4*>(e.p + base);
+    f32x4 g = *reinterpret_cast<const f32x4*>(e.g + base);
+    f32x4 m = *reinterpret_cast<const f32x4*>(e.m + base);
+    f32x4 v = *reinterpret_cast<const f32x4*>(e.v + base);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float gi = g[i] * grad_scale;
+      m[i] = beta1 * m[i] + (1.f - beta1) * gi;
+      v[i] = beta2 * v[i] + (1.f - beta2) * gi * gi;
+      p[i] -= lr_over_bc1 * m[i] / (sqrtf(v[i]) * inv_sqrt_bc2 + eps);
+    }
+    *reinterpret_cast<f32x4*>(e.p + base) = p;
+    *reinterpret_cast<f32x4*>(e.m + base) = m;
+    *reinterpret_cast<f32x4*>(e.v + base) = v;
+  } else {
+    for (long long i = base; i < base + 4 && i < e.n; ++i) {
+      const float gi = e.g[i] * grad_scale;
+      const float m = beta1 * e.m[i] + (1.f - beta1) * gi;
+      const float v = beta2 * e.v[i] + (1.f - beta2) * gi * gi;
+      e.m[i] = m;
+      e.v[i] = v;
+      e.p[i] -= lr_over_bc1 * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+    }
+  }
+}
+
+static int bad_dtype(int dtype) { return !(dtype == JPDSE_F32 || dtype == JPDSE_BF16); }
+
+#define DISPATCH(dtype, KERNEL, grid, s, ...)                                                    \
+  do {                                                                                           \
+    if ((dtype) == JPDSE_BF16)                                                                   \
+      hipLaunchKernelGGL((KERNEL<bf16_t>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);            \
+    else                                                                                         \
+      hipLaunchKernelGGL((KERNEL<float>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);             \
+  } while (0)
+
+template <typename T> static const T* cptr(const void* p) { return reinterpret_cast<const T*>(p); }
+template <typename T> static T* mptr(void* p) { return reinterpret_cast<T*>(p); }
+
+}  // namespace jpdse
+
+using namespace jpdse;
+
+extern "C" {
+
+int jpdse_avgpool3s2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, void* y,
+                         void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && x && y && N > 0 && H > 0 && W > 0 && C > 0, "avgpool3s2_fwd: bad argument");
+  const int Cs = cpad(C), OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long tv = (long long)N * OH * OW * (Cs / (16 / (int)esize(dtype)));
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((avgpool3s2_fwd_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(x), mptr<bf16_t>(y), H, W, OH, OW, Cs, tv);
+  else
+    hipLaunchKernelGGL((avgpool3s2_fwd_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<float>(x), mptr<float>(y), H, W, OH, OW, Cs, tv);
+  return check_launch("avgpool3s2_fwd");
+}
+
+int jpdse_avgpool3s2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* dy, void* dx,
+                         void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "avgpool3s2_bwd: bad argument");
+  const int Cs = cpad(C), OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long tv = (long long)N * H * W * (Cs / (16 / (int)esize(dtype)));
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((avgpool3s2_bwd_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(dy), mptr<bf16_t>(dx), H, W, OH, OW, Cs, tv);
+  else
+    hipLaunchKernelGGL((avgpool3s2_bwd_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<float>(dy), mptr<float>(dx), H, W, OH, OW, Cs, tv);
+  return check_launch("avgpool3s2_bwd");
+}
+
+int jpdse_maxpool2_fwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, void* y,
+                       void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && x && y && N > 0 && H > 1 && W > 1 && C > 0, "maxpool2_fwd: bad argument");
+  const int Cs = cpad(C), OH = H / 2, OW = W / 2;
+  const long long tv = (long long)N * OH * OW * (Cs / (16 / (int)esize(dtype)));
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((maxpool2_fwd_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(x), mptr<bf16_t>(y), H, W, OH, OW, Cs, tv);
+  else
+    hipLaunchKernelGGL((maxpool2_fwd_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<float>(x), mptr<float>(y), H, W, OH, OW, Cs, tv);
+  return check_launch("maxpool2_fwd");
+}
+
+int jpdse_maxpool2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, const void* x, const void* dy,
+                       void* dx, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && x && dy && dx && N > 0 && H > 1 && W > 1 && C > 0, "maxpool2_bwd: bad argument");
+  const int Cs = cpad(C), OH = H / 2, OW = W / 2;
+  const long long tv = (long long)N * H * W * (Cs / (16 / (int)esize(dtype)));
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(x), cptr<bf16_t>(dy), mptr<bf16_t>(dx), H, W, OH, OW, Cs, tv);
+  else
+    hipLaunchKernelGGL((maxpool2_bwd_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<float>(x), cptr<float>(dy), mptr<float>(dx), H, W, OH, OW, Cs, tv);
+  return check_launch("maxpool2_bwd");
+}
+
+int jpdse_act_bwd(int32_t dtype, int64_t n, int32_t act, float slope, const void* y, const void* dy, void* dz,
+                  void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && y && dy && dz && n > 0, "act_bwd: bad argument");
+  const int VE = 16 / (int)esize(dtype);
+  JPDSE_REQUIRE(n % VE == 0, "act_bwd: n=%lld not a multiple of %d", (long long)n, VE);
+  const long long tv = n / VE;
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(y), cptr<bf16_t>(dy), mptr<bf16_t>(dz), act, slope, tv);
+  else
+    hipLaunchKernelGGL((act_bwd_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream), cptr<float>(y),
+                       cptr<float>(dy), mptr<float>(dz), act, slope, tv);
+  return check_launch("act_bwd");
+}
+
+int jpdse_add(int32_t dtype, int64_t n, const void* a, const void* b, void* out, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && a && b && out && n > 0, "add: bad argument");
+  const int VE = 16 / (int)esize(dtype);
+  JPDSE_REQUIRE(n % VE == 0, "add: n=%lld not a multiple of %d", (long long)n, VE);
+  const long long tv = n / VE;
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream), cptr<bf16_t>(a),
+                       cptr<bf16_t>(b), mptr<bf16_t>(out), tv);
+  else
+    hipLaunchKernelGGL((add_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream), cptr<float>(a),
+                       cptr<float>(b), mptr<float>(out), tv);
+  return check_launch("add");
+}
+
+int jpdse_zero(int32_t dtype, int64_t n, void* p, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && p && n >= 0, "zero: bad argument");
+  if (n == 0) return JPDSE_OK;
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)n * esize(dtype), as_stream(stream));
+  if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "zero: %s", hipGetErrorString(e));
+  return JPDSE_OK;
+}
+
+static void csum_geom(int dtype, int64_t npix, int Cs, int& TX, int& TY, long long& ppb, int& nblk) {
+  const int VE = 16 / (int)esize(dtype);
+  const int cv = Cs / VE;
+  TX = 1;
+  while (TX < cv && TX < 256) TX <<= 1;
+  TY = 256 / TX;
+  nblk = 512;
+  if ((long long)nblk * TY * 4 > npix) nblk = (int)((npix + (long long)TY * 4 - 1) / ((long long)TY * 4));
+  if (nblk < 1) nblk = 1;
+  ppb = (npix + nblk - 1) / nblk;
+  nblk = (int)((npix + ppb - 1) / ppb);
+}
+
+size_t jpdse_channel_sum_workspace_size(int64_t npix, int32_t C) {
+  return (size_t)512 * cpad(C) * sizeof(float);
+}
+
+int jpdse_channel_sum(int32_t dtype, int64_t npix, int32_t C, const void* dy, float* out, void* ws, size_t ws_bytes,
+                      void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && dy && out && npix > 0 && C > 0, "channel_sum: bad argument");
+  const int Cs = cpad(C);
+  if (ws == nullptr || ws_bytes < jpdse_channel_sum_workspace_size(npix, C))
+    return set_error(JPDSE_EWORKSPACE, "channel_sum: workspace too small");
+  int TX, TY, nblk;
+  long long ppb;
+  csum_geom(dtype, npix, Cs, TX, TY, ppb, nblk);
+  const int VE = 16 / (int)esize(dtype);
+  const int col_blocks = (Cs / VE + TX - 1) / TX;
+  float* partial = reinterpret_cast<float*>(ws);
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((channel_sum_kernel<bf16_t>), dim3(nblk * col_blocks), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(dy), partial, (long long)npix, Cs, TX, TY, ppb);
+  else
+    hipLaunchKernelGGL((channel_sum_kernel<float>), dim3(nblk * col_blocks), dim3(256), 0, as_stream(stream),
+                       cptr<float>(dy), partial, (long long)npix, Cs, TX, TY, ppb);
+  if (int rc = check_launch("channel_sum")) return rc;
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3((Cs + 255) / 256), dim3(256), 0, as_stream(stream), partial, out,
+                     Cs, nblk);
+  return check_launch("channel_sum_final");
+}
+
+int jpdse_channel_copy(int32_t dtype, int64_t npix, const void* src, int32_t src_cs, int32_t src_c0, void* dst,
+                       int32_t dst_cs, int32_t dst_c0, int32_t nch, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && src && dst && npix > 0 && nch > 0, "channel_copy: bad argument");
+  JPDSE_REQUIRE(src_c0 >= 0 && dst_c0 >= 0 && src_c0 + nch <= src_cs && dst_c0 + nch <= dst_cs,
+                "channel_copy: channel range out of bounds");
+  const long long total = (long long)npix * nch;
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((channel_copy_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(src), src_cs, src_c0, mptr<bf16_t>(dst), dst_cs, dst_c0, nch, total);
+  else
+    hipLaunchKernelGGL((channel_copy_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                       cptr<float>(src), src_cs, src_c0, mptr<float>(dst), dst_cs, dst_c0, nch, total);
+  return check_launch("channel_copy");
+}
+
+int jpdse_nchw_to_nhwc(int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W, const float* src, void* dst,
+                       void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && src && dst && N > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad argument");
+  const int Cs = cpad(C);
+  const long long HW = (long long)H * W, total = (long long)N * Cs * HW;
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), src,
+                       mptr<bf16_t>(dst), C, Cs, HW, total);
+  else
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream), src,
+                       mptr<float>(dst), C, Cs, HW, total);
+  return check_launch("nchw_to_nhwc");
+}
+
+int jpdse_nhwc_to_nchw(int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W, const void* src, float* dst,
+                       void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && src && dst && N > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad argument");
+  const int Cs = cpad(C);
+  const long long HW = (long long)H * W, total = (long long)N * C * HW;
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(src), dst, C, Cs, HW, total);
+  else
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                       cptr<float>(src), dst, C, Cs, HW, total);
+  return check_launch("nhwc_to_nchw");
+}
+
+int jpdse_onehot_edge(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t num_labels, const float* label,
+                      const int64_t* instance, void* dst, int32_t cs, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && label && instance && dst && N > 0 && H > 0 && W > 0, "onehot_edge: bad argument");
+  JPDSE_REQUIRE(num_labels > 0 && num_labels < cs && cs % 8 == 0, "onehot_edge: need num_labels < cs, cs %% 8 == 0");
+  const int VE = 16 / (int)esize(dtype);
+  const long long tv = (long long)N * H * W * (cs / VE);
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((onehot_edge_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream), label,
+                       reinterpret_cast<const long long*>(instance), mptr<bf16_t>(dst), H, W, num_labels, cs, tv);
+  else
+    hipLaunchKernelGGL((onehot_edge_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream), label,
+                       reinterpret_cast<const long long*>(instance), mptr<float>(dst), H, W, num_labels, cs, tv);
+  return check_launch("onehot_edge");
+}
+
+size_t jpdse_loss_workspace_size(int64_t n) { return kRedBlocks * sizeof(float); }
+
+}  // extern "C"
+
+template <int MODE>
+static int loss_fwd(const char* name, int dtype, long long total, long long count, const void* a, const void* b,
+                    float target, int cs, float* out, void* ws, size_t ws_bytes, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && a && out && total > 0 && count > 0, "%s: bad argument", name);
+  if (ws == nullptr || ws_bytes < kRedBlocks * sizeof(float))
+    return set_error(JPDSE_EWORKSPACE, "%s: workspace too small", name);
+  int grid = ew_blocks(total);
+  if (grid > kRedBlocks) grid = kRedBlocks;
+  float* partial = reinterpret_cast<float*>(ws);
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((loss_partial_kernel<bf16_t, MODE>), dim3(grid), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(a), cptr<bf16_t>(b), target, cs, partial, total);
+  else
+    hipLaunchKernelGGL((loss_partial_kernel<float, MODE>), dim3(grid), dim3(256), 0, as_stream(stream), cptr<float>(a),
+                       cptr<float>(b), target, cs, partial, total);
+  if (int rc = check_launch(name)) return rc;
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, grid,
+                     1.f / (float)count, out);
+  return check_launch(name);
+}
+
+template <int MODE>
+static int loss_bwd(const char* name, int dtype, long long total, long long count, const void* a, const void* b,
+                    float target, int cs, const float* gout, float scale, void* da, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && a && gout && da && total > 0 && count > 0, "%s: bad argument", name);
+  const float sc = scale / (float)count;
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, MODE>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(a), cptr<bf16_t>(b), target, cs, gout, sc, mptr<bf16_t>(da), total);
+  else
+    hipLaunchKernelGGL((loss_bwd_kernel<float, MODE>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                       cptr<float>(a), cptr<float>(b), target, cs, gout, sc, mptr<float>(da), total);
+  return check_launch(name);
+}
+
+static int vec_count(const char* name, int dtype, int64_t n, long long* tv) {
+  JPDSE_REQUIRE(!bad_dtype(dtype), "%s: bad dtype", name);
+  const int VE = 16 / (int)esize(dtype);
+  JPDSE_REQUIRE(n > 0 && n % VE == 0, "%s: n=%lld not a positive multiple of %d", name, (long long)n, VE);
+  *tv = n / VE;
+  return JPDSE_OK;
+}
+
+extern "C" {
+
+int jpdse_l1_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out, void* ws,
+                 size_t ws_bytes, void* stream) {
+  long long tv;
+  if (int rc = vec_count("l1_fwd", dtype, n, &tv)) return rc;
+  JPDSE_REQUIRE(b != nullptr, "l1_fwd: null b");
+  return loss_fwd<RED_L1>("l1_fwd", dtype, tv, count, a, b, 0.f, 0, out, ws, ws_bytes, stream);
+}
+int jpdse_l1_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, const float* gout,
+                 float scale, void* da, void* stream) {
+  long long tv;
+  if (int rc = vec_count("l1_bwd", dtype, n, &tv)) return rc;
+  JPDSE_REQUIRE(b != nullptr, "l1_bwd: null b");
+  return loss_bwd<RED_L1>("l1_bwd", dtype, tv, count, a, b, 0.f, 0, gout, scale, da, stream);
+}
+int jpdse_mse_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out, void* ws,
+                  size_t ws_bytes, void* stream) {
+  long long tv;
+  if (int rc = vec_count("mse_fwd", dtype, n, &tv)) return rc;
+  JPDSE_REQUIRE(b != nullptr, "mse_fwd: null b");
+  return loss_fwd<RED_MSE>("mse_fwd", dtype, tv, count, a, b, 0.f, 0, out, ws, ws_bytes, stream);
+}
+int jpdse_mse_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, const float* gout,
+                  float scale, void* da, void* stream) {
+  long long tv;
+  if (int rc = vec_count("mse_bwd", dtype, n, &tv)) return rc;
+  JPDSE_REQUIRE(b != nullptr, "mse_bwd: null b");
+  return loss_bwd<RED_MSE>("mse_bwd", dtype, tv, count, a, b, 0.f, 0, gout, scale, da, stream);
+}
+int jpdse_mse_const_fwd(int32_t dtype, int64_t npix, int32_t cs, float target, const void* x, float* out, void* ws,
+                        size_t ws_bytes, void* stream) {
+  JPDSE_REQUIRE(cs > 0, "mse_const_fwd: bad cs");
+  return loss_fwd<RED_MSE_CONST>("mse_const_fwd", dtype, npix, npix, x, nullptr, target, cs, out, ws, ws_bytes, stream);
+}
+int jpdse_mse_const_bwd(int32_t dtype, int64_t npix, int32_t cs, float target, const void* x, const float* gout,
+                        float scale, void* dx, void* stream) {
+  JPDSE_REQUIRE(cs > 0, "mse_const_bwd: bad cs");
+  return loss_bwd<RED_MSE_CONST>("mse_const_bwd", dtype, (long long)npix * cs, npix, x, nullptr, target, cs, gout,
+                                 scale, dx, stream);
+}
+
+int jpdse_adam_step(const jpdse_adam_entry* table, int32_t n_entries, int64_t total_blocks, float lr, float beta1,
+                    float beta2, float eps, int32_t step, float grad_scale, void* stream) {
+  JPDSE_REQUIRE(table && n_entries > 0 && total_blocks > 0 && step >= 1, "adam_step: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), table, n_entries,
+                     (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+  return check_launch("adam_step");
+}
+
+}  // extern "C"

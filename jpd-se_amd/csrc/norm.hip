@@ -1,0 +1,331 @@
+// InstanceNorm2d(affine=False) fused with ReLU / LeakyReLU / residual add, forward and
+// backward, NHWC (reference: networks.py:31 and the activation sites listed in jpdse.h).
+//
+// HBM-bound.  Per-(n,c) reductions run as: (1) a moment kernel in which each thread owns one
+// 16-byte channel vector column and walks pixels (coalesced: a pixel's channels are
+// contiguous), partial sums per pixel-split written to the workspace; (2) a tiny finalize
+// kernel (deterministic order, no atomics); (3) a fully parallel apply kernel.
+#include "common.h"
+
+namespace jpdse {
+
+struct MomentGeom {
+  int N, HW, Cs, cv;      // cv = Cs / VE vector columns
+  int TX, TY;             // threads across columns / pixels (TX*TY = 256)
+  int splits, pix_per_split;
+};
+
+static MomentGeom moment_geom(int N, int HW, int Cs, int VE) {
+  MomentGeom g;
+  g.N = N; g.HW = HW; g.Cs = Cs; g.cv = Cs / VE;
+  int tx = 1;
+  while (tx < g.cv && tx < 256) tx <<= 1;
+  g.TX = tx; g.TY = 256 / tx;
+  // aim for ~2048 blocks in total, at least 8 pixels per thread row
+  const int col_blocks = (g.cv + g.TX - 1) / g.TX;
+  long long want = 2048 / ((long long)N * col_blocks);
+  if (want < 1) want = 1;
+  long long max_splits = HW / ((long long)g.TY * 8);
+  if (max_splits < 1) max_splits = 1;
+  if (want > max_splits) want = max_splits;
+  if (want > 256) want = 256;
+  g.splits = (int)want;
+  g.pix_per_split = (HW + g.splits - 1) / g.splits;
+  g.splits = (HW + g.pix_per_split - 1) / g.pix_per_split;
+  return g;
+}
+
+// ---- per-element functors -----------------------------------------------------------------
+// forward moments: (x - shift), (x - shift)^2 with shift = x[n, pixel 0, c]
+template <typename T> struct FwdMoments {
+  const T* x;
+  __device__ __forceinline__ void prep(int n, int HW, int Cs, int c0, float (&aux)[8]) const {
+    float v[Vec16<T>::N];
+    Vec16<T>::load(x + (long long)n * HW * Cs + c0, v);
+#pragma unroll
+    for (int e = 0; e < Vec16<T>::N; ++e) aux[e] = v[e];
+  }
+  __device__ __forceinline__ void at(long long off, int, const float (&aux)[8], float (&s1)[8], float (&s2)[8]) const {
+    float v[Vec16<T>::N];
+    Vec16<T>::load(x + off, v);
+#pragma unroll
+    for (int e = 0; e < Vec16<T>::N; ++e) {
+      const float d = v[e] - aux[e];
+      s1[e] += d;
+      s2[e] += d * d;
+    }
+  }
+};
+
+__device__ __forceinline__ float act_grad(float yhat, int act, float slope) {
+  if (act == JPDSE_ACT_RELU) return yhat > 0.f ? 1.f : 0.f;
+  if (act == JPDSE_ACT_LRELU) return yhat > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+// backward moments: dz, dz*yhat with dz = dy*act'(yhat), yhat = (x-mean)*rstd
+template <typename T> struct BwdMoments {
+  const T* x;
+  const T* dy;
+  const float* stats;  // [N][Cs][2]
+  int act;
+  float slope;
+  // aux packs mean[e] in [0..VE) -- rstd kept separately
+  __device__ __forceinline__ void at2(long long off, int n, int Cs, int c0, float (&s1)[8], float (&s2)[8]) const {
+    float v[Vec16<T>::N], g[Vec16<T>::N];
+    Vec16<T>::load(x + off, v);
+    Vec16<T>::load(dy + off, g);
+    const float* st = stats + ((long long)n * Cs + c0) * 2;
+#pragma unroll
+    for (int e = 0; e < Vec16<T>::N; ++e) {
+      const float yh = (v[e] - st[2 * e]) * st[2 * e + 1];
+      const float dz = g[e] * act_grad(yh, act, slope);
+      s1[e] += dz;
+      s2[e] += dz * yh;
+    }
+  }
+};
+
+// partial[n][split][c][2]
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void moment_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                    const float* __restrict__ stats, int act, float slope,
+                                                    float* __restrict__ partial, MomentGeom g) {
+  constexpr int VE = Vec16<T>::N;
+  __shared__ float red[256 * 2 * VE];
+  const int tx = threadIdx.x % g.TX, ty = threadIdx.x / g.TX;
+  const int col_blocks = (g.cv + g.TX - 1) / g.TX;
+  const int cb = blockIdx.x % col_blocks;
+  const int split = (blockIdx.x / col_blocks) % g.splits;
+  const int n = blockIdx.x / (col_blocks * g.splits);
+  const int col = cb * g.TX + tx;
+  const bool on = col < g.cv;
+  const int c0 = col * VE;
+  float s1[8], s2[8], aux[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; aux[e] = 0.f; }
+  if (on) {
+    const int p0 = split * g.pix_per_split;
+    int p1 = p0 + g.pix_per_split;
+    p1 = p1 < g.HW ? p1 : g.HW;
+    const long long base = (long long)n * g.HW * g.Cs + c0;
+    if (!BWD) {
+      FwdMoments<T> f{x};
+      f.prep(n, g.HW, g.Cs, c0, aux);
+      for (int p = p0 + ty; p < p1; p += g.TY) f.at(base + (long long)p * g.Cs, 0, aux, s1, s2);
+    } else {
+      BwdMoments<T> f{x, dy, stats, act, slope};
+      for (int p = p0 + ty; p < p1; p += g.TY) f.at2(base + (long long)p * g.Cs, n, g.Cs, c0, s1, s2);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    red[(threadIdx.x * VE + e) * 2] = s1[e];
+    red[(threadIdx.x * VE + e) * 2 + 1] = s2[e];
+  }
+  __syncthreads();
+  if (ty == 0 && on) {
+    float* out = partial + (((long long)n * g.splits + split) * g.Cs + c0) * 2;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int y = 0; y < g.TY; ++y) {
+        a += red[((y * g.TX + tx) * VE + e) * 2];
+        b += red[((y * g.TX + tx) * VE + e) * 2 + 1];
+      }
+      out[2 * e] = a;
+      out[2 * e + 1] = b;
+    }
+  }
+}
+
+// forward finalize: partial sums of shifted values -> (mean, rstd)
+template <typename T>
+__global__ void finalize_fwd_kernel(const T* __restrict__ x, const float* __restrict__ partial,
+                                    float* __restrict__ stats, int N, int HW, int Cs, int splits, float eps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * Cs) return;
+  const int n = idx / Cs, c = idx % Cs;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float* p = partial + (((long long)n * splits + s) * Cs + c) * 2;
+    a += p[0];
+    b += p[1];
+  }
+  const float shift = ElemOps<T>::ld(x + (long long)n * HW * Cs + c);
+  const float inv = 1.f / (float)HW;
+  const float dm = a * inv;
+  float var = b * inv - dm * dm;
+  var = var > 0.f ? var : 0.f;
+  stats[2 * idx] = shift + dm;
+  stats[2 * idx + 1] = rsqrtf(var + eps);
+}
+
+// backward finalize: (mean(dz), mean(dz*yhat))
+__global__ void finalize_bwd_kernel(const float* __restrict__ partial, float* __restrict__ sums, int N, int HW,
+                                    int Cs, int splits) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * Cs) return;
+  const int n = idx / Cs, c = idx % Cs;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float* p = partial + (((long long)n * splits + s) * Cs + c) * 2;
+    a += p[0];
+    b += p[1];
+  }
+  const float inv = 1.f / (float)HW;
+  sums[2 * idx] = a * inv;
+  sums[2 * idx + 1] = b * inv;
+}
+
+template <typename T>
+__global__ void inorm_apply_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                       const float* __restrict__ stats, int HW, int Cs, int act, float slope,
+                                       long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = Cs / VE;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % cv);
+    const long long pix = idx / cv;
+    const int n = (int)(pix / HW);
+    const float* st = stats + ((long long)n * Cs + col * VE) * 2;
+    float v[VE], r[VE];
+    Vec16<T>::load(x + idx * VE, v);
+    if (res != nullptr) Vec16<T>::load(res + idx * VE, r);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      float t = (v[e] - st[2 * e]) * st[2 * e + 1];
+      if (act == JPDSE_ACT_RELU) t = t > 0.f ? t : 0.f;
+      else if (act == JPDSE_ACT_LRELU) t = t > 0.f ? t : t * slope;
+      if (res != nullptr) t += r[e];
+      v[e] = t;
+    }
+    Vec16<T>::store(y + idx * VE, v);
+  }
+}
+
+template <typename T>
+__global__ void inorm_apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                       const float* __restrict__ stats, const float* __restrict__ sums, int HW,
+                                       int Cs, int act, float slope, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = Cs / VE;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % cv);
+    const long long pix = idx / cv;
+    const int n = (int)(pix / HW);
+    const long long sidx = ((long long)n * Cs + col * VE) * 2;
+    const float* st = stats + sidx;
+    const float* sm = sums + sidx;
+    float v[VE], g[VE];
+    Vec16<T>::load(x + idx * VE, v);
+    Vec16<T>::load(dy + idx * VE, g);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const float rstd = st[2 * e + 1];
+      const float yh = (v[e] - st[2 * e]) * rstd;
+      const float dz = g[e] * act_grad(yh, act, slope);
+      v[e] = rstd * (dz - sm[2 * e] - yh * sm[2 * e + 1]);
+    }
+    Vec16<T>::store(dx + idx * VE, v);
+  }
+}
+
+static int validate(const jpdse_inorm_desc* d) {
+  JPDSE_REQUIRE(d != nullptr, "inorm: null descriptor");
+  JPDSE_REQUIRE(d->dtype == JPDSE_F32 || d->dtype == JPDSE_BF16, "inorm: bad dtype");
+  JPDSE_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0, "inorm: non-positive shape");
+  JPDSE_REQUIRE(d->act == JPDSE_ACT_NONE || d->act == JPDSE_ACT_RELU || d->act == JPDSE_ACT_LRELU,
+                "inorm: unsupported activation %d", d->act);
+  return JPDSE_OK;
+}
+
+static size_t ws_bytes_for(const jpdse_inorm_desc* d) {
+  const int VE = d->dtype == JPDSE_BF16 ? 8 : 4;
+  MomentGeom g = moment_geom(d->N, d->H * d->W, cpad(d->C), VE);
+  const size_t partial = (size_t)d->N * g.splits * g.Cs * 2 * sizeof(float);
+  const size_t sums = (size_t)d->N * g.Cs * 2 * sizeof(float);
+  return align_up(partial, 256) + align_up(sums, 256);
+}
+
+template <typename T>
+static int inorm_fwd_t(const jpdse_inorm_desc* d, const void* x, const void* res, void* y, float* stats, void* ws,
+                       hipStream_t s) {
+  constexpr int VE = Vec16<T>::N;
+  const int HW = d->H * d->W, Cs = cpad(d->C);
+  MomentGeom g = moment_geom(d->N, HW, Cs, VE);
+  float* partial = reinterpret_cast<float*>(ws);
+  const int col_blocks = (g.cv + g.TX - 1) / g.TX;
+  hipLaunchKernelGGL((moment_kernel<T, false>), dim3(d->N * g.splits * col_blocks), dim3(256), 0, s,
+                     reinterpret_cast<const T*>(x), (const T*)nullptr, (const float*)nullptr, 0, 0.f, partial, g);
+  if (int rc = check_launch("inorm moment fwd")) return rc;
+  hipLaunchKernelGGL((finalize_fwd_kernel<T>), dim3((d->N * Cs + 255) / 256), dim3(256), 0, s,
+                     reinterpret_cast<const T*>(x), partial, stats, d->N, HW, Cs, g.splits, d->eps);
+  if (int rc = check_launch("inorm finalize fwd")) return rc;
+  const long long total_vec = (long long)d->N * HW * g.cv;
+  hipLaunchKernelGGL((inorm_apply_fwd_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s,
+                     reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(res), reinterpret_cast<T*>(y), stats,
+                     HW, Cs, d->act, d->slope, total_vec);
+  return check_launch("inorm apply fwd");
+}
+
+template <typename T>
+static int inorm_bwd_t(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy, void* dx,
+                       void* ws, hipStream_t s) {
+  constexpr int VE = Vec16<T>::N;
+  const int HW = d->H * d->W, Cs = cpad(d->C);
+  MomentGeom g = moment_geom(d->N, HW, Cs, VE);
+  float* partial = reinterpret_cast<float*>(ws);
+  float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
+                                         align_up((size_t)d->N * g.splits * g.Cs * 2 * sizeof(float), 256));
+  const int col_blocks = (g.cv + g.TX - 1) / g.TX;
+  hipLaunchKernelGGL((moment_kernel<T, true>), dim3(d->N * g.splits * col_blocks), dim3(256), 0, s,
+                     reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), stats, d->act, d->slope,
+                     partial, g);
+  if (int rc = check_launch("inorm moment bwd")) return rc;
+  hipLaunchKernelGGL(finalize_bwd_kernel, dim3((d->N * Cs + 255) / 256), dim3(256), 0, s, partial, sums, d->N, HW,
+                     Cs, g.splits);
+  if (int rc = check_launch("inorm finalize bwd")) return rc;
+  const long long total_vec = (long long)d->N * HW * g.cv;
+  hipLaunchKernelGGL((inorm_apply_bwd_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s,
+                     reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx), stats,
+                     sums, HW, Cs, d->act, d->slope, total_vec);
+  return check_launch("inorm apply bwd");
+}
+
+}  // namespace jpdse
+
+using namespace jpdse;
+
+extern "C" {
+
+size_t jpdse_inorm_workspace_size(const jpdse_inorm_desc* d) {
+  if (jpdse::validate(d)) return 0;
+  return ws_bytes_for(d);
+}
+
+int jpdse_inorm_fwd(const jpdse_inorm_desc* d, const void* x, const void* residual, void* y, float* stats, void* ws,
+                    size_t ws_bytes, void* stream) {
+  if (int rc = jpdse::validate(d)) return rc;
+  JPDSE_REQUIRE(x && y && stats, "inorm_fwd: null pointer");
+  JPDSE_REQUIRE(!d->has_residual || residual, "inorm_fwd: has_residual set but residual is null");
+  if (ws == nullptr || ws_bytes < ws_bytes_for(d))
+    return set_error(JPDSE_EWORKSPACE, "inorm_fwd: workspace %zu < %zu", ws_bytes, ws_bytes_for(d));
+  const void* res = d->has_residual ? residual : nullptr;
+  return d->dtype == JPDSE_BF16 ? inorm_fwd_t<bf16_t>(d, x, res, y, stats, ws, as_stream(stream))
+                                : inorm_fwd_t<float>(d, x, res, y, stats, ws, as_stream(stream));
+}
+
+int jpdse_inorm_bwd(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy, void* dx, void* ws,
+                    size_t ws_bytes, void* stream) {
+  if (int rc = jpdse::validate(d)) return rc;
+  JPDSE_REQUIRE(x && stats && dy && dx, "inorm_bwd: null pointer");
+  if (ws == nullptr || ws_bytes < ws_bytes_for(d))
+    return set_error(JPDSE_EWORKSPACE, "inorm_bwd: workspace %zu < %zu", ws_bytes, ws_bytes_for(d));
+  return d->dtype == JPDSE_BF16 ? inorm_bwd_t<bf16_t>(d, x, stats, dy, dx, ws, as_stream(stream))
+                                : inorm_bwd_t<float>(d, x, stats, dy, dx, ws, as_stream(stream));
+}
+
+}  // extern "C"

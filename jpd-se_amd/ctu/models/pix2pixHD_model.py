@@ -1,0 +1,425 @@
+"""JPD-SE model on the MI355X-native kernels, behind the reference's `Pix2PixHDModel` API.
+
+Reference: /root/reference/ctu/models/pix2pixHD_model.py
+  __init__ :105-220   forward :231-245   create_optimizers :248-280   preprocess :362-412
+  discriminate :451-460   _get_img :508-618   get_eval_loss :621-643   get_train_loss :709-771
+  get_edges :774-783   save :786-792
+
+What changed structurally (results identical; DESIGN.md "schedule"):
+  * no autograd: `train_step` runs an explicit forward/backward program over libjpdse_hip.so;
+  * the discriminator sees ONE batched pass [label|fake ; label|real] (InstanceNorm is per
+    sample, so this equals the reference's separate passes) and the reference's third pass
+    D(label|fake) -- numerically the same forward as D((label|fake).detach()) -- is not
+    recomputed: its gradient w.r.t. the fake image is back-propagated through the saved fake
+    half with weight gradients skipped (the reference computes and then discards them);
+  * the one-hot / edge / concat input builder writes the 39-channel NHWC tensor directly.
+Only the flag subset used by scripts/pix2pixHD_bpg_train.sh is accelerated; other branches
+raise NotImplementedError.
+"""
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+from jpdse_hip import F32, BF16, JpdseError, require_gpu
+from jpdse_hip import ops
+from jpdse_hip.ops import Act
+from jpdse_hip.optim import FusedAdam
+from ctu.utils.image_pool import ImagePool
+from ctu.utils.misc import tensor2im
+from ctu.models.pix2pixHD_networks.base_model import BaseModel
+from ctu.models.pix2pixHD_networks import networks
+
+LOSS_NAMES = ('G_GAN', 'G_GAN_Feat', 'G_VGG', 'G_Distortion', 'D_real', 'D_fake')
+
+
+class Pix2PixHDModel(BaseModel):
+
+  @staticmethod
+  def modify_commandline_options(parser, train):
+    """Same flag names/defaults as the reference setter (pix2pixHD_model.py:21-102) for the
+    options the hot path reads, plus --compute_dtype."""
+    a = parser.add_argument
+    a('--num_D', type=int, default=2)
+    a('--n_layers_D', type=int, default=3)
+    a('--ndf', type=int, default=64)
+    a('--no_lsgan', action='store_true')
+    a('--pool_size', type=int, default=0)
+    a('--no_instance', action='store_true')
+    a('--no_label', action='store_true')
+    a('--sem_masking', action='store_true')
+    a('--norm', type=str, default='instance')
+    a('--lambda_feat', type=float, default=10.0)
+    a('--lambda_distortion', type=float, default=10.0)
+    a('--anneal_lambda', action='store_true')
+    a('--anneal_interval', type=int, default=5000)
+    a('--anneal_factor', type=float, default=5.)
+    a('--match_raw_feat', action='store_true')
+    for f in ('gan_feat', 'vgg', 'distortion', 'g_gan', 'd_gan'):
+      a('--no_%s_loss' % f, action='store_true')
+    a('--data_type', default=32, type=int, choices=[8, 16, 32])
+    a('--fp16', action='store_true', default=False)
+    a('--compute_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
+      help='MFMA input type of the HIP kernels (fp32 accumulate either way)')
+    a('--local_rank', type=int, default=0)
+    a('--input_nc', type=int, default=3)
+    a('--use_compressed', action='store_true')
+    a('--ext', type=str, default='jpg', choices=['jpg', 'j2k', 'bpg', 'webp'])
+    a('--quality', type=str, default='100')
+    a('--zero_sem', action='store_true')
+    a('--zero_ins', action='store_true')
+    a('--zero_vis', action='store_true')
+    a('--checkpoints_dir', type=str)
+    a('--netG', type=str, default='global')
+    a('--ngf', type=int, default=64)
+    a('--n_downsample_global', type=int, default=4)
+    a('--n_blocks_global', type=int, default=9)
+    a('--n_blocks_local', type=int, default=3)
+    a('--n_local_enhancers', type=int, default=1)
+    a('--niter_fix_global', type=int, default=0)
+    a('--no_feat_encoding', action='store_true')
+    a('--no_feat', action='store_true')
+    a('--no_label_encoding', action='store_true')
+    a('--no_generator_binarization', action='store_true')
+    a('--bin_generator_before_res', action='store_true')
+    a('--generator_binarizer_out_channels', type=int, default=128)
+    a('--use_netE_output', action='store_true')
+    return parser
+
+  # ------------------------------------------------------------------------------------------
+  def __init__(self, opt):
+    super(Pix2PixHDModel, self).__init__(opt)
+    g = lambda name, default=False: getattr(opt, name, default)
+    unsupported = []
+    if not g('no_label_encoding') or not g('no_feat_encoding'):
+      unsupported.append('learned label/feature encoders (run with --no_label_encoding --no_feat_encoding)')
+    if not g('no_generator_binarization'):
+      unsupported.append('generator binarization (run with --no_generator_binarization)')
+    for flag in ('sem_masking', 'no_label', 'no_feat', 'match_raw_feat', 'no_lsgan', 'use_netE_output',
+                 'zero_sem', 'zero_ins', 'zero_vis'):
+      if g(flag):
+        unsupported.append('--' + flag)
+    if g('norm', 'instance') != 'instance':
+      unsupported.append('--norm ' + str(opt.norm))
+    if unsupported:
+      raise NotImplementedError('outside the accelerated JPD-SE path (SURVEY.md §2): ' + '; '.join(unsupported))
+    self.opt = opt
+    self.is_train = opt.is_train
+    self.use_features = True
+    cd = 'bf16' if (g('compute_dtype', 'fp32') == 'bf16' or g('fp16')) else 'fp32'
+    self.cdtype = networks.dtype_code(cd)
+    if self.use_gpu():
+      require_gpu(opt.gpu_ids[0])
+
+    # channel bookkeeping (pix2pixHD_model.py:117-158)
+    self.n_onehot = opt.num_labels + 1 if g('contain_dontcare_label') else opt.num_labels
+    self.label_nc = self.n_onehot + (0 if g('no_instance') else 1)
+    netG_input_nc = self.label_nc + opt.input_nc
+    netD_input_nc = self.label_nc + opt.num_out_channels
+
+    self.netG = networks.define_G(netG_input_nc, opt.num_out_channels, opt.ngf, opt.netG,
+                                  opt.n_downsample_global, opt.n_blocks_global, opt.n_local_enhancers,
+                                  opt.n_blocks_local, opt.norm, gpu_ids=self.gpu_ids, compute_dtype=cd)
+    if self.is_train:
+      self.netD = networks.define_D(netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm, False, opt.num_D, True,
+                                    gpu_ids=self.gpu_ids, compute_dtype=cd)
+    print('---------- networks initialized -------------')
+    if not self.is_train or g('load_model'):
+      self.load_network(self.netG, 'G', opt)
+      if self.is_train:
+        self.load_network(self.netD, 'D', opt)
+    if self.is_train:
+      if opt.pool_size > 0 and len(self.gpu_ids) > 1:
+        raise NotImplementedError('Fake Pool Not Implemented for MultiGPU')
+      self.fake_pool = ImagePool(opt.pool_size)
+      self.criterionGAN = networks.GANLoss(use_lsgan=True)
+      self.criterionVGG = networks.VGGLoss(self.gpu_ids, compute_dtype=cd)
+      vgg_path = g('vgg19_state_dict', None)
+      if vgg_path:
+        self.criterionVGG.vgg.load_torchvision_state_dict(torch.load(vgg_path, map_location='cpu'))
+      self.loss_names = LOSS_NAMES
+    else:
+      self.loss_names = ('G_Distortion')
+    if opt.distortion_loss_fn not in ('l1', 'mse'):
+      raise ValueError('distortion_loss_fn must be l1 or mse')
+    self.grad_buckets = {}           # 'G' / 'D' -> jpdse_hip.ddp.GradBuckets (set by the trainer for DDP)
+    self._one = None
+
+  def use_gpu(self):
+    return len(self.opt.gpu_ids) > 0
+
+  def _device(self):
+    if not self.use_gpu():
+      raise JpdseError('the JPD-SE HIP path needs --gpu_ids >= 0: there is no CPU fallback')
+    return torch.device('cuda', self.opt.gpu_ids[0])
+
+  # ------------------------------------------------------------------------------------------
+  def forward(self, x_dict, opt=None, mode='get_train_loss'):
+    if mode == 'get_img':
+      return self.get_img(x_dict)
+    if mode == 'get_train_loss':
+      return self.get_train_loss(x_dict)
+    if mode == 'get_eval_loss':
+      return self.get_eval_loss(x_dict)
+    if mode in ('get_code', 'get_eval_rate'):
+      raise NotImplementedError('binary codes exist only for the learned-codec ablations (SURVEY.md §2 row 3)')
+    raise ValueError('Invalid forward mode: {}'.format(mode))
+
+  def create_optimizers(self, opt):
+    """Two Adams, lr/betas from opt (pix2pixHD_model.py:248-280); with niter_fix_global > 0 only
+    the outermost enhancer (`model<n>_*`) is trained."""
+    if opt.niter_fix_global > 0:
+      prefix = 'model' + str(opt.n_local_enhancers)
+      params = [p for k, p in self.netG.named_parameters() if k.startswith(prefix)]
+      print('------------- only training the local enhancer network (for %d epochs) ------------'
+            % opt.niter_fix_global)
+    else:
+      params = list(self.netG.parameters())
+    for m in list(self.netG.modules()) + list(self.netD.modules()):
+      if hasattr(m, 'ensure_grads'):
+        m.ensure_grads()
+    optimizer_G = FusedAdam(params, lr=opt.lr, betas=(opt.beta1, opt.beta2))
+    optimizer_D = FusedAdam(list(self.netD.parameters()), lr=opt.lr, betas=(opt.beta1, opt.beta2))
+    return optimizer_G, optimizer_D
+
+  # ---- external codec hook (config 1 plumbing; CPU, third-party) -----------------------------
+  @staticmethod
+  def converter(filename, ext, quality):
+    """Round-trip `filename` through an outside codec, return the path of the decoded image
+    (pix2pixHD_model.py:287-321).  BPG shells out to bpgenc/bpgdec when they are installed."""
+    from PIL import Image
+    stem = os.path.splitext(filename)[0]
+    out = stem + '.' + ext
+    if ext in ('jpg', 'webp'):
+      Image.open(filename).save(out, quality=quality)
+      return out
+    if ext == 'j2k':
+      Image.open(filename).save(out, quality_mode='rates', quality_layers=[quality])
+      return out
+    if ext == 'bpg':
+      decoded = stem + '_decoded_from_bpg.png'
+      subprocess.run(['bpgenc', '-q', str(quality), '-o', out, filename], check=True)
+      subprocess.run(['bpgdec', '-o', decoded, out], check=True)
+      return decoded
+    raise ValueError('format must be one of jpg, webp, j2k, or bpg')
+
+  def compress(self, x_dict, tmp_folder):
+    """Decoded frame(s) of x_dict['image'] after the codec, normalised like the input
+    (pix2pixHD_model.py:324-359); unlike the reference this loops over the batch."""
+    from PIL import Image
+    imgs = tensor2im(x_dict['image'], self.opt)
+    mean = torch.tensor(self.opt.normalize_mean, dtype=torch.float32)[:, None, None]
+    std = torch.tensor(self.opt.normalize_std, dtype=torch.float32)[:, None, None]
+    out = []
+    for b in range(imgs.shape[0]):
+      name = os.path.join(tmp_folder, 'tmp_image_%d.png' % b)
+      Image.fromarray(imgs[b]).save(name)
+      decoded = np.asarray(Image.open(self.converter(name, self.opt.ext, self.opt.quality[0])).convert('RGB'))
+      t = torch.from_numpy(decoded.astype(np.float32) / 255.0).permute(2, 0, 1)
+      out.append((t - mean) / std)
+    return torch.stack(out, 0)
+
+  # ---- input builder ------------------------------------------------------------------------
+  def preprocess(self, x_dict):
+    """x_dict (CPU or cuda tensors from the loader) -> NHWC device activations.
+    Returns dict(base=Act[B,H,W,label_nc+3] with one-hot+edge filled (model.py:375-394),
+    real=Act 3ch, src=Act 3ch (decoded frame when use_compressed else real))."""
+    dev = self._device()
+    opt = self.opt
+    comp = None
+    if opt.use_compressed:
+      comp = x_dict.get('compressed_img')
+      if comp is None:
+        tmp_dir = os.path.join(opt.save_dir, 'tmp_imgs')
+        os.makedirs(tmp_dir, exist_ok=True)
+        comp = self.compress(x_dict, tmp_dir)
+    label = x_dict['label'].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+    inst = x_dict['instance'].to(dev, dtype=torch.int64, non_blocking=True).contiguous()
+    image = x_dict['image'].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+    if getattr(opt, 'no_instance', False):
+      inst = torch.zeros_like(inst)      # a constant map has no edges; its channel is not part of label_nc
+    total_c = self.label_nc + opt.input_nc
+    base = ops.onehot_edge(label, inst, self.n_onehot, total_c, self.cdtype)
+    real = ops.nchw_to_nhwc(image, self.cdtype)
+    src = real
+    if comp is not None:
+      src = ops.nchw_to_nhwc(comp.to(dev, dtype=torch.float32, non_blocking=True).contiguous(), self.cdtype)
+    return dict(base=base, real=real, src=src, image_nchw=image)
+
+  def _with_image(self, base, img, out=None):
+    """torch.cat((input_label, img), dim=1) in NHWC: copy of `base` with the image channels filled."""
+    dst = out if out is not None else base.empty_like()
+    dst.t.copy_(base.t)
+    ops.channel_copy(img, 0, dst, self.label_nc, img.C)
+    return dst
+
+  # ---- inference ------------------------------------------------------------------------------
+  def get_img(self, x_dict):
+    with torch.no_grad():
+      pre = self.preprocess(x_dict)
+      fake, _ = self.netG.fwd(self._with_image(pre['base'], pre['src']))
+      return ops.nhwc_to_nchw(fake)
+
+  def get_eval_loss(self, x_dict):
+    """Distortion on de-normalised, clipped, uint8-truncated images (0..255 scale), as the
+    reference does on the host (pix2pixHD_model.py:636-641)."""
+    recon = self.get_img(x_dict)
+    a = torch.tensor(tensor2im(recon, self.opt).transpose(0, 3, 1, 2)).to(torch.float)
+    b = torch.tensor(tensor2im(x_dict['image'], self.opt).transpose(0, 3, 1, 2)).to(torch.float)
+    dev = self._device()
+    A, Bm = ops.nchw_to_nhwc(a.to(dev).contiguous(), F32), ops.nchw_to_nhwc(b.to(dev).contiguous(), F32)
+    slot = torch.zeros(1, dtype=torch.float32, device=dev)
+    (ops.l1_fwd if self.opt.distortion_loss_fn == 'l1' else ops.mse_fwd)(A, Bm, slot)
+    return slot[0]
+
+  # ---- training -------------------------------------------------------------------------------
+  def _forward_losses(self, x_dict):
+    """Forward pass of the whole loss graph.  Returns (state for backward, slots tensor, layout)."""
+    opt = self.opt
+    dev = self._device()
+    pre = self.preprocess(x_dict)
+    base, real, src = pre['base'], pre['real'], pre['src']
+    B = base.N
+    fake, g_ctx = self.netG.fwd(self._with_image(base, src))
+
+    # one batched discriminator pass: [label|fake ; label|real]  (model.py:717,722,733)
+    d_in = Act.empty(2 * B, base.H, base.W, base.C, self.cdtype, dev)
+    self._with_image(base, fake, out=d_in.batch_slice(0, B))
+    self._with_image(base, real, out=d_in.batch_slice(B, 2 * B))
+    pred, d_ctx = self.netD.fwd(d_in)
+
+    vgg = self.criterionVGG.vgg
+    vf, v_ctx = vgg.fwd(fake, save=True)
+    vr, _ = vgg.fwd(real, save=False)
+
+    nD, nF = opt.num_D, opt.n_layers_D + 1
+    layout = dict(D_fake=list(range(0, nD)), D_real=list(range(nD, 2 * nD)), G_GAN=list(range(2 * nD, 3 * nD)))
+    o = 3 * nD
+    layout['feat'] = [[o + i * nF + j for j in range(nF)] for i in range(nD)]
+    o += nD * nF
+    layout['vgg'] = list(range(o, o + len(vf)))
+    o += len(vf)
+    layout['dist'] = o
+    slots = torch.zeros(o + 1, dtype=torch.float32, device=dev)
+    s = lambda i: slots[i:i + 1]
+    for i in range(nD):
+      p = pred[i][-1]
+      ops.mse_const_fwd(p.batch_slice(0, B), 0.0, s(layout['D_fake'][i]))
+      ops.mse_const_fwd(p.batch_slice(B, 2 * B), 1.0, s(layout['D_real'][i]))
+      ops.mse_const_fwd(p.batch_slice(0, B), 1.0, s(layout['G_GAN'][i]))
+      for j in range(nF):
+        f = pred[i][j]
+        ops.l1_fwd(f.batch_slice(0, B), f.batch_slice(B, 2 * B), s(layout['feat'][i][j]))
+    for k in range(len(vf)):
+      ops.l1_fwd(vf[k], vr[k], s(layout['vgg'][k]))
+    (ops.l1_fwd if opt.distortion_loss_fn == 'l1' else ops.mse_fwd)(fake, real, s(layout['dist']))
+    state = dict(B=B, fake=fake, real=real, g_ctx=g_ctx, pred=pred, d_ctx=d_ctx, vf=vf, vr=vr, v_ctx=v_ctx)
+    return state, slots, layout
+
+  def _reduce_losses(self, vals, layout):
+    """Host arithmetic on the slot values -> the reference's six loss scalars."""
+    nD = self.opt.num_D
+    w = networks.VGGLoss.weights
+    return dict(
+        G_GAN=sum(vals[i] for i in layout['G_GAN']),
+        G_GAN_Feat=sum((1.0 / nD) * vals[i] for row in layout['feat'] for i in row),
+        G_VGG=sum(w[k] * vals[i] for k, i in enumerate(layout['vgg'])),
+        G_Distortion=vals[layout['dist']],
+        D_real=sum(vals[i] for i in layout['D_real']),
+        D_fake=sum(vals[i] for i in layout['D_fake']))
+
+  def get_train_loss(self, x_dict):
+    """The six losses as 0-dim device tensors in `loss_names` order (values only: the HIP path
+    keeps no autograd graph -- use `train_step` to optimise)."""
+    state, slots, layout = self._forward_losses(x_dict)
+    L = self._reduce_losses(slots.cpu().tolist(), layout)
+    return tuple(torch.tensor(L[k], device=slots.device) for k in LOSS_NAMES)
+
+  def _ones(self, dev):
+    if self._one is None or self._one.device != dev:
+      self._one = torch.ones(1, dtype=torch.float32, device=dev)
+    return self._one
+
+  def backward_G(self, state, w_gan, w_feat, w_vgg, w_dist):
+    """d(loss_G)/d(netG params), loss_G = w_gan*G_GAN + w_feat*G_GAN_Feat + w_vgg*G_VGG + w_dist*G_Dist."""
+    opt, B = self.opt, state['B']
+    one = self._ones(state['fake'].t.device)
+    fake, real = state['fake'], state['real']
+    d_fake = None
+    if w_gan != 0.0 or w_feat != 0.0:
+      dres = []
+      for i in range(opt.num_D):
+        row = []
+        for j, f in enumerate(state['pred'][i]):
+          ff, fr = f.batch_slice(0, B), f.batch_slice(B, 2 * B)
+          if j == len(state['pred'][i]) - 1:
+            row.append(ops.mse_const_bwd(ff, 1.0, one, w_gan) if w_gan != 0.0 else None)
+          else:
+            row.append(ops.l1_bwd(ff, fr, one, w_feat / opt.num_D) if w_feat != 0.0 else None)
+        dres.append(row)
+      d_in = self.netD.bwd(state['d_ctx'], dres, need_dx=True, need_dw=False, batch=(0, B))
+      d_fake = Act(torch.zeros_like(fake.t), fake.C)
+      ops.channel_copy(d_in, self.label_nc, d_fake, 0, fake.C)
+    if w_vgg != 0.0:
+      wk = networks.VGGLoss.weights
+      dmaps = [ops.l1_bwd(state['vf'][k], state['vr'][k], one, w_vgg * wk[k]) for k in range(len(wk))]
+      dv = self.criterionVGG.vgg.bwd(state['v_ctx'], dmaps)
+      d_fake = dv if d_fake is None else ops.add_(d_fake, dv)
+    if w_dist != 0.0:
+      fn = ops.l1_bwd if opt.distortion_loss_fn == 'l1' else ops.mse_bwd
+      dd = fn(fake, real, one, w_dist)
+      d_fake = dd if d_fake is None else ops.add_(d_fake, dd)
+    if d_fake is None:
+      return False
+    self.netG.bwd(state['g_ctx'], d_fake, need_dx=False, need_dw=True)
+    return True
+
+  def backward_D(self, state, w_d):
+    """d(loss_D)/d(netD params), loss_D = w_d * (D_fake + D_real)  (w_d = 0.5 in the trainer)."""
+    if w_d == 0.0:
+      return False
+    opt, B = self.opt, state['B']
+    one = self._ones(state['fake'].t.device)
+    dres = []
+    for i in range(opt.num_D):
+      p = state['pred'][i][-1]
+      dp = p.empty_like()
+      ops.mse_const_bwd(p.batch_slice(0, B), 0.0, one, w_d, out=dp.batch_slice(0, B))
+      ops.mse_const_bwd(p.batch_slice(B, 2 * B), 1.0, one, w_d, out=dp.batch_slice(B, 2 * B))
+      dres.append([None] * (len(state['pred'][i]) - 1) + [dp])
+    self.netD.bwd(state['d_ctx'], dres, need_dx=False, need_dw=True)
+    return True
+
+  def train_step(self, x_dict, optimizer_G, optimizer_D, lambda_distortion_weight=1.0):
+    """One optimisation step with the reference's order (pix2pixHD_trainer.py:44-78): forward,
+    loss_G backward + Adam(G), loss_D backward + Adam(D).  One host sync (the loss readback)."""
+    opt = self.opt
+    state, slots, layout = self._forward_losses(x_dict)
+    w_gan = 0.0 if opt.no_g_gan_loss else 1.0
+    w_feat = 0.0 if opt.no_gan_feat_loss else opt.lambda_feat
+    w_vgg = 0.0 if opt.no_vgg_loss else opt.lambda_feat
+    w_dist = 0.0 if opt.no_distortion_loss else opt.lambda_distortion * lambda_distortion_weight
+    bg = self.grad_buckets.get('G')
+    if self.backward_G(state, w_gan, w_feat, w_vgg, w_dist):
+      if bg is not None:
+        bg.finish()
+      optimizer_G.step()
+    bd = self.grad_buckets.get('D')
+    if self.backward_D(state, 0.0 if opt.no_d_gan_loss else 0.5):
+      if bd is not None:
+        bd.finish()
+      optimizer_D.step()
+    return self._reduce_losses(slots.cpu().tolist(), layout)
+
+  # ------------------------------------------------------------------------------------------
+  def save(self):
+    self.save_network(self.netG, 'G', self.opt)
+    self.save_network(self.netD, 'D', self.opt)
+
+  def update_fixed_params(self, optimizer_G):
+    """After niter_fix_global epochs also fine-tune the coarse generator (model.py:795-804)."""
+    for m in self.netG.modules():
+      if hasattr(m, 'ensure_grads'):
+        m.ensure_grads()
+    return FusedAdam(list(self.netG.parameters()), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))

@@ -1,0 +1,122 @@
+"""ctypes binding of libjpdse_hip.so (C ABI: include/jpdse.h).
+
+The library is the product; there is deliberately NO fallback.  If the shared object is
+missing or a call fails, this module raises -- it never routes to torch ops or to oracle/.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libjpdse_hip.so')
+
+F32, BF16 = 0, 1
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+
+class JpdseError(RuntimeError):
+  pass
+
+
+class ConvDesc(ctypes.Structure):
+  _fields_ = [('dtype', ctypes.c_int32), ('N', ctypes.c_int32), ('H', ctypes.c_int32),
+              ('W', ctypes.c_int32), ('C', ctypes.c_int32), ('K', ctypes.c_int32),
+              ('R', ctypes.c_int32), ('S', ctypes.c_int32), ('stride', ctypes.c_int32),
+              ('pad', ctypes.c_int32), ('pad_mode', ctypes.c_int32), ('act', ctypes.c_int32),
+              ('slope', ctypes.c_float)]
+
+
+class InormDesc(ctypes.Structure):
+  _fields_ = [('dtype', ctypes.c_int32), ('N', ctypes.c_int32), ('H', ctypes.c_int32),
+              ('W', ctypes.c_int32), ('C', ctypes.c_int32), ('act', ctypes.c_int32),
+              ('slope', ctypes.c_float), ('eps', ctypes.c_float), ('has_residual', ctypes.c_int32)]
+
+
+class AdamEntry(ctypes.Structure):
+  _fields_ = [('p', ctypes.c_void_p), ('g', ctypes.c_void_p), ('m', ctypes.c_void_p),
+              ('v', ctypes.c_void_p), ('n', ctypes.c_int64), ('block0', ctypes.c_int64)]
+
+
+_P, _I32, _I64, _F, _SZ = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,
+                           ctypes.c_size_t)
+_CD, _ND = ctypes.POINTER(ConvDesc), ctypes.POINTER(InormDesc)
+
+# name -> (restype, argtypes); every symbol declared in include/jpdse.h
+SIGNATURES = {
+    'jpdse_version': (_I32, []),
+    'jpdse_last_error': (ctypes.c_char_p, []),
+    'jpdse_arch_check': (_I32, [_I32]),
+    'jpdse_prof_select': (_I32, [_I32, _I32, _I64, _I32]),
+    'jpdse_prof_collect': (_I32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64)]),
+    'jpdse_conv_out_shape': (_I32, [_CD, ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
+    'jpdse_conv_plan_query': (_I32, [_CD, ctypes.POINTER(_I32), _I32]),
+    'jpdse_conv_fwd_pack_size': (_SZ, [_CD]),
+    'jpdse_conv_dgrad_pack_size': (_SZ, [_CD]),
+    'jpdse_conv_pack_weights': (_I32, [_CD, _P, _P, _P, _P]),
+    'jpdse_conv_workspace_size': (_SZ, [_CD]),
+    'jpdse_conv_fwd': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_conv_dgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_conv_wgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_convT_fwd': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_convT_dgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_convT_wgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_inorm_workspace_size': (_SZ, [_ND]),
+    'jpdse_inorm_fwd': (_I32, [_ND, _P, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_inorm_bwd': (_I32, [_ND, _P, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_avgpool3s2_fwd': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    'jpdse_avgpool3s2_bwd': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    'jpdse_maxpool2_fwd': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    'jpdse_maxpool2_bwd': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    'jpdse_act_bwd': (_I32, [_I32, _I64, _I32, _F, _P, _P, _P, _P]),
+    'jpdse_add': (_I32, [_I32, _I64, _P, _P, _P, _P]),
+    'jpdse_channel_sum_workspace_size': (_SZ, [_I64, _I32]),
+    'jpdse_channel_sum': (_I32, [_I32, _I64, _I32, _P, _P, _P, _SZ, _P]),
+    'jpdse_channel_copy': (_I32, [_I32, _I64, _P, _I32, _I32, _P, _I32, _I32, _I32, _P]),
+    'jpdse_zero': (_I32, [_I32, _I64, _P, _P]),
+    'jpdse_nchw_to_nhwc': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    'jpdse_nhwc_to_nchw': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    'jpdse_onehot_edge': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
+    'jpdse_loss_workspace_size': (_SZ, [_I64]),
+    'jpdse_l1_fwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_l1_bwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),
+    'jpdse_mse_fwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_mse_bwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),
+    'jpdse_mse_const_fwd': (_I32, [_I32, _I64, _I32, _F, _P, _P, _P, _SZ, _P]),
+    'jpdse_mse_const_bwd': (_I32, [_I32, _I64, _I32, _F, _P, _P, _F, _P, _P]),
+    'jpdse_adam_step': (_I32, [_P, _I32, _I64, _F, _F, _F, _F, _I32, _F, _P]),
+}
+
+_lib = None
+
+
+def lib():
+  """The loaded library; raises JpdseError when libjpdse_hip.so has not been built."""
+  global _lib
+  if _lib is None:
+    if not os.path.isfile(LIB_PATH):
+      raise JpdseError(
+          'libjpdse_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
+          'g.build()"` or `make -C jpd-se_amd/csrc`.  There is no CPU/torch fallback.' % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(handle, name)   # AttributeError here == ABI/header drift: fail loudly
+      fn.restype, fn.argtypes = res, args
+    _lib = handle
+  return _lib
+
+
+def last_error():
+  return lib().jpdse_last_error().decode('utf-8', 'replace')
+
+
+def check(rc, what):
+  if rc != 0:
+    raise JpdseError('%s failed (%d): %s' % (what, rc, last_error()))
+
+
+def require_gpu(device=0):
+  """Fail loudly unless `device` is a gfx950 GPU visible to this process."""
+  import torch
+  if not torch.cuda.is_available():
+    raise JpdseError('no GPU visible: the JPD-SE HIP path has no CPU fallback')
+  check(lib().jpdse_arch_check(int(device)), 'jpdse_arch_check')

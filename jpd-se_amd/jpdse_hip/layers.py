@@ -1,0 +1,247 @@
+"""Layer objects with explicit forward/backward over the C ABI (no autograd on the hot path).
+
+Each layer exposes
+    fwd(x: Act) -> (y: Act, ctx)          ctx = what backward needs (batch-sliceable)
+    bwd(ctx, dy: Act, need_dx, need_dw) -> dx | None
+Parameters are torch Parameters whose logical shapes/keys equal the reference checkpoint
+layout while their memory is channels_last (= KRSC, the ABI's master
+layout), so `state_dict()` round-trips with reference `net_G.pth` / `net_D.pth` files.
+Weight gradients are written by the kernels straight into persistent `.grad` buffers.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT, F32, BF16
+from . import ops
+from .ops import Act
+
+_weights_epoch = [0]
+
+
+def bump_weights_epoch():
+  """Call after any in-place update of master weights done outside torch's version counter
+  (the fused Adam kernel): packed GEMM panels are rebuilt lazily on next use."""
+  _weights_epoch[0] += 1
+
+
+class Ctx(object):
+  """Saved tensors of one layer call; every entry is batch-first so a sub-batch can be
+  back-propagated on its own (used for the fake half of the batched discriminator pass)."""
+  __slots__ = ('items',)
+
+  def __init__(self, *items):
+    self.items = items
+
+  def slice(self, b0, b1):
+    out = []
+    for it in self.items:
+      if isinstance(it, Act):
+        out.append(it.batch_slice(b0, b1))
+      elif torch.is_tensor(it):
+        out.append(it[b0:b1])
+      elif isinstance(it, Ctx):
+        out.append(it.slice(b0, b1))
+      elif isinstance(it, (list, tuple)):
+        out.append(type(it)(c.slice(b0, b1) if isinstance(c, Ctx) else c for c in it))
+      else:
+        out.append(it)
+    return Ctx(*out)
+
+
+class HipConv2d(nn.Module):
+  """nn.Conv2d / nn.ConvTranspose2d with the padding layer and the activation folded in."""
+
+  def __init__(self, cin, cout, k, stride=1, pad=0, pad_mode=PAD_ZERO, act=ACT_NONE, slope=0.2,
+               apply_bias=True, transposed=False, dtype=F32, device=None):
+    super(HipConv2d, self).__init__()
+    self.cin, self.cout, self.k = cin, cout, k
+    self.stride, self.pad, self.pad_mode = stride, pad, pad_mode
+    self.act, self.slope = act, slope
+    self.apply_bias = apply_bias      # False: conv feeds an affine-less InstanceNorm (bias is dead)
+    self.transposed = transposed
+    self.cdtype = dtype
+    if transposed:
+      assert stride == 2 and pad == 1 and k == 3 and act == ACT_NONE and not apply_bias
+      shape = (cin, cout, k, k)       # torch IOHW
+    else:
+      shape = (cout, cin, k, k)
+    w = torch.empty(shape, device=device).contiguous(memory_format=torch.channels_last)
+    w.normal_(0.0, 0.02)              # weights_init (networks.py:19-25)
+    fan_in = shape[1] * k * k
+    bound = 1.0 / math.sqrt(fan_in)
+    b = torch.empty(cout, device=device).uniform_(-bound, bound)
+    self.weight = nn.Parameter(w)
+    self.bias = nn.Parameter(b)
+    self._packs = None
+    self._pack_key = None
+    self._bias_grad_store = None
+    self.grad_ready_hook = None       # callable(param) fired right after a gradient is written
+
+  # -- descriptors ---------------------------------------------------------------------------
+  def _desc(self, N, H, W):
+    """H, W: spatial size of the underlying Conv2d's INPUT."""
+    if self.transposed:
+      return ops.conv_desc(self.cdtype, N, H, W, self.cout, self.cin, self.k, self.k, 2, 1, PAD_ZERO)
+    return ops.conv_desc(self.cdtype, N, H, W, self.cin, self.cout, self.k, self.k, self.stride, self.pad,
+                         self.pad_mode, self.act, self.slope)
+
+  def _master(self):
+    w = self.weight
+    assert w.dtype == torch.float32 and w.permute(0, 2, 3, 1).is_contiguous(), \
+        'master weights must be fp32 channels_last (KRSC)'
+    return w
+
+  def packs(self):
+    w = self._master()
+    key = (w._version, _weights_epoch[0], w.data_ptr(), self.cdtype)
+    if self._pack_key != key:
+      d = self._desc(1, 64, 64)   # pack layout does not depend on N,H,W
+      if self._packs is None or self._pack_key[3] != self.cdtype:
+        self._packs = ops.conv_pack(d, w, w.device)
+      else:
+        ops.conv_pack_into(d, w, self._packs[0], self._packs[1])
+      self._pack_key = key
+    return self._packs
+
+  def _wgrad_buffer(self):
+    w = self.weight
+    if w.grad is None or w.grad.data_ptr() == 0 or not w.grad.permute(0, 2, 3, 1).is_contiguous():
+      w.grad = torch.zeros_like(w, memory_format=torch.preserve_format)
+    return w.grad
+
+  def _bgrad_buffer(self):
+    if self._bias_grad_store is None or self._bias_grad_store.device != self.bias.device:
+      self._bias_grad_store = torch.zeros(ops.cpad(self.cout), dtype=torch.float32, device=self.bias.device)
+      self.bias.grad = self._bias_grad_store[:self.cout]
+    elif self.bias.grad is None:
+      self.bias.grad = self._bias_grad_store[:self.cout]
+    return self._bias_grad_store
+
+  def ensure_grads(self):
+    if self.weight.requires_grad:
+      self._wgrad_buffer()
+      self._bgrad_buffer()
+
+  # -- forward / backward ---------------------------------------------------------------------
+  def fwd(self, x):
+    fwd_pack, dgrad_pack = self.packs()
+    if self.transposed:
+      d = self._desc(x.N, 2 * x.H, 2 * x.W)
+      y = ops.conv_dgrad(d, x, dgrad_pack)
+      return y, Ctx(x)
+    d = self._desc(x.N, x.H, x.W)
+    y = ops.conv_fwd(d, x, fwd_pack, self.bias if self.apply_bias else None)
+    return y, Ctx(x, y if self.act != ACT_NONE else None)
+
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True):
+    fwd_pack, dgrad_pack = self.packs()
+    need_dw = need_dw and self.weight.requires_grad
+    if self.transposed:
+      (x,) = ctx.items
+      d = self._desc(x.N, 2 * x.H, 2 * x.W)
+      if need_dw:
+        ops.conv_wgrad(d, dy, x, self._wgrad_buffer())
+        self._bgrad_buffer()
+        self._fire()
+      return ops.conv_fwd(d, dy, fwd_pack, None) if need_dx else None
+    x, y = ctx.items
+    d = self._desc(x.N, x.H, x.W)
+    dz = dy if self.act == ACT_NONE else ops.act_bwd(y, dy, self.act, self.slope)
+    if need_dw:
+      ops.conv_wgrad(d, x, dz, self._wgrad_buffer())
+      store = self._bgrad_buffer()
+      if self.apply_bias:
+        ops.channel_sum(dz, store)          # writes CPAD(K) sums into the layer's private store
+        if self.bias.grad.data_ptr() != store.data_ptr():
+          self.bias.grad.copy_(store[:self.cout])   # .grad re-homed into a DDP bucket view
+      self._fire()
+    return ops.conv_dgrad(d, dz, dgrad_pack) if need_dx else None
+
+  def _fire(self):
+    if self.grad_ready_hook is not None:
+      self.grad_ready_hook(self)
+
+
+class InstNormAct(object):
+  """InstanceNorm2d(affine=False, eps=1e-5) + {none, ReLU, LeakyReLU(0.2)} (+ residual)."""
+
+  def __init__(self, act=ACT_NONE, slope=0.2, eps=1e-5):
+    self.act, self.slope, self.eps = act, slope, eps
+
+  def fwd(self, x, residual=None):
+    y, stats = ops.inorm_fwd(x, self.act, self.slope, self.eps, residual)
+    return y, Ctx(x, stats)
+
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True):
+    x, stats = ctx.items
+    return ops.inorm_bwd(x, stats, dy, self.act, self.slope, self.eps)
+
+
+class ConvNormAct(object):
+  """[pad] conv -> InstanceNorm -> activation: one stage of the generator trunk / PatchGAN.
+  A plain object (not an nn.Module) so the conv is registered once, under its reference key."""
+
+  def __init__(self, conv, norm):
+    self.conv, self.norm = conv, norm
+
+  def fwd(self, x):
+    h, c1 = self.conv.fwd(x)
+    y, c2 = self.norm.fwd(h)
+    return y, Ctx(c1, c2)
+
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True):
+    c1, c2 = ctx.items
+    dh = self.norm.bwd(c2, dy)
+    return self.conv.bwd(c1, dh, need_dx, need_dw)
+
+
+class _Slot(nn.Module):
+  """Parameter-free placeholder keeping nn.Sequential indices equal to the reference's."""
+
+  def forward(self, x):
+    return x
+
+
+class HipResnetBlock(nn.Module):
+  """x + IN(conv3(reflpad(ReLU(IN(conv3(reflpad(x)))))))   (networks.py:266-305)."""
+
+  def __init__(self, dim, dtype=F32, device=None):
+    super(HipResnetBlock, self).__init__()
+    mk = lambda: HipConv2d(dim, dim, 3, 1, 1, PAD_REFLECT, apply_bias=False, dtype=dtype, device=device)
+    self.conv_block = nn.Sequential(_Slot(), mk(), _Slot(), _Slot(), _Slot(), mk(), _Slot())
+    self.norm1 = InstNormAct(ACT_RELU)
+    self.norm2 = InstNormAct(ACT_NONE)
+
+  def fwd(self, x):
+    h, c1 = self.conv_block[1].fwd(x)
+    h, n1 = self.norm1.fwd(h)
+    h, c2 = self.conv_block[5].fwd(h)
+    y, n2 = self.norm2.fwd(h, residual=x)
+    return y, Ctx(c1, n1, c2, n2)
+
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True):
+    c1, n1, c2, n2 = ctx.items
+    d = self.norm2.bwd(n2, dy)
+    d = self.conv_block[5].bwd(c2, d, True, need_dw)
+    d = self.norm1.bwd(n1, d)
+    d = self.conv_block[1].bwd(c1, d, need_dx, need_dw)
+    if not need_dx:
+      return None
+    return ops.add_(d, dy)
+
+
+def run_chain_fwd(stages, x):
+  ctxs = []
+  for st in stages:
+    x, c = st.fwd(x)
+    ctxs.append(c)
+  return x, ctxs
+
+
+def run_chain_bwd(stages, ctxs, dy, need_dx=True, need_dw=True):
+  """Back-propagate through `stages`; the first stage computes dx only when need_dx."""
+  for i in range(len(stages) - 1, -1, -1):
+    dy = stages[i].bwd(ctxs[i], dy, need_dx or i > 0, need_dw)
+  return dy

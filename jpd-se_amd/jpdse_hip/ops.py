@@ -1,0 +1,288 @@
+"""Thin tensor-level wrappers over the C ABI.
+
+torch is used for device memory (caching allocator) and the current HIP stream only; all
+arithmetic happens inside libjpdse_hip.so.  Activations travel as `Act`: an NHWC tensor
+[N,H,W,CPAD(C)] (fp32 or bf16) plus its logical channel count.
+"""
+import ctypes
+
+import torch
+
+from . import (lib, check, F32, BF16, ConvDesc, InormDesc, ACT_NONE, PAD_ZERO, PAD_REFLECT)
+
+
+def cpad(c):
+  return (c + 7) & ~7
+
+
+def code_of(tdtype):
+  if tdtype == torch.float32:
+    return F32
+  if tdtype == torch.bfloat16:
+    return BF16
+  raise TypeError('unsupported compute dtype %r' % (tdtype,))
+
+
+def tdtype_of(code):
+  return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def _p(t):
+  return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Act(object):
+  """NHWC activation: `t` has shape [N,H,W,CPAD(C)], padding lanes are zero."""
+  __slots__ = ('t', 'C')
+
+  def __init__(self, t, C):
+    assert t.dim() == 4 and t.shape[3] == cpad(C) and t.is_contiguous(), (tuple(t.shape), C)
+    self.t, self.C = t, C
+
+  N = property(lambda s: s.t.shape[0])
+  H = property(lambda s: s.t.shape[1])
+  W = property(lambda s: s.t.shape[2])
+  Cs = property(lambda s: s.t.shape[3])
+  dtype = property(lambda s: code_of(s.t.dtype))
+
+  def batch_slice(self, b0, b1):
+    return Act(self.t[b0:b1], self.C)
+
+  @staticmethod
+  def empty(N, H, W, C, dtype_code, device):
+    return Act(torch.empty((N, H, W, cpad(C)), dtype=tdtype_of(dtype_code), device=device), C)
+
+  def empty_like(self):
+    return Act(torch.empty_like(self.t), self.C)
+
+
+# ---- shared workspace (all ops are enqueued on one stream, so one arena suffices) ------------
+_ws = {}
+
+
+def workspace(nbytes, device):
+  key = (device.index if device.index is not None else torch.cuda.current_device())
+  cur = _ws.get(key)
+  if cur is None or cur.numel() < nbytes:
+    nbytes = int(nbytes * 1.25) + (1 << 20)
+    cur = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    _ws[key] = cur
+  return cur
+
+
+# ---- convolution ------------------------------------------------------------------------------
+def conv_desc(dtype, N, H, W, C, K, R, S, stride, pad, pad_mode, act=ACT_NONE, slope=0.2):
+  return ConvDesc(dtype, N, H, W, C, K, R, S, stride, pad, pad_mode, act, slope)
+
+
+def conv_out_shape(d):
+  oh, ow = ctypes.c_int32(), ctypes.c_int32()
+  check(lib().jpdse_conv_out_shape(ctypes.byref(d), ctypes.byref(oh), ctypes.byref(ow)), 'conv_out_shape')
+  return oh.value, ow.value
+
+
+def conv_pack(d, w_master, device):
+  """fp32 KRSC master -> (fwd_pack, dgrad_pack) uint8 buffers in the compute dtype."""
+  L = lib()
+  nf, nd = L.jpdse_conv_fwd_pack_size(ctypes.byref(d)), L.jpdse_conv_dgrad_pack_size(ctypes.byref(d))
+  fwd = torch.empty(nf, dtype=torch.uint8, device=device)
+  dgr = torch.empty(nd, dtype=torch.uint8, device=device)
+  check(L.jpdse_conv_pack_weights(ctypes.byref(d), _p(w_master), _p(fwd), _p(dgr), _stream()), 'conv_pack_weights')
+  return fwd, dgr
+
+
+def conv_pack_into(d, w_master, fwd, dgr):
+  check(lib().jpdse_conv_pack_weights(ctypes.byref(d), _p(w_master), _p(fwd), _p(dgr), _stream()),
+        'conv_pack_weights')
+
+
+def _conv_ws(d, device):
+  n = lib().jpdse_conv_workspace_size(ctypes.byref(d))
+  return workspace(n, device), n
+
+
+def conv_fwd(d, x, fwd_pack, bias, out=None):
+  oh, ow = conv_out_shape(d)
+  y = out if out is not None else Act.empty(d.N, oh, ow, d.K, d.dtype, x.t.device)
+  ws, n = _conv_ws(d, x.t.device)
+  check(lib().jpdse_conv_fwd(ctypes.byref(d), _p(x.t), _p(fwd_pack), _p(bias), _p(y.t), _p(ws), ws.numel(), _stream()),
+        'conv_fwd')
+  return y
+
+
+def conv_dgrad(d, dy, dgrad_pack):
+  dx = Act.empty(d.N, d.H, d.W, d.C, d.dtype, dy.t.device)
+  ws, n = _conv_ws(d, dy.t.device)
+  check(lib().jpdse_conv_dgrad(ctypes.byref(d), _p(dy.t), _p(dgrad_pack), _p(dx.t), _p(ws), ws.numel(), _stream()),
+        'conv_dgrad')
+  return dx
+
+
+def conv_wgrad(d, x, dy, dw):
+  """dw: fp32 tensor in the KRSC master layout, overwritten."""
+  ws, n = _conv_ws(d, x.t.device)
+  check(lib().jpdse_conv_wgrad(ctypes.byref(d), _p(x.t), _p(dy.t), _p(dw), _p(ws), ws.numel(), _stream()), 'conv_wgrad')
+
+
+# ---- instance norm ----------------------------------------------------------------------------
+def inorm_fwd(x, act, slope=0.2, eps=1e-5, residual=None):
+  d = InormDesc(x.dtype, x.N, x.H, x.W, x.C, act, slope, eps, 1 if residual is not None else 0)
+  y = x.empty_like()
+  stats = torch.empty((x.N, x.Cs, 2), dtype=torch.float32, device=x.t.device)
+  n = lib().jpdse_inorm_workspace_size(ctypes.byref(d))
+  ws = workspace(n, x.t.device)
+  check(lib().jpdse_inorm_fwd(ctypes.byref(d), _p(x.t), _p(residual.t if residual is not None else None), _p(y.t),
+                              _p(stats), _p(ws), ws.numel(), _stream()), 'inorm_fwd')
+  return y, stats
+
+
+def inorm_bwd(x, stats, dy, act, slope=0.2, eps=1e-5):
+  d = InormDesc(x.dtype, x.N, x.H, x.W, x.C, act, slope, eps, 0)
+  dx = x.empty_like()
+  n = lib().jpdse_inorm_workspace_size(ctypes.byref(d))
+  ws = workspace(n, x.t.device)
+  check(lib().jpdse_inorm_bwd(ctypes.byref(d), _p(x.t), _p(stats), _p(dy.t), _p(dx.t), _p(ws), ws.numel(), _stream()),
+        'inorm_bwd')
+  return dx
+
+
+# ---- pooling ----------------------------------------------------------------------------------
+def avgpool3s2_fwd(x):
+  y = Act.empty(x.N, (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1, x.C, x.dtype, x.t.device)
+  check(lib().jpdse_avgpool3s2_fwd(x.dtype, x.N, x.H, x.W, x.C, _p(x.t), _p(y.t), _stream()), 'avgpool3s2_fwd')
+  return y
+
+
+def avgpool3s2_bwd(dy, H, W):
+  dx = Act.empty(dy.N, H, W, dy.C, dy.dtype, dy.t.device)
+  check(lib().jpdse_avgpool3s2_bwd(dy.dtype, dy.N, H, W, dy.C, _p(dy.t), _p(dx.t), _stream()), 'avgpool3s2_bwd')
+  return dx
+
+
+def maxpool2_fwd(x):
+  y = Act.empty(x.N, x.H // 2, x.W // 2, x.C, x.dtype, x.t.device)
+  check(lib().jpdse_maxpool2_fwd(x.dtype, x.N, x.H, x.W, x.C, _p(x.t), _p(y.t), _stream()), 'maxpool2_fwd')
+  return y
+
+
+def maxpool2_bwd(x, dy):
+  dx = x.empty_like()
+  check(lib().jpdse_maxpool2_bwd(x.dtype, x.N, x.H, x.W, x.C, _p(x.t), _p(dy.t), _p(dx.t), _stream()), 'maxpool2_bwd')
+  return dx
+
+
+# ---- elementwise -------------------------------------------------------------------------------
+def act_bwd(y, dy, act, slope=0.2):
+  dz = y.empty_like()
+  check(lib().jpdse_act_bwd(y.dtype, y.t.numel(), act, slope, _p(y.t), _p(dy.t), _p(dz.t), _stream()), 'act_bwd')
+  return dz
+
+
+def add(a, b):
+  out = a.empty_like()
+  check(lib().jpdse_add(a.dtype, a.t.numel(), _p(a.t), _p(b.t), _p(out.t), _stream()), 'add')
+  return out
+
+
+def add_(a, b):
+  check(lib().jpdse_add(a.dtype, a.t.numel(), _p(a.t), _p(b.t), _p(a.t), _stream()), 'add')
+  return a
+
+
+def zero_(t):
+  check(lib().jpdse_zero(code_of(t.dtype), t.numel(), _p(t), _stream()), 'zero')
+  return t
+
+
+def channel_sum(dy, out):
+  """out: fp32 [>= CPAD(C)] device tensor; receives the per-channel sums (bias gradient)."""
+  npix = dy.N * dy.H * dy.W
+  n = lib().jpdse_channel_sum_workspace_size(npix, dy.C)
+  ws = workspace(n, dy.t.device)
+  check(lib().jpdse_channel_sum(dy.dtype, npix, dy.C, _p(dy.t), _p(out), _p(ws), ws.numel(), _stream()), 'channel_sum')
+
+
+def channel_copy(src, src_c0, dst, dst_c0, nch):
+  assert src.t.shape[:3] == dst.t.shape[:3]
+  npix = src.N * src.H * src.W
+  check(lib().jpdse_channel_copy(src.dtype, npix, _p(src.t), src.Cs, src_c0, _p(dst.t), dst.Cs, dst_c0, nch, _stream()),
+        'channel_copy')
+
+
+def nchw_to_nhwc(src, dtype_code):
+  """fp32 NCHW device tensor -> Act."""
+  assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 4
+  N, C, H, W = src.shape
+  out = Act.empty(N, H, W, C, dtype_code, src.device)
+  check(lib().jpdse_nchw_to_nhwc(dtype_code, N, C, H, W, _p(src), _p(out.t), _stream()), 'nchw_to_nhwc')
+  return out
+
+
+def nhwc_to_nchw(x):
+  out = torch.empty((x.N, x.C, x.H, x.W), dtype=torch.float32, device=x.t.device)
+  check(lib().jpdse_nhwc_to_nchw(x.dtype, x.N, x.C, x.H, x.W, _p(x.t), _p(out), _stream()), 'nhwc_to_nchw')
+  return out
+
+
+def onehot_edge(label, instance, num_labels, total_c, dtype_code):
+  """label fp32 [N,1,H,W], instance int64 [N,1,H,W] -> Act with `total_c` logical channels whose
+  channels [0,num_labels) are the one-hot map and channel num_labels the edge map."""
+  assert label.dtype == torch.float32 and instance.dtype == torch.int64
+  assert label.is_contiguous() and instance.is_contiguous()
+  N, _, H, W = label.shape
+  out = Act.empty(N, H, W, total_c, dtype_code, label.device)
+  check(lib().jpdse_onehot_edge(dtype_code, N, H, W, num_labels, _p(label), _p(instance), _p(out.t), out.Cs, _stream()),
+        'onehot_edge')
+  return out
+
+
+# ---- losses -------------------------------------------------------------------------------------
+def _loss_ws(device):
+  return workspace(lib().jpdse_loss_workspace_size(0), device)
+
+
+def l1_fwd(a, b, out):
+  """out: fp32 device scalar slot (1-element view); mean over LOGICAL elements."""
+  ws = _loss_ws(a.t.device)
+  count = a.N * a.H * a.W * a.C
+  check(lib().jpdse_l1_fwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(out), _p(ws), ws.numel(), _stream()), 'l1_fwd')
+
+
+def l1_bwd(a, b, gout, scale):
+  da = a.empty_like()
+  count = a.N * a.H * a.W * a.C
+  check(lib().jpdse_l1_bwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(gout), scale, _p(da.t), _stream()), 'l1_bwd')
+  return da
+
+
+def mse_fwd(a, b, out):
+  ws = _loss_ws(a.t.device)
+  count = a.N * a.H * a.W * a.C
+  check(lib().jpdse_mse_fwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(out), _p(ws), ws.numel(), _stream()), 'mse_fwd')
+
+
+def mse_bwd(a, b, gout, scale):
+  da = a.empty_like()
+  count = a.N * a.H * a.W * a.C
+  check(lib().jpdse_mse_bwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(gout), scale, _p(da.t), _stream()), 'mse_bwd')
+  return da
+
+
+def mse_const_fwd(x, target, out):
+  assert x.C == 1
+  ws = _loss_ws(x.t.device)
+  npix = x.N * x.H * x.W
+  check(lib().jpdse_mse_const_fwd(x.dtype, npix, x.Cs, target, _p(x.t), _p(out), _p(ws), ws.numel(), _stream()),
+        'mse_const_fwd')
+
+
+def mse_const_bwd(x, target, gout, scale, out=None):
+  dx = out if out is not None else x.empty_like()
+  npix = x.N * x.H * x.W
+  check(lib().jpdse_mse_const_bwd(x.dtype, npix, x.Cs, target, _p(x.t), _p(gout), scale, _p(dx.t), _stream()),
+        'mse_const_bwd')
+  return dx

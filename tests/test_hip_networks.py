@@ -1,0 +1,138 @@
+"""GPU parity, network level: the HIP generator / discriminator / VGG19 against (a) golden
+vectors produced by the REAL reference (tests/golden, oracle/make_golden.py) and (b) the oracle on
+fresh seeded inputs.  fp32 bound 1e-3 relative (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import jpdse_hip
+from jpdse_hip import ops, F32, BF16
+from ctu.models.pix2pixHD_networks import networks
+from oracle.ctu_cpu import nets as onets
+from hip_util import DEV, RTOL, to_act, to_nchw, assert_close, rel_err
+
+
+def _load(golden_dir, name):
+  return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _gen_case(golden_dir, name, cfg, dtype, tol_scale=1.0):
+  g = _load(golden_dir, name)
+  torch.manual_seed(int(g['seed']))
+  sd = onets.init_generator(cfg, 39, 3)           # bit-identical to the reference's define_G(seed)
+  net = networks.define_G(39, 3, cfg['ngf'], cfg['netG'], cfg['n_downsample_global'], cfg['n_blocks_global'],
+                          cfg['n_local_enhancers'], cfg['n_blocks_local'], gpu_ids=[0],
+                          compute_dtype='bf16' if dtype == BF16 else 'fp32')
+  assert list(net.state_dict().keys()) == list(g['keys'])
+  net.load_state_dict(sd)
+  tol = RTOL[dtype] * tol_scale
+  x = torch.tensor(g['x'])
+  y, ctxs = net.fwd(to_act(x, dtype))
+  assert_close(to_nchw(y), g['y'], tol, name + ' forward')
+  # reference-style call: NCHW cuda tensor in, NCHW out
+  assert_close(net(x.to(DEV)).cpu(), g['y'], tol, name + ' forward (NCHW API)')
+  net.bwd(ctxs, to_act(torch.tensor(g['r']), dtype), need_dx=False, need_dw=True)
+  torch.cuda.synchronize()
+  params = dict(net.named_parameters())
+  worst = 0.0
+  for k in g.files:
+    if k.startswith('g:') and k.endswith('.weight'):
+      e = rel_err(params[k[2:]].grad.cpu(), g[k])
+      worst = max(worst, e)
+      assert e <= 5 * tol, '%s grad of %s: %.3e' % (name, k[2:], e)
+  norms = {k: float(p.grad.double().norm()) for k, p in params.items()}
+  for k, ref in zip(g['keys'], g['gradnorms']):
+    k = str(k)
+    if k.endswith('.weight'):
+      assert abs(norms[k] - ref) <= 5 * tol * max(ref, 1e-12), (k, norms[k], ref)
+  return worst
+
+
+GLOBAL8 = dict(netG='global', ngf=8, n_downsample_global=4, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=3)
+LOCAL4 = dict(netG='local', ngf=4, n_downsample_global=4, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=3)
+
+
+def test_global_generator_golden_fp32(golden_dir):
+  _gen_case(golden_dir, 'netG_global_ngf8', GLOBAL8, F32)
+
+
+def test_local_enhancer_golden_fp32(golden_dir):
+  _gen_case(golden_dir, 'netG_local_ngf4', LOCAL4, F32)
+
+
+def test_generators_golden_bf16(golden_dir):
+  # no reference bf16 exists; bound documented in hip_util.RTOL, x3 through ~30 layers
+  _gen_case(golden_dir, 'netG_global_ngf8', GLOBAL8, BF16, tol_scale=3.0)
+  _gen_case(golden_dir, 'netG_local_ngf4', LOCAL4, BF16, tol_scale=3.0)
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_discriminator_golden(golden_dir, dtype):
+  g = _load(golden_dir, 'netD_ndf8')
+  torch.manual_seed(int(g['seed']))
+  sd = onets.init_discriminator(39, 8, 3, 2)
+  net = networks.define_D(39, 8, 3, 'instance', False, 2, True, gpu_ids=[0],
+                          compute_dtype='bf16' if dtype == BF16 else 'fp32')
+  assert list(net.state_dict().keys()) == list(g['keys'])
+  net.load_state_dict(sd)
+  tol = RTOL[dtype] * (3.0 if dtype == BF16 else 1.0)
+  x = torch.tensor(g['x'])
+  result, ctxs = net.fwd(to_act(x, dtype))
+  dres = []
+  for i, scale in enumerate(result):
+    assert len(scale) == 5
+    row = []
+    for j, f in enumerate(scale):
+      ref = g['f:%d:%d' % (i, j)]
+      assert tuple(to_nchw(f).shape) == ref.shape
+      assert_close(to_nchw(f), ref, tol, 'D feature %d/%d' % (i, j))
+      row.append(to_act(torch.full(ref.shape, 0.1 + 0.05 * (i * 5 + j)), dtype))
+    dres.append(row)
+  dx = net.bwd(ctxs, dres, need_dx=True, need_dw=True)
+  torch.cuda.synchronize()
+  assert_close(to_nchw(dx), g['dx'], 5 * tol, 'D input gradient')
+  params = dict(net.named_parameters())
+  for k in g.files:
+    if k.startswith('g:') and k.endswith('.weight'):
+      assert_close(params[k[2:]].grad.cpu(), g[k], 5 * tol, 'D grad ' + k[2:])
+  # sub-batch backward (used for the fake half of the batched pass) == full backward restricted
+  dx0 = net.bwd(ctxs, [[a.batch_slice(0, 1) for a in row] for row in dres], need_dx=True, need_dw=False,
+                batch=(0, 1))
+  assert_close(to_nchw(dx0), g['dx'][0:1], 5 * tol, 'D sub-batch input gradient')
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_vgg19_golden(golden_dir, dtype):
+  g = _load(golden_dir, 'vgg19_seed20')
+  vgg = networks.Vgg19(compute_dtype='bf16' if dtype == BF16 else 'fp32', device=DEV, seed=int(g['vgg_seed']))
+  tol = RTOL[dtype] * (3.0 if dtype == BF16 else 1.0)
+  x = torch.tensor(g['x'])
+  maps, ctxs = vgg.fwd(to_act(x, dtype), save=True)
+  dmaps = []
+  for k, m in enumerate(maps):
+    ref = torch.tensor(g['m:%d' % k])
+    assert_close(to_nchw(m), ref, tol, 'vgg map %d' % k)
+    # d/dm of w_k * mean|m|  (post-ReLU maps are >= 0)
+    dmaps.append(to_act(onets.VGG_LOSS_WEIGHTS[k] * torch.sign(ref) / ref.numel(), dtype))
+  dx = vgg.bwd(ctxs, dmaps)
+  assert_close(to_nchw(dx), g['dx'], 8 * tol, 'vgg input gradient')
+  for p in vgg.parameters():
+    assert not p.requires_grad
+
+
+def test_full_width_generator_vs_oracle():
+  """The production shapes (ngf=64: 1024-channel ResnetBlocks, K=9216) at 32x64, fp32."""
+  cfg = dict(netG='global', ngf=64, n_downsample_global=4, n_blocks_global=9, n_local_enhancers=1, n_blocks_local=3)
+  torch.manual_seed(4321)
+  sd = onets.init_generator(cfg, 39, 3)
+  net = networks.define_G(39, 3, 64, 'global', 4, 9, gpu_ids=[0])
+  net.load_state_dict(sd)
+  x = torch.rand(1, 39, 32, 64, generator=torch.Generator().manual_seed(1)) - 0.5
+  with torch.no_grad():
+    y_ref = onets.generator(sd, x, cfg)
+  y, _ = net.fwd(to_act(x, F32))
+  assert_close(to_nchw(y), y_ref, 1e-3, 'ngf64 generator forward')

@@ -1,0 +1,309 @@
+"""GPU parity, per kernel: every C-ABI op against the torch-CPU oracle primitives on the same
+seeded inputs (fp32: <= 1e-3 relative, the north_star bound; bf16: documented looser bound).
+Shapes cover each distinct conv class of SURVEY.md §2.1 at sizes the CPU finishes in seconds,
+ragged tails (M, K not multiples of the tile), and the borders of pad / pool / convT."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import jpdse_hip
+from jpdse_hip import ops, F32, BF16, PAD_ZERO, PAD_REFLECT, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH
+from jpdse_hip.ops import Act
+from jpdse_hip.layers import HipConv2d, InstNormAct, HipResnetBlock
+from jpdse_hip.optim import FusedAdam
+from oracle.ctu_cpu import nets as onets, model as omodel
+from hip_util import DEV, DTYPES, RTOL, to_act, to_nchw, assert_close, bf16_round, quantize_like
+
+
+def G(seed):
+  return torch.Generator().manual_seed(seed)
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _gpu():
+  jpdse_hip.require_gpu(0)
+
+
+# ---- layout ----------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('C', [1, 3, 39, 64])
+def test_layout_roundtrip(dtype, C):
+  x = torch.randn(2, C, 5, 7, generator=G(C))
+  a = to_act(x, dtype)
+  assert a.t.shape == (2, 5, 7, (C + 7) // 8 * 8)
+  nhwc = a.t.float().cpu()
+  assert torch.equal(nhwc[..., :C], quantize_like(x, dtype).permute(0, 2, 3, 1))
+  assert (nhwc[..., C:] == 0).all()
+  assert torch.equal(to_nchw(a), quantize_like(x, dtype))
+
+
+# ---- convolution -----------------------------------------------------------------------------
+CONV_CASES = [
+    # name,           N, H,  W,  C,    K,   k, st, pad, mode,        act
+    ('g_first7x7',    2, 12, 20, 39,   64,  7, 1,  3,  PAD_REFLECT, ACT_NONE),
+    ('g_down3x3s2',   2, 12, 20, 64,   128, 3, 2,  1,  PAD_ZERO,    ACT_NONE),
+    ('g_down_odd',    1, 11, 13, 16,   24,  3, 2,  1,  PAD_ZERO,    ACT_NONE),
+    ('resblock1024',  1, 4,  8,  1024, 1024, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    ('resblock_tail', 3, 5,  9,  72,   136, 3, 1,  1,  PAD_REFLECT, ACT_NONE),
+    ('g_last7x7tanh', 1, 10, 18, 64,   3,   7, 1,  3,  PAD_REFLECT, ACT_TANH),
+    ('d_layer0',      2, 16, 24, 39,   64,  4, 2,  2,  PAD_ZERO,    ACT_LRELU),
+    ('d_layer2',      2, 9,  13, 128,  256, 4, 2,  2,  PAD_ZERO,    ACT_NONE),
+    ('d_layer3_s1',   1, 5,  9,  256,  512, 4, 1,  2,  PAD_ZERO,    ACT_NONE),
+    ('d_layer4_1ch',  2, 6,  10, 512,  1,   4, 1,  2,  PAD_ZERO,    ACT_NONE),
+    ('vgg_conv1_1',   1, 16, 24, 3,    64,  3, 1,  1,  PAD_ZERO,    ACT_RELU),
+    ('vgg_conv3',     1, 8,  12, 128,  256, 3, 1,  1,  PAD_ZERO,    ACT_RELU),
+    ('local_32ch',    1, 14, 22, 39,   32,  7, 1,  3,  PAD_REFLECT, ACT_NONE),
+]
+
+
+def _torch_conv(x, w, b, st, pad, mode, act):
+  xp = F.pad(x, (pad,) * 4, mode='reflect') if mode == PAD_REFLECT else F.pad(x, (pad,) * 4)
+  y = F.conv2d(xp, w, b, stride=st)
+  if act == ACT_RELU:
+    y = F.relu(y)
+  elif act == ACT_LRELU:
+    y = F.leaky_relu(y, 0.2)
+  elif act == ACT_TANH:
+    y = torch.tanh(y)
+  return y
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+  name, N, H, W, C, K, k, st, pad, mode, act = case
+  g = G(hash(name) % 1000)
+  x = quantize_like(torch.randn(N, C, H, W, generator=g), dtype)
+  w = torch.randn(K, C, k, k, generator=g) * (1.0 / (C * k * k) ** 0.5)
+  b = torch.randn(K, generator=g) * 0.1
+  layer = HipConv2d(C, K, k, st, pad, mode, act=act, apply_bias=True, dtype=dtype, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(w)
+    layer.bias.copy_(b)
+  wq = quantize_like(w, dtype)            # the packed panel is in the compute dtype
+  xr = x.clone().requires_grad_(True)
+  wr = wq.clone().requires_grad_(True)
+  br = b.clone().requires_grad_(True)
+  y_ref = _torch_conv(xr, wr, br, st, pad, mode, act)
+  gy = quantize_like(torch.randn(y_ref.shape, generator=g), dtype)
+  y_ref.backward(gy)
+
+  y, ctx = layer.fwd(to_act(x, dtype))
+  tol = RTOL[dtype]
+  assert_close(to_nchw(y), y_ref.detach(), tol, name + ' fwd')
+  assert (y.t[..., K:] == 0).all(), 'padding lanes of the output must stay zero'
+  dx = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=True)
+  torch.cuda.synchronize()
+  assert_close(to_nchw(dx), xr.grad, 2 * tol, name + ' dgrad')
+  assert (dx.t[..., C:] == 0).all()
+  assert_close(layer.weight.grad.cpu(), wr.grad, 2 * tol, name + ' wgrad')
+  assert_close(layer.bias.grad.cpu(), br.grad, 2 * tol, name + ' bias grad')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 128, 64, 5, 7), (1, 1024, 512, 2, 4), (1, 24, 12, 3, 5)])
+def test_conv_transpose(shape, dtype):
+  N, Cin, Cout, H, W = shape
+  g = G(Cin + H)
+  x = quantize_like(torch.randn(N, Cin, H, W, generator=g), dtype)
+  w = torch.randn(Cin, Cout, 3, 3, generator=g) * (1.0 / (Cin * 9) ** 0.5)
+  layer = HipConv2d(Cin, Cout, 3, 2, 1, transposed=True, apply_bias=False, dtype=dtype, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(w)
+  xr = x.clone().requires_grad_(True)
+  wr = quantize_like(w, dtype).clone().requires_grad_(True)
+  y_ref = F.conv_transpose2d(xr, wr, None, stride=2, padding=1, output_padding=1)
+  gy = quantize_like(torch.randn(y_ref.shape, generator=g), dtype)
+  y_ref.backward(gy)
+  y, ctx = layer.fwd(to_act(x, dtype))
+  assert y.t.shape[1:3] == (2 * H, 2 * W)
+  tol = RTOL[dtype]
+  assert_close(to_nchw(y), y_ref.detach(), tol, 'convT fwd')
+  dx = layer.bwd(ctx, to_act(gy, dtype), True, True)
+  assert_close(to_nchw(dx), xr.grad, 2 * tol, 'convT dgrad')
+  assert_close(layer.weight.grad.cpu(), wr.grad, 2 * tol, 'convT wgrad')
+
+
+# ---- instance norm -----------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('act', [ACT_NONE, ACT_RELU, ACT_LRELU])
+@pytest.mark.parametrize('shape', [(2, 64, 9, 13), (1, 1024, 4, 8), (3, 40, 16, 24), (1, 8, 33, 65)])
+def test_instance_norm_act(shape, act, dtype):
+  N, C, H, W = shape
+  g = G(C * H + act)
+  x = quantize_like(torch.randn(N, C, H, W, generator=g) * 2.0 + 3.0, dtype)   # mean >> 0: stresses the variance
+  xr = x.clone().requires_grad_(True)
+  y_ref = F.instance_norm(xr, eps=1e-5)
+  if act == ACT_RELU:
+    y_ref = F.relu(y_ref)
+  elif act == ACT_LRELU:
+    y_ref = F.leaky_relu(y_ref, 0.2)
+  gy = quantize_like(torch.randn(y_ref.shape, generator=g), dtype)
+  y_ref.backward(gy)
+  layer = InstNormAct(act)
+  y, ctx = layer.fwd(to_act(x, dtype))
+  tol = RTOL[dtype]
+  assert_close(to_nchw(y), y_ref.detach(), tol, 'inorm fwd')
+  dx = layer.bwd(ctx, to_act(gy, dtype))
+  assert_close(to_nchw(dx), xr.grad, 3 * tol, 'inorm bwd')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_resnet_block(dtype):
+  dim, H, W = 64, 6, 10
+  g = G(77)
+  sd = {'b.conv_block.1.weight': torch.randn(dim, dim, 3, 3, generator=g) * 0.05,
+        'b.conv_block.1.bias': torch.randn(dim, generator=g),
+        'b.conv_block.5.weight': torch.randn(dim, dim, 3, 3, generator=g) * 0.05,
+        'b.conv_block.5.bias': torch.randn(dim, generator=g)}
+  x = quantize_like(torch.randn(2, dim, H, W, generator=g), dtype)
+  blk = HipResnetBlock(dim, dtype=dtype, device=DEV)
+  blk.load_state_dict({k[2:]: v for k, v in sd.items()})
+  ref_sd = {k: (quantize_like(v, dtype) if k.endswith('weight') else v).clone().requires_grad_(True)
+            for k, v in sd.items()}
+  xr = x.clone().requires_grad_(True)
+  y_ref = onets.resblock(ref_sd, 'b', xr)
+  gy = quantize_like(torch.randn(y_ref.shape, generator=g), dtype)
+  y_ref.backward(gy)
+  y, ctx = blk.fwd(to_act(x, dtype))
+  tol = RTOL[dtype]
+  assert_close(to_nchw(y), y_ref.detach(), 2 * tol, 'resblock fwd')
+  dx = blk.bwd(ctx, to_act(gy, dtype), True, True)
+  assert_close(to_nchw(dx), xr.grad, 4 * tol, 'resblock dx')
+  assert_close(blk.conv_block[1].weight.grad.cpu(), ref_sd['b.conv_block.1.weight'].grad, 4 * tol, 'resblock dw1')
+  assert_close(blk.conv_block[5].weight.grad.cpu(), ref_sd['b.conv_block.5.weight'].grad, 4 * tol, 'resblock dw5')
+
+
+# ---- pooling -----------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('hw', [(8, 12), (9, 13), (1, 5), (2, 2)])
+def test_avgpool3s2(hw, dtype):
+  H, W = hw
+  x = quantize_like(torch.randn(2, 39, H, W, generator=G(H * W)), dtype)
+  xr = x.clone().requires_grad_(True)
+  y_ref = onets.avgpool3s2(xr)
+  gy = quantize_like(torch.randn(y_ref.shape, generator=G(1)), dtype)
+  y_ref.backward(gy)
+  a = to_act(x, dtype)
+  y = ops.avgpool3s2_fwd(a)
+  assert_close(to_nchw(y), y_ref.detach(), RTOL[dtype], 'avgpool fwd')
+  dx = ops.avgpool3s2_bwd(to_act(gy, dtype), H, W)
+  assert_close(to_nchw(dx), xr.grad, RTOL[dtype], 'avgpool bwd')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('hw', [(8, 12), (9, 13)])
+def test_maxpool2(hw, dtype):
+  H, W = hw
+  x = quantize_like(torch.randn(2, 64, H, W, generator=G(H)), dtype)
+  xr = x.clone().requires_grad_(True)
+  y_ref = F.max_pool2d(xr, 2, 2)
+  gy = quantize_like(torch.randn(y_ref.shape, generator=G(2)), dtype)
+  y_ref.backward(gy)
+  a = to_act(x, dtype)
+  assert torch.equal(to_nchw(ops.maxpool2_fwd(a)), y_ref.detach())
+  dx = ops.maxpool2_bwd(a, to_act(gy, dtype))
+  assert torch.equal(to_nchw(dx), xr.grad)
+
+
+# ---- elementwise -------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_act_bwd_add_channel_ops(dtype):
+  g = G(9)
+  y = quantize_like(torch.randn(2, 24, 5, 7, generator=g), dtype)
+  dy = quantize_like(torch.randn(2, 24, 5, 7, generator=g), dtype)
+  ya, da = to_act(y, dtype), to_act(dy, dtype)
+  tol = RTOL[dtype]
+  assert_close(to_nchw(ops.act_bwd(ya, da, ACT_RELU)), dy * (y > 0).float(), tol, 'relu bwd')
+  assert_close(to_nchw(ops.act_bwd(ya, da, ACT_LRELU, 0.2)), dy * torch.where(y > 0, 1.0, 0.2), tol, 'lrelu bwd')
+  yt = quantize_like(torch.tanh(y), dtype)
+  assert_close(to_nchw(ops.act_bwd(to_act(yt, dtype), da, ACT_TANH)), dy * (1 - yt * yt), tol, 'tanh bwd')
+  assert_close(to_nchw(ops.add(ya, da)), y + dy, tol, 'add')
+  out = torch.zeros(24, device=DEV)
+  ops.channel_sum(da, out)
+  assert_close(out.cpu(), dy.sum((0, 2, 3)), tol, 'channel_sum')
+  dst = Act(torch.zeros(2, 5, 7, 40, dtype=ya.t.dtype, device=DEV), 39)
+  ops.channel_copy(ya, 0, dst, 36, 3)
+  got = to_nchw(dst)
+  assert torch.equal(got[:, 36:39], y[:, 0:3]) and (got[:, :36] == 0).all()
+
+
+def test_onehot_edge_integer_exact(golden_dir):
+  import os
+  gd = np.load(os.path.join(golden_dir, 'preprocess_cityscapes_crop.npz'))
+  lab = torch.tensor(gd['label'].astype(np.float32))[None, None]
+  lab[lab == 255] = 35
+  ins = torch.tensor(gd['instance'].astype(np.int64))[None, None]
+  for dtype in DTYPES:
+    out = ops.onehot_edge(lab.to(DEV).contiguous(), ins.to(DEV).contiguous(), 35, 39, dtype)
+    got = to_nchw(out)
+    assert np.array_equal(got[:, :36].numpy().astype(np.uint8), gd['input_label'])   # the reference's output
+    assert (got[:, 36:] == 0).all()
+  # batch > 1, ragged size, ids up to 34, vs the oracle
+  xd = omodel.synthetic_batch(3, 20, 44, seed=5)
+  ref = omodel.preprocess(xd, omodel.default_opt())
+  out = ops.onehot_edge(xd['label'].to(DEV).contiguous(), xd['instance'].to(DEV).contiguous(), 35, 39, F32)
+  assert torch.equal(to_nchw(out)[:, :36], ref)
+
+
+# ---- losses ------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_losses_fwd_bwd(dtype):
+  g = G(11)
+  a = quantize_like(torch.randn(2, 39, 9, 13, generator=g), dtype)
+  b = quantize_like(torch.randn(2, 39, 9, 13, generator=g), dtype)
+  A, Bm = to_act(a, dtype), to_act(b, dtype)
+  slots = torch.zeros(4, device=DEV)
+  one = torch.full((1,), 0.5, device=DEV)
+  ops.l1_fwd(A, Bm, slots[0:1])
+  ops.mse_fwd(A, Bm, slots[1:2])
+  ar = a.clone().requires_grad_(True)
+  F.l1_loss(ar, b).backward()
+  tol = RTOL[dtype]
+  assert_close(slots[0].cpu(), F.l1_loss(a, b), 1e-4, 'l1 fwd')
+  assert_close(slots[1].cpu(), F.mse_loss(a, b), 1e-4, 'mse fwd')
+  assert_close(to_nchw(ops.l1_bwd(A, Bm, one, 3.0)), 1.5 * ar.grad, tol, 'l1 bwd')
+  ar.grad = None
+  F.mse_loss(ar, b).backward()
+  assert_close(to_nchw(ops.mse_bwd(A, Bm, one, 3.0)), 1.5 * ar.grad, tol, 'mse bwd')
+  p = quantize_like(torch.randn(3, 1, 7, 11, generator=g), dtype)
+  P = to_act(p, dtype)
+  ops.mse_const_fwd(P, 1.0, slots[2:3])
+  pr = p.clone().requires_grad_(True)
+  F.mse_loss(pr, torch.ones_like(pr)).backward()
+  assert_close(slots[2].cpu(), F.mse_loss(p, torch.ones_like(p)), 1e-4, 'mse_const fwd')
+  dp = ops.mse_const_bwd(P, 1.0, one, 2.0)
+  assert_close(to_nchw(dp), pr.grad, tol, 'mse_const bwd')
+  assert (dp.t[..., 1:] == 0).all()
+
+
+# ---- Adam --------------------------------------------------------------------------------------
+def test_fused_adam_matches_torch():
+  g = G(13)
+  shapes = [(16, 8, 3, 3), (5,), (1030,), (3, 64, 7, 7)]
+  ps = [torch.randn(s, generator=g) for s in shapes]
+  ref = [p.clone().requires_grad_(True) for p in ps]
+  mine = []
+  for p in ps:
+    q = p.clone().to(DEV)
+    if q.dim() == 4:
+      q = q.contiguous(memory_format=torch.channels_last)
+    mine.append(torch.nn.Parameter(q))
+  o_ref = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+  o_hip = FusedAdam(mine, lr=2e-4, betas=(0.5, 0.999))
+  for step in range(3):
+    for r, m in zip(ref, mine):
+      gr = torch.randn(r.shape, generator=g)
+      r.grad = gr.clone()
+      if m.grad is None:
+        m.grad = torch.zeros_like(m, memory_format=torch.preserve_format)
+      m.grad.copy_(gr)
+    o_ref.step()
+    o_hip.step()
+  for r, m in zip(ref, mine):
+    assert_close(m.detach().cpu(), r.detach(), 1e-6, 'adam param')
+  sd = o_hip.state_dict()
+  assert set(sd['state'][0].keys()) >= {'step', 'exp_avg', 'exp_avg_sq'} and float(sd['state'][0]['step']) == 3.0
