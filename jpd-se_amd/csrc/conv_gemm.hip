@@ -111,6 +111,50 @@ template <int TM, int TN> struct MmaChunk<float, TM, TN> {
   }
 };
 
+// fp32 only: every kFlushChunks K-chunks the running MFMA accumulator is folded into a second
+// fp32 accumulator and cleared.  A v_mfma_f32_32x32x2_f32 chain is a plain sequential fma chain
+// (rounding error ~ sqrt(chain length)); two-level summation brings a K = 9216 reduction from
+// ~7x torch-CPU's rounding error down to its level, which matters for fp32 parity of gradients
+// through the sign()-discontinuous L1 losses.  bf16 keeps a single accumulator.
+static constexpr int kFlushChunks = 16;
+template <typename T, int TM, int TN> struct TwoLevel {
+  __device__ static __forceinline__ void init(f32x16 (&)[TM][TN]) {}
+  __device__ static __forceinline__ void flush(int, f32x16 (&)[TM][TN], f32x16 (&)[TM][TN]) {}
+  __device__ static __forceinline__ void finish(f32x16 (&)[TM][TN], f32x16 (&)[TM][TN]) {}
+  static constexpr int kMasters = 1;   // dummy storage
+};
+template <int TM, int TN> struct TwoLevel<float, TM, TN> {
+  __device__ static __forceinline__ void init(f32x16 (&m)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m[i][j][e] = 0.f;
+  }
+  __device__ static __forceinline__ void flush(int t, f32x16 (&acc)[TM][TN], f32x16 (&m)[TM][TN]) {
+    if ((t % kFlushChunks) != kFlushChunks - 1) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          m[i][j][e] += acc[i][j][e];
+          acc[i][j][e] = 0.f;
+        }
+  }
+  __device__ static __forceinline__ void finish(f32x16 (&acc)[TM][TN], f32x16 (&m)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += m[i][j][e];
+  }
+  static constexpr int kMasters = TM * TN;
+};
+
 template <int TM, int TN, int BMW, int BNW>
 __device__ __forceinline__ void frag_offsets(int lane, int wm, int wn, int (&a_rd)[TM][2], int (&b_rd)[TN][2]) {
   const int r = lane & 31, h = lane >> 5;
@@ -187,6 +231,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArg
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  f32x16 master[(sizeof(T) == 4) ? TM : 1][(sizeof(T) == 4) ? TN : 1];
+  using TL = TwoLevel<T, (sizeof(T) == 4) ? TM : 1, (sizeof(T) == 4) ? TN : 1>;
+  if constexpr (sizeof(T) == 4) TL::init(master);
   const int T_total = a.R * a.cpr;
   const long long a_row_bytes = a.in_sr * ES;
   u32x4 areg[AV], breg[BV];
@@ -216,6 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArg
       for (int i = 0; i < BV; ++i) breg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + b_off);
     }
     MmaChunk<T, TM, TN>::run(As + cur * BM * 64, Bs + cur * BN * 64, a_rd, b_rd, acc);
+    if constexpr (sizeof(T) == 4) TL::flush(t, acc, master);
     if (more) {
       char* const An = As + (cur ^ 1) * BM * 64;
       char* const Bn = Bs + (cur ^ 1) * BN * 64;
@@ -227,6 +275,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArg
     __syncthreads();
   }
 
+  if constexpr (sizeof(T) == 4) TL::finish(acc, master);
   // ---- epilogue: bias + activation, NHWC store through the output addressing -------------
   long long* const row_off = reinterpret_cast<long long*>(smem);
   for (int row = tid; row < BM; row += NT) {
@@ -397,6 +446,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_kernel(const GemmWgra
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  f32x16 master[(sizeof(T) == 4) ? TM : 1][(sizeof(T) == 4) ? TN : 1];
+  using TL = TwoLevel<T, (sizeof(T) == 4) ? TM : 1, (sizeof(T) == 4) ? TN : 1>;
+  if constexpr (sizeof(T) == 4) TL::init(master);
   const T* const DY = reinterpret_cast<const T*>(a.DY);
   const T* const X = reinterpret_cast<const T*>(a.X);
   typename ST::Regs areg[AI], breg[BI];
@@ -468,9 +520,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_kernel(const GemmWgra
       load_chunk();
     }
     MmaChunk<T, TM, TN>::run(As + cur * BM * 64, Bs + cur * BN * 64, a_rd, b_rd, acc);
+    if constexpr (sizeof(T) == 4) TL::flush(c - c_begin, acc, master);
     if (more) store_chunk(cur ^ 1);
     __syncthreads();
   }
+  if constexpr (sizeof(T) == 4) TL::finish(acc, master);
 
   // ---- epilogue: scatter the (k, r, j) tile into the fp32 KRSC master-layout gradient -----
 #pragma unroll

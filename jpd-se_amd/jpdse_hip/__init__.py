@@ -93,6 +93,9 @@ def lib():
   """The loaded library; raises JpdseError when libjpdse_hip.so has not been built."""
   global _lib
   if _lib is None:
+    # torch first: it ships its own libamdhip64; loading ours before it would put a second HIP
+    # runtime (the system one) into the process, which then sees no device.
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
       raise JpdseError(
           'libjpdse_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '

@@ -82,7 +82,8 @@ def preprocess(x_dict, opt):
   b, _, h, w = lab.shape
   nc = opt.num_labels + 1 if opt.contain_dontcare_label else opt.num_labels
   onehot = torch.zeros(b, nc, h, w).scatter_(1, lab, 1.0)
-  return torch.cat((onehot, edge_map(x_dict['instance'])), dim=1)
+  out = torch.cat((onehot, edge_map(x_dict['instance'])), dim=1)
+  return out.to(x_dict['image'].dtype) if 'image' in x_dict else out
 
 
 def tensor2im(img, opt):
@@ -161,6 +162,30 @@ class OracleTrainer(object):
       loss_dist = F.mse_loss(fake, real)
     self.last_fake = fake
     return loss_G_GAN, loss_feat, loss_vgg, loss_dist, loss_D_real, loss_D_fake
+
+  def grads_in_dtype(self, x_dict, dtype):
+    """(d loss_G / d G-params, d loss_D / d D-params) at the CURRENT weights, evaluated in
+    `dtype` (float64 gives the conditioning yardstick the GPU parity tests use: the L1 terms
+    have sign() gradients, so two correct fp32 implementations differ by ~sqrt(#sign flips))."""
+    opt = self.opt
+    keepG, keepD, keepV = self.G, self.D, self.vgg
+    try:
+      self.G = OrderedDict((k, v.detach().to(dtype).requires_grad_(True)) for k, v in keepG.items())
+      self.D = OrderedDict((k, v.detach().to(dtype).requires_grad_(True)) for k, v in keepD.items())
+      self.vgg = OrderedDict((k, v.to(dtype)) for k, v in keepV.items())
+      xd = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in x_dict.items()}
+      L = dict(zip(LOSS_NAMES, self.train_losses(xd)))
+      loss_G = 0
+      if not opt.no_g_gan_loss: loss_G = loss_G + L['G_GAN']
+      if not opt.no_vgg_loss: loss_G = loss_G + L['G_VGG'] * opt.lambda_feat
+      if not opt.no_gan_feat_loss: loss_G = loss_G + L['G_GAN_Feat'] * opt.lambda_feat
+      if not opt.no_distortion_loss:
+        loss_G = loss_G + L['G_Distortion'] * opt.lambda_distortion * self.lambda_distortion_weight
+      gG = torch.autograd.grad(loss_G, list(self.G.values()), retain_graph=True, allow_unused=True)
+      gD = torch.autograd.grad((L['D_fake'] + L['D_real']) * 0.5, list(self.D.values()), allow_unused=True)
+      return (OrderedDict(zip(self.G.keys(), gG)), OrderedDict(zip(self.D.keys(), gD)))
+    finally:
+      self.G, self.D, self.vgg = keepG, keepD, keepV
 
   # -- public API mirrored from Pix2PixHDTrainer -----------------------------
   def step(self, x_dict, keep_grads=False):
