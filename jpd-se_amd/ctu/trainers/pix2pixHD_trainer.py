@@ -41,7 +41,10 @@ class Pix2PixHDTrainer(BaseTrainer):
     world = dist.get_world_size(process_group)
     for net in (self.model.netG, self.model.netD):
       for p in net.parameters():
-        dist.broadcast(p.data, src=0, group=process_group)
+        # 4-D masters are channels_last: hand the collective the dense KRSC view of the same memory
+        dense = p.data.permute(0, 2, 3, 1) if p.dim() == 4 else p.data
+        assert dense.is_contiguous()
+        dist.broadcast(dense, src=0, group=process_group)
     bump_weights_epoch()
     for tag, net, optim in (('G', self.model.netG, self.optimizer_G), ('D', self.model.netD, self.optimizer_D)):
       trained = {id(p) for grp in optim.param_groups for p in grp['params']}

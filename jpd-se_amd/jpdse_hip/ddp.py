@@ -28,7 +28,7 @@ class GradBuckets(object):
     self.buckets = []        # dict(flat, params[(name,param,offset,numel)], pending, handle)
     cur, cur_bytes = [], 0
     for n, p in items:
-      nb = p.numel() * 4
+      nb = p.numel() * p.element_size()
       if cur and cur_bytes + nb > bucket_bytes:
         self.buckets.append(self._make_bucket(cur))
         cur, cur_bytes = [], 0
@@ -44,9 +44,9 @@ class GradBuckets(object):
 
   @staticmethod
   def _make_bucket(items):
-    total = sum(((p.numel() + 3) // 4) * 4 for _, p in items)   # keep every view 16-byte aligned
-    dev = items[0][1].device
-    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    dev, dt = items[0][1].device, items[0][1].dtype    # fp32 masters on the GPU (fp64 in CPU tests)
+    total = sum(((p.numel() + 3) // 4) * 4 for _, p in items)   # keep every view >= 16-byte aligned
+    flat = torch.zeros(total, dtype=dt, device=dev)
     params, off = [], 0
     for n, p in items:
       numel = p.numel()
@@ -92,4 +92,4 @@ class GradBuckets(object):
     self.reset()
 
   def total_bytes(self):
-    return sum(b['flat'].numel() * 4 for b in self.buckets)
+    return sum(b['flat'].numel() * b['flat'].element_size() for b in self.buckets)
