@@ -59,6 +59,9 @@ int jpdse_arch_check(int device);
  * jpdse_prof_collect waits for them and returns the summed kernel time, the summed algorithmic
  * FLOPs (2*M*Ks*kdim per launch) and the number of launches, then resets the log.
  * Not thread safe; select with enable = 0 to switch it off. */
+/* A/B switch for tests and benchmarks: 0 routes every convolution through the generic
+ * register-staged kernels, 1 (default) lets eligible bf16 layers use the LDS-DMA fast kernel. */
+int jpdse_debug_set_fast_path(int32_t enable);
 int jpdse_prof_select(int32_t enable, int32_t Ks, int64_t kdim, int32_t max_launches);
 int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
 

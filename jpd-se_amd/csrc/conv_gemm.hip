@@ -66,6 +66,11 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   return v;
 }
 
+}  // namespace jpdse
+#include "gemm_fast.h"
+#include "wgrad_fast.h"
+namespace jpdse {
+
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
 template <typename T, int TM, int TN> struct MmaChunk;
 
@@ -840,10 +845,85 @@ static int launch_wgrad(const GemmWgradArgs& a, hipStream_t s) {
   return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, s);
 }
 
+template <int WM, int WN, int TM, int TN>
+static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int lds = 3 * 2 * (BM + BN) * 64;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<WM, WN, TM, TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_fast: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Ks + BN - 1) / BN;
+  const long long kdim = (long long)a.R * a.S * a.Cs;
+  const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
+                     (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a);
+  if (timed) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
+    g_prof.flops[g_prof.used] = 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
+    ++g_prof.used;
+  }
+  return check_launch("gemm_fast_kernel");
+}
+
+static int launch_fast(const FastArgs& a, hipStream_t s) {
+  if (a.M <= 0) return JPDSE_OK;
+  if (a.Ks > 64) return launch_fast_cfg<4, 2, 2, 2>(a, s);   // 256 x 128
+  if (a.Ks > 32) return launch_fast_cfg<4, 2, 2, 1>(a, s);   // 256 x 64
+  return launch_fast_cfg<8, 1, 1, 1>(a, s);                  // 256 x 32
+}
+
+static bool g_fast_enabled = true;   // jpdse_debug_set_fast_path(0) forces the generic kernels (A/B tests)
+
+// The fast kernel runs ONE 256-row tile per CU (144 KiB of LDS), so its grid should either cover
+// the 256 CUs many times over or be an exact multiple of them; in between (e.g. the 288 tiles of the
+// ResnetBlock data gradient) the generic 128x128 kernel with 3 co-resident blocks per CU wins
+// (measured: scripts/bench_conv.py, profiles/r01_conv_layers_*.log).
+static bool fast_pays(int M, int Ks) {
+  if (!g_fast_enabled) return false;
+  const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32);
+  const long long tiles = (long long)((M + 255) / 256) * ((Ks + bn - 1) / bn);
+  return tiles >= 448 || (tiles >= 256 && tiles % 256 == 0);
+}
+
 template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
                       const float* bias, void* y, void* ws, hipStream_t s) {
-  // always staged through the workspace: the GEMM loaders rely on the zeroed slack behind it
+  if constexpr (sizeof(T) == 2) {
+    if (p.Cs % 64 == 0 && fast_pays(d->N * p.OH * p.OW, p.Ks)) {
+      FastArgs f = {};
+      f.X = reinterpret_cast<const bf16_t*>(x);
+      f.B = reinterpret_cast<const bf16_t*>(pack);
+      f.bias = bias;
+      f.Y = reinterpret_cast<bf16_t*>(y);
+      f.M = d->N * p.OH * p.OW;
+      f.OH = p.OH;
+      f.OW = p.OW;
+      f.IH = d->H;
+      f.IW = d->W;
+      f.Cs = p.Cs;
+      f.R = d->R;
+      f.S = d->S;
+      f.sy = f.sx = d->stride;
+      f.py = f.px = d->pad;
+      f.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+      f.Kout = d->K;
+      f.Ks = p.Ks;
+      f.b_rows = p.Ks;
+      f.out_sn = (long long)p.OH * p.OW * p.Ks;
+      f.out_sh = (long long)p.OW * p.Ks;
+      f.out_sw = p.Ks;
+      f.out_base = 0;
+      f.act = d->act;
+      f.slope = d->slope;
+      return launch_fast(f, s);
+    }
+  }
+  // generic path: staged through the workspace, the GEMM loaders rely on the zeroed slack behind it
   if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
     return rc;
   const void* xin = ws;
@@ -882,12 +962,62 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   void* dyp = wsb;
   void* dxp = wsb + p.dypad_bytes;
   const bool refl = d->pad_mode == JPDSE_PAD_REFLECT;
-  int rc = launch_pad<T>(dy, dyp, d->N, p.OH, p.OW, p.Ks, p.PT, p.PB, p.PL, p.PR, JPDSE_PAD_ZERO, s);
-  if (rc) return rc;
   const int st = d->stride;
+  bool fast = false;
+  if constexpr (sizeof(T) == 2) {
+    fast = p.Ks % 64 == 0;
+    for (int i = 0; i < p.nph && fast; ++i)
+      if (p.ph[i].cnth > 0 && p.ph[i].cntw > 0) fast = fast_pays(d->N * p.ph[i].cnth * p.ph[i].cntw, p.Cs);
+  }
+  int rc = JPDSE_OK;
+  if (!fast) {
+    rc = launch_pad<T>(dy, dyp, d->N, p.OH, p.OW, p.Ks, p.PT, p.PB, p.PL, p.PR, JPDSE_PAD_ZERO, s);
+    if (rc) return rc;
+  }
   for (int i = 0; i < p.nph; ++i) {
     const Phase& f = p.ph[i];
     if (f.cnth <= 0 || f.cntw <= 0) continue;
+    if constexpr (sizeof(T) == 2) {
+      if (fast) {
+        FastArgs g = {};
+        g.X = reinterpret_cast<const bf16_t*>(dy);
+        g.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
+        g.bias = nullptr;
+        g.M = d->N * f.cnth * f.cntw;
+        g.OH = f.cnth;
+        g.OW = f.cntw;
+        g.IH = p.OH;
+        g.IW = p.OW;
+        g.Cs = p.Ks;
+        g.R = f.Uh;
+        g.S = f.Uw;
+        g.sy = g.sx = 1;
+        g.py = (f.Uh - 1) - f.i0h;
+        g.px = (f.Uw - 1) - f.i0w;
+        g.reflect = 0;
+        g.Kout = d->C;
+        g.Ks = p.Cs;
+        g.b_rows = p.Cs;
+        if (refl) {
+          g.Y = reinterpret_cast<bf16_t*>(dxp);
+          g.out_sn = (long long)p.Hp * p.Wp * p.Cs;
+          g.out_sh = (long long)st * p.Wp * p.Cs;
+          g.out_sw = (long long)st * p.Cs;
+          g.out_base = ((long long)(st * f.i0h + f.qh) * p.Wp + (st * f.i0w + f.qw)) * p.Cs;
+        } else {
+          g.Y = reinterpret_cast<bf16_t*>(dx);
+          g.out_sn = (long long)d->H * d->W * p.Cs;
+          g.out_sh = (long long)st * d->W * p.Cs;
+          g.out_sw = (long long)st * p.Cs;
+          g.out_base = ((long long)(st * f.i0h + f.qh - d->pad) * d->W + (st * f.i0w + f.qw - d->pad)) * p.Cs;
+        }
+        g.act = JPDSE_ACT_NONE;
+        g.slope = 0.f;
+        rc = launch_fast(g, s);
+        if (rc) return rc;
+        continue;
+      }
+    }
     GemmFwdArgs a = {};
     a.A = dyp;
     a.B = reinterpret_cast<const char*>(pack) + f.pack_off;
@@ -935,9 +1065,71 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   return rc;
 }
 
+template <int TM, int TN>
+static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int lds = 2 * 64 * 2 * (BM + BN);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<TM, TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_fast: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  a.chunks_total = (a.M + 63) / 64;
+  const int tiles = ((a.Ks + BM - 1) / BM) * a.R * a.S * ((a.Cs + BN - 1) / BN);
+  int splits = 1;
+  if (tiles < 512) {
+    splits = (768 + tiles - 1) / tiles;
+    const int max_splits = (a.chunks_total + 7) / 8;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  a.chunks_per_split = (a.chunks_total + splits - 1) / splits;
+  splits = (a.chunks_total + a.chunks_per_split - 1) / a.chunks_per_split;
+  a.atomic = splits > 1;
+  if (a.atomic) {
+    hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), s);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL((wgrad_fast_kernel<TM, TN>), dim3(tiles, splits), dim3(256), lds, s, a);
+  return check_launch("wgrad_fast_kernel");
+}
+
+static int launch_wgrad_fast(const FastWgArgs& a, hipStream_t s) {
+  const bool m2 = a.Ks >= 128, n2 = a.Cs >= 128;
+  if (m2 && n2) return launch_wgrad_fast_cfg<2, 2>(a, s);
+  if (m2) return launch_wgrad_fast_cfg<2, 1>(a, s);
+  if (n2) return launch_wgrad_fast_cfg<1, 2>(a, s);
+  return launch_wgrad_fast_cfg<1, 1>(a, s);
+}
+
 template <typename T>
 static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* dy, float* dw,
                         void* ws, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (g_fast_enabled && p.Cs % 64 == 0 && p.Ks % 64 == 0) {
+      FastWgArgs f = {};
+      f.X = reinterpret_cast<const bf16_t*>(x);
+      f.DY = reinterpret_cast<const bf16_t*>(dy);
+      f.DW = dw;
+      f.M = d->N * p.OH * p.OW;
+      f.OH = p.OH;
+      f.OW = p.OW;
+      f.IH = d->H;
+      f.IW = d->W;
+      f.Cs = p.Cs;
+      f.C = d->C;
+      f.Ks = p.Ks;
+      f.K = d->K;
+      f.R = d->R;
+      f.S = d->S;
+      f.sy = f.sx = d->stride;
+      f.py = f.px = d->pad;
+      f.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+      return launch_wgrad_fast(f, s);
+    }
+  }
   // always staged through the workspace: the GEMM loaders rely on the zeroed slack behind it
   if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
     return rc;
@@ -981,6 +1173,11 @@ int jpdse_conv_out_shape(const jpdse_conv_desc* d, int32_t* OH, int32_t* OW) {
   make_plan(d, &p);
   *OH = p.OH;
   *OW = p.OW;
+  return JPDSE_OK;
+}
+
+int jpdse_debug_set_fast_path(int32_t enable) {
+  g_fast_enabled = enable != 0;
   return JPDSE_OK;
 }
 

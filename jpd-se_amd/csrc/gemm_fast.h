@@ -1,0 +1,243 @@
+// Fast bf16 implicit-GEMM convolution kernel (forward / data gradient) for CDNA4.
+//
+// Used whenever the input channel storage is a multiple of 64 (every layer of the hot path except
+// the 40-channel network inputs and the 8-channel images).  Differences from gemm_fwd_kernel:
+//   * no materialised padding: the A loader resolves reflect / zero padding per K-tile (one K-tile
+//     = 64 channels of ONE filter tap), zero taps read a zero page;
+//   * staging is LDS-DMA: `global_load_lds_dwordx4` writes 1 KiB per wave instruction straight
+//     into LDS (16 rows x 64 B of a half-tile).  The DMA destination is lane-linear, so the
+//     conflict-free XOR swizzle of the 16-byte slots is applied to the per-lane SOURCE address and
+//     again on the fragment reads (cdna_hip_programming.md rule 21);
+//   * a 3-stage LDS ring (3 x 48 KiB for the 256x128 tile), one raw s_barrier per K-tile and a
+//     COUNTED s_waitcnt vmcnt(N): the DMA of tile t+1 stays in flight across the barrier while
+//     tile t is consumed and tile t+2 is issued (never vmcnt(0) inside the loop);
+//   * 8 waves (2 per SIMD), BK = 64, s_setprio around the MFMA cluster.
+#pragma once
+#include "common.h"
+
+namespace jpdse {
+
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];   // 256 B of zeros (static init)
+
+struct FastArgs {
+  const bf16_t* X;     // NHWC input [N][IH][IW][Cs], NOT padded
+  const bf16_t* B;     // panel [b_rows][R*S*Cs]
+  const float* bias;
+  bf16_t* Y;
+  int M, OH, OW;
+  int IH, IW, Cs;
+  int R, S;
+  int sy, sx;          // ih = oh*sy + r - py
+  int py, px;
+  int reflect;
+  int Kout, Ks, b_rows;
+  long long out_sn, out_sh, out_sw, out_base;
+  int act;
+  float slope;
+};
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs a) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int STAGES = 3;
+  constexpr int A_HALF = BM * 64, B_HALF = BN * 64;
+  constexpr int STAGE_BYTES = 2 * (A_HALF + B_HALF);
+  constexpr int A_RG = BM / 16, B_RG = BN / 16;     // 16-row groups per half
+  constexpr int A_UNITS = 2 * A_RG, B_UNITS = 2 * B_RG;
+  constexpr int AU = (A_UNITS + NW - 1) / NW, BU = (B_UNITS + NW - 1) / NW;
+  static_assert(A_UNITS % NW == 0, "every wave stages the same number of A units");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int lrow = lane >> 2, lslot = lane & 3;
+
+  // ---- per-unit staging state -------------------------------------------------------------
+  long long a_nbase[AU];
+  int a_oh[AU], a_ow[AU], a_choff[AU], a_lds[AU];
+#pragma unroll
+  for (int i = 0; i < AU; ++i) {
+    const int u = wid + i * NW;
+    const int half = u / A_RG, rg = u % A_RG;
+    const int row = rg * 16 + lrow;
+    int m = m0 + row;
+    m = m < a.M ? m : a.M - 1;
+    const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
+    a_nbase[i] = (long long)n * a.IH * a.IW * a.Cs;
+    a_oh[i] = oh * a.sy - a.py;
+    a_ow[i] = ow * a.sx - a.px;
+    a_choff[i] = half * 32 + ((lslot ^ (row >> 3)) & 3) * 8;
+    a_lds[i] = half * A_HALF + rg * 1024;
+  }
+  const bf16_t* b_ptr[BU];
+  int b_lds[BU];
+  bool b_on[BU];
+  const long long ktot = (long long)a.R * a.S * a.Cs;
+#pragma unroll
+  for (int j = 0; j < BU; ++j) {
+    const int u = wid + j * NW;
+    b_on[j] = u < B_UNITS;
+    const int uu = b_on[j] ? u : 0;
+    const int half = uu / B_RG, rg = uu % B_RG;
+    const int row = rg * 16 + lrow;
+    int br = n0 + row;
+    br = br < a.b_rows ? br : a.b_rows - 1;
+    b_ptr[j] = a.B + (long long)br * ktot + half * 32 + ((lslot ^ (row >> 3)) & 3) * 8;
+    b_lds[j] = 2 * A_HALF + half * B_HALF + rg * 1024;
+  }
+  int n_b = 0;
+#pragma unroll
+  for (int j = 0; j < BU; ++j) n_b += b_on[j] ? 1 : 0;   // wave-uniform
+  const int LW = AU + n_b;                               // DMA instructions per wave per K-tile
+
+  int a_rd[TM][2], b_rd[TN][2];
+  {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * TM * 32 + i * 32 + r;
+      a_rd[i][0] = swz(row, h);
+      a_rd[i][1] = swz(row, 2 + h);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * TN * 32 + j * 32 + r;
+      b_rd[j][0] = 2 * A_HALF + swz(row, h);
+      b_rd[j][1] = 2 * A_HALF + swz(row, 2 + h);
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int CC = a.Cs >> 6;
+  const int T_total = a.R * a.S * CC;
+  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+  // K-tile cursor of the NEXT tile to issue.  The padded source address of a tap is resolved only
+  // when the tap (r,s) changes; within a tap consecutive K-tiles advance the pointer by 64 channels.
+  int ir = 0, is = 0, ic = 0, it = 0, istage = 0;
+  const bf16_t* a_src[AU];
+  int a_step[AU];
+  auto retap = [&]() {
+#pragma unroll
+    for (int i = 0; i < AU; ++i) {
+      int ih = a_oh[i] + ir, iw = a_ow[i] + is;
+      bool ok = true;
+      if (a.reflect) {
+        ih = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
+        iw = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
+      } else {
+        ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
+      }
+      a_src[i] = ok ? a.X + a_nbase[i] + ((long long)ih * a.IW + iw) * a.Cs + a_choff[i] : zero;
+      a_step[i] = ok ? 64 : 0;
+    }
+  };
+  auto issue = [&]() {
+    char* const st = smem + istage * STAGE_BYTES;
+    if (ic == 0) retap();
+#pragma unroll
+    for (int i = 0; i < AU; ++i) {
+      glds16(a_src[i], st + a_lds[i]);
+      a_src[i] += a_step[i];
+    }
+    const long long koff = (long long)it * 64;
+#pragma unroll
+    for (int j = 0; j < BU; ++j)
+      if (b_on[j]) glds16(b_ptr[j] + koff, st + b_lds[j]);
+    ++it;
+    if (++ic == CC) {
+      ic = 0;
+      if (++is == a.S) { is = 0; ++ir; }
+    }
+    istage = istage == STAGES - 1 ? 0 : istage + 1;
+  };
+
+  issue();
+  if (T_total > 1) issue();
+  int cstage = 0;
+  for (int t = 0; t < T_total; ++t) {
+    if (t + 1 < T_total) {
+      if (LW == AU + BU) wait_vmcnt<AU + BU>();
+      else wait_vmcnt<AU + (BU > 0 ? BU - 1 : 0)>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < T_total) issue();
+    const char* const st = smem + cstage * STAGE_BYTES;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        s16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(st + hh * A_HALF + a_rd[i][u]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + hh * B_HALF + b_rd[j][u]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    cstage = cstage == STAGES - 1 ? 0 : cstage + 1;
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------
+  __syncthreads();
+  long long* const row_off = reinterpret_cast<long long*>(smem);
+  for (int row = tid; row < BM; row += 64 * NW) {
+    const int m = m0 + row;
+    long long off = -1;
+    if (m < a.M) {
+      const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
+      off = a.out_base + n * a.out_sn + oh * a.out_sh + ow * a.out_sw;
+    }
+    row_off[row] = off;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+    if (col >= a.Ks) continue;
+    const bool live = col < a.Kout;
+    const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const long long off = row_off[row];
+        if (off < 0) continue;
+        const float v = live ? apply_act(acc[i][j][e] + bv, a.act, a.slope) : 0.f;
+        a.Y[off + col] = f2bf(v);
+      }
+    }
+  }
+}
+
+}  // namespace jpdse

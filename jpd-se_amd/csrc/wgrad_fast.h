@@ -1,0 +1,216 @@
+// Fast bf16 weight-gradient kernel for CDNA4:  dW[k][tap][c] = sum_p dy[p][k] * x[p (+) tap][c].
+//
+// Both MFMA operands need 8 consecutive PIXELS per lane while memory is channel-contiguous.  The
+// generic kernel transposes while staging (8 ds_write_b32 per 32 bytes, VALU packing); here the
+// tiles are staged in their natural [pixel][channel] order by LDS-DMA (global_load_lds, 1 KiB per
+// wave instruction, source-side swizzle) and transposed for free by ds_read_b64_tr_b16: per group
+// of 16 lanes it returns a 4-pixel x 16-channel block column-major (semantics verified on
+// hardware by scripts/probe_tr16.hip).  Padding (reflect / zero) is resolved per pixel in the
+// loader, so no padded copy of x is made.  One tile = 64*TM k-channels x 64*TN c-channels of one
+// filter tap; reduction over pixels in 64-pixel chunks, 2 LDS stages, one barrier per chunk.
+//
+// LDS image of an operand stage: row = pixel, ROWB = 128*T bytes; the 16-byte slot index is XORed
+// with f(pixel) so that the 4 rows touched by one transposed read fall on distinct bank groups:
+//   ROWB = 256:  slot ^= (pixel & 3) << 2        ROWB = 128:  slot ^= ((pixel >> 1) & 1) << 2
+#pragma once
+#include "common.h"
+#include "gemm_fast.h"
+
+namespace jpdse {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct FastWgArgs {
+  const bf16_t* X;    // [N][IH][IW][Cs] unpadded
+  const bf16_t* DY;   // [M][Ks]
+  float* DW;          // fp32 KRSC master-layout gradient
+  int M, OH, OW;
+  int IH, IW, Cs, C;
+  int Ks, K;
+  int R, S, sy, sx, py, px, reflect;
+  int chunks_total, chunks_per_split, atomic;
+};
+
+template <int ROWB> __device__ __forceinline__ int trswz(int pix) {
+  return ROWB == 256 ? ((pix & 3) << 2) : (((pix >> 1) & 1) << 2);
+}
+
+__device__ __forceinline__ s16x8 tr_frag(const char* p, int row4_bytes) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + row4_bytes));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// TM, TN in {1,2}: tile = (64*TM) k-channels x (64*TN) c-channels; 4 waves as 2x2, wave tile 32*TM x 32*TN
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
+  constexpr int BKP = 64;                         // pixels per chunk
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int A_ROWB = BM * 2, B_ROWB = BN * 2; // 128 or 256 bytes per pixel row
+  constexpr int A_STAGE = BKP * A_ROWB, B_STAGE = BKP * B_ROWB;
+  constexpr int STAGE = A_STAGE + B_STAGE;
+  constexpr int A_PPU = 1024 / A_ROWB, B_PPU = 1024 / B_ROWB;   // pixels per 1 KiB DMA unit
+  constexpr int A_UNITS = BKP / A_PPU, B_UNITS = BKP / B_PPU;
+  constexpr int AU = A_UNITS / 4, BU = B_UNITS / 4;             // per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+
+  // blockIdx.x -> (k tile, tap, c tile)
+  const int c_tiles = (a.Cs + BN - 1) / BN;
+  const int ct = blockIdx.x % c_tiles;
+  const int t1 = blockIdx.x / c_tiles;
+  const int tap = t1 % (a.R * a.S);
+  const int kt = t1 / (a.R * a.S);
+  const int r = tap / a.S, s = tap - r * a.S;
+  const int k0 = kt * BM, c0 = ct * BN;
+  const int ch_begin = blockIdx.y * a.chunks_per_split;
+  int ch_end = ch_begin + a.chunks_per_split;
+  ch_end = ch_end < a.chunks_total ? ch_end : a.chunks_total;
+  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+  // ---- DMA unit state -----------------------------------------------------------------------
+  // A' (dy): unit u covers pixels [u*A_PPU, +A_PPU) of the chunk; lane -> (pixel in unit, 16-B slot)
+  int a_pix[AU], a_soff[AU], a_lds[AU];
+#pragma unroll
+  for (int i = 0; i < AU; ++i) {
+    const int u = wid + 4 * i;
+    const int pl = lane / (A_ROWB / 16), slot = lane % (A_ROWB / 16);
+    const int pix = u * A_PPU + pl;
+    a_pix[i] = pix;
+    int ch = k0 + ((slot ^ trswz<A_ROWB>(pix)) << 3);
+    ch = ch + 8 <= a.Ks ? ch : a.Ks - 8;                 // tile overhang: rows >= K are masked at the store
+    a_soff[i] = ch;
+    a_lds[i] = u * 1024;
+  }
+  // B' (x): same, plus the tap-shifted, padded source pixel
+  int b_pix[BU], b_soff[BU], b_lds[BU];
+  int bn[BU], boh[BU], bow[BU];                          // cursor of the unit's pixel: (n, oh, ow)
+#pragma unroll
+  for (int i = 0; i < BU; ++i) {
+    const int u = wid + 4 * i;
+    const int pl = lane / (B_ROWB / 16), slot = lane % (B_ROWB / 16);
+    const int pix = u * B_PPU + pl;
+    b_pix[i] = pix;
+    int ch = c0 + ((slot ^ trswz<B_ROWB>(pix)) << 3);
+    ch = ch + 8 <= a.Cs ? ch : a.Cs - 8;
+    b_soff[i] = ch;
+    b_lds[i] = A_STAGE + u * 1024;
+    int p = ch_begin * BKP + pix;
+    p = p < a.M ? p : a.M - 1;
+    bow[i] = p % a.OW;
+    const int t = p / a.OW;
+    boh[i] = t % a.OH;
+    bn[i] = t / a.OH;
+  }
+
+  // ---- transposed fragment read offsets -----------------------------------------------------
+  // lane: g = lane>>4 -> (h = g>>1: which 8 pixels of the 16-pixel k-step, cb = g&1: 16-channel block),
+  //       li = lane&15 -> q = li>>2 (row of the 4x16 block), p = li&3 (4-channel column group)
+  int a_tr[TM], b_tr[TN];
+  {
+    const int g = lane >> 4, li = lane & 15, h = g >> 1, cb = g & 1, q = li >> 2, p = li & 3;
+    const int pix = 8 * h + q;                          // + 16*ks + 4*half are multiples of 4: swizzle unchanged
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ch = (wm * TM + i) * 32 + cb * 16 + 4 * p;          // channel within the tile
+      a_tr[i] = pix * A_ROWB + ((((ch >> 3) ^ trswz<A_ROWB>(pix)) << 4) | ((ch & 7) << 1));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ch = (wn * TN + j) * 32 + cb * 16 + 4 * p;
+      b_tr[j] = A_STAGE + pix * B_ROWB + ((((ch >> 3) ^ trswz<B_ROWB>(pix)) << 4) | ((ch & 7) << 1));
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int ich = ch_begin;       // next chunk to issue
+  auto issue = [&](int stage) {
+    char* const st = smem + stage * STAGE;
+    const int pbase = ich * BKP;
+#pragma unroll
+    for (int i = 0; i < AU; ++i) {
+      const int p = pbase + a_pix[i];
+      const bf16_t* src = p < a.M ? a.DY + (long long)p * a.Ks + a_soff[i] : zero;
+      glds16(src, st + a_lds[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < BU; ++i) {
+      int ih = boh[i] * a.sy + r - a.py, iw = bow[i] * a.sx + s - a.px;
+      bool ok = true;
+      if (a.reflect) {
+        ih = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
+        iw = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
+      } else {
+        ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
+      }
+      const bf16_t* src = ok ? a.X + (((long long)bn[i] * a.IH + ih) * a.IW + iw) * a.Cs + b_soff[i] : zero;
+      glds16(src, st + b_lds[i]);
+      // advance the cursor by one chunk (clamped at the last pixel: its dy row is the zero page)
+      if (pbase + BKP + b_pix[i] < a.M) {
+        bow[i] += BKP;
+        while (bow[i] >= a.OW) {
+          bow[i] -= a.OW;
+          if (++boh[i] == a.OH) { boh[i] = 0; ++bn[i]; }
+        }
+      }
+    }
+    ++ich;
+  };
+
+  int stage = 0;
+  if (ch_begin < ch_end) issue(0);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  for (int c = ch_begin; c < ch_end; ++c) {
+    if (c + 1 < ch_end) issue(stage ^ 1);
+    const char* const st = smem + stage * STAGE;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < BKP / 16; ++ks) {
+      s16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = tr_frag(st + a_tr[i] + ks * 16 * A_ROWB, 4 * A_ROWB);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = tr_frag(st + b_tr[j] + ks * 16 * B_ROWB, 4 * B_ROWB);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    stage ^= 1;
+  }
+
+  // ---- epilogue: scatter into the KRSC master-layout gradient -------------------------------
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cc = c0 + (wn * TN + j) * 32 + (lane & 31);
+    if (cc >= a.C) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = k0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (k >= a.K) continue;
+        float* dst = a.DW + (((long long)k * a.R + r) * a.S + s) * a.C + cc;
+        if (a.atomic) atomicAdd(dst, acc[i][j][e]);
+        else *dst = acc[i][j][e];
+      }
+    }
+  }
+}
+
+}  // namespace jpdse

@@ -46,6 +46,7 @@ SIGNATURES = {
     'jpdse_version': (_I32, []),
     'jpdse_last_error': (ctypes.c_char_p, []),
     'jpdse_arch_check': (_I32, [_I32]),
+    'jpdse_debug_set_fast_path': (_I32, [_I32]),
     'jpdse_prof_select': (_I32, [_I32, _I32, _I64, _I32]),
     'jpdse_prof_collect': (_I32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64)]),
     'jpdse_conv_out_shape': (_I32, [_CD, ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
