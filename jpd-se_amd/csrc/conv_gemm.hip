@@ -845,13 +845,15 @@ static int launch_wgrad(const GemmWgradArgs& a, hipStream_t s) {
   return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, s);
 }
 
-template <int WM, int WN, int TM, int TN>
+static int g_fast_variant = 0;   // A/B (scripts/bench_conv.py): the simple schedule is as fast or faster
+
+template <int WM, int WN, int TM, int TN, int VAR>
 static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int lds = 3 * 2 * (BM + BN) * 64;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<WM, WN, TM, TN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<WM, WN, TM, TN, VAR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_fast: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -861,7 +863,7 @@ static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN, VAR>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
@@ -870,11 +872,16 @@ static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
   return check_launch("gemm_fast_kernel");
 }
 
+template <int VAR>
+static int launch_fast_v(const FastArgs& a, hipStream_t s) {
+  if (a.Ks > 64) return launch_fast_cfg<4, 2, 2, 2, VAR>(a, s);   // 256 x 128
+  if (a.Ks > 32) return launch_fast_cfg<4, 2, 2, 1, VAR>(a, s);   // 256 x 64
+  return launch_fast_cfg<8, 1, 1, 1, VAR>(a, s);                  // 256 x 32
+}
+
 static int launch_fast(const FastArgs& a, hipStream_t s) {
   if (a.M <= 0) return JPDSE_OK;
-  if (a.Ks > 64) return launch_fast_cfg<4, 2, 2, 2>(a, s);   // 256 x 128
-  if (a.Ks > 32) return launch_fast_cfg<4, 2, 2, 1>(a, s);   // 256 x 64
-  return launch_fast_cfg<8, 1, 1, 1>(a, s);                  // 256 x 32
+  return g_fast_variant == 0 ? launch_fast_v<0>(a, s) : launch_fast_v<1>(a, s);
 }
 
 static bool g_fast_enabled = true;   // jpdse_debug_set_fast_path(0) forces the generic kernels (A/B tests)
@@ -1078,21 +1085,24 @@ static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
   }
   a.chunks_total = (a.M + 63) / 64;
   const int tiles = ((a.Ks + BM - 1) / BM) * a.R * a.S * ((a.Cs + BN - 1) / BN);
-  int splits = 1;
-  if (tiles < 512) {
-    splits = (768 + tiles - 1) / tiles;
-    const int max_splits = (a.chunks_total + 7) / 8;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-  }
-  a.chunks_per_split = (a.chunks_total + splits - 1) / splits;
-  splits = (a.chunks_total + a.chunks_per_split - 1) / a.chunks_per_split;
-  a.atomic = splits > 1;
+  // stream-K partition: the tiles x chunks iteration space is cut into equal contiguous shares, one
+  // per block, two blocks per CU.  A tile whose chunks all fall into one share is stored; a tile
+  // straddling shares is accumulated with fp32 atomics into the zeroed gradient.
+  const long long total = (long long)tiles * a.chunks_total;
+  long long nblocks = 512;
+  if (total < nblocks * 8) nblocks = (total + 7) / 8;
+  if (nblocks < 1) nblocks = 1;
+  a.iters_per_block = (int)((total + nblocks - 1) / nblocks);
+  nblocks = (total + a.iters_per_block - 1) / a.iters_per_block;
+  a.total_iters = total;
+  a.atomic = (a.iters_per_block % a.chunks_total) != 0 || nblocks * (long long)a.iters_per_block != total;
   if (a.atomic) {
     hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), s);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL((wgrad_fast_kernel<TM, TN>), dim3(tiles, splits), dim3(256), lds, s, a);
+  const int splits = 1;
+  const int tiles_grid = (int)nblocks;
+  hipLaunchKernelGGL((wgrad_fast_kernel<TM, TN>), dim3(tiles_grid, splits), dim3(256), lds, s, a);
   return check_launch("wgrad_fast_kernel");
 }
 
@@ -1177,7 +1187,9 @@ int jpdse_conv_out_shape(const jpdse_conv_desc* d, int32_t* OH, int32_t* OW) {
 }
 
 int jpdse_debug_set_fast_path(int32_t enable) {
+  // 0: generic kernels only; 1: fast kernels (default schedule 0); 2: fast kernels, alternative schedule 1
   g_fast_enabled = enable != 0;
+  g_fast_variant = enable == 2 ? 1 : 0;
   return JPDSE_OK;
 }
 

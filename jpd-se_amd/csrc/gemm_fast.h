@@ -45,7 +45,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN>
+// VAR selects the inner-loop schedule (A/B-able in one process via jpdse_debug_set_fast_path):
+//   0: DMA issue right after the barrier, then 4 x {4 ds_read_b128, 4 MFMA}
+//   1: fragment reads of k-step g+1 requested before the MFMAs of step g, DMA issued behind group 0
+template <int WM, int WN, int TM, int TN, int VAR>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs a) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -184,26 +187,53 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs 
       wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < T_total) issue();
     const char* const st = smem + cstage * STAGE_BYTES;
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (VAR == 0) {
+      if (t + 2 < T_total) issue();
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+      for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        s16x8 af[TM], bf[TN];
+        for (int u = 0; u < 2; ++u) {
+          s16x8 af[TM], bf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(st + hh * A_HALF + a_rd[i][u]);
+          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(st + hh * A_HALF + a_rd[i][u]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + hh * B_HALF + b_rd[j][u]);
+          for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + hh * B_HALF + b_rd[j][u]);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+      s16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const s16x8*>(st + a_rd[i][0]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const s16x8*>(st + b_rd[j][0]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cur = g & 1, nxt = cur ^ 1;
+        if (g < 3) {
+          const int hh = (g + 1) >> 1, u = (g + 1) & 1;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const s16x8*>(st + hh * A_HALF + a_rd[i][u]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const s16x8*>(st + hh * B_HALF + b_rd[j][u]);
+        }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (g == 0 && t + 2 < T_total) issue();
       }
     }
-    __builtin_amdgcn_s_setprio(0);
     cstage = cstage == STAGES - 1 ? 0 : cstage + 1;
   }
 

@@ -28,7 +28,8 @@ struct FastWgArgs {
   int IH, IW, Cs, C;
   int Ks, K;
   int R, S, sy, sx, py, px, reflect;
-  int chunks_total, chunks_per_split, atomic;
+  int chunks_total, iters_per_block, atomic;
+  long long total_iters;   // tiles * chunks_total
 };
 
 template <int ROWB> __device__ __forceinline__ int trswz(int pix) {
@@ -58,17 +59,25 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
 
-  // blockIdx.x -> (k tile, tap, c tile)
   const int c_tiles = (a.Cs + BN - 1) / BN;
-  const int ct = blockIdx.x % c_tiles;
-  const int t1 = blockIdx.x / c_tiles;
+  long long it0 = (long long)blockIdx.x * a.iters_per_block;
+  long long it1 = it0 + a.iters_per_block;
+  it1 = it1 < a.total_iters ? it1 : a.total_iters;
+  // ---- stream-K: this block owns the iteration range [it0, it1) of the (tile, chunk) space --------
+  while (it0 < it1) {
+  const int tile = (int)(it0 / a.chunks_total);
+  const int ch_begin = (int)(it0 - (long long)tile * a.chunks_total);
+  int ch_end = ch_begin + (int)(it1 - it0);
+  ch_end = ch_end < a.chunks_total ? ch_end : a.chunks_total;
+  it0 += ch_end - ch_begin;
+  const bool whole_tile = ch_begin == 0 && ch_end == a.chunks_total;
+  // tile -> (k tile, tap, c tile)
+  const int ct = tile % c_tiles;
+  const int t1 = tile / c_tiles;
   const int tap = t1 % (a.R * a.S);
   const int kt = t1 / (a.R * a.S);
   const int r = tap / a.S, s = tap - r * a.S;
   const int k0 = kt * BM, c0 = ct * BN;
-  const int ch_begin = blockIdx.y * a.chunks_per_split;
-  int ch_end = ch_begin + a.chunks_per_split;
-  ch_end = ch_end < a.chunks_total ? ch_end : a.chunks_total;
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
   // ---- DMA unit state -----------------------------------------------------------------------
@@ -206,11 +215,13 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
         const int k = k0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (k >= a.K) continue;
         float* dst = a.DW + (((long long)k * a.R + r) * a.S + s) * a.C + cc;
-        if (a.atomic) atomicAdd(dst, acc[i][j][e]);
+        if (!whole_tile) atomicAdd(dst, acc[i][j][e]);
         else *dst = acc[i][j][e];
       }
     }
   }
+  __syncthreads();   // the next segment re-uses the LDS stages
+  }  // stream-K segment loop
 }
 
 }  // namespace jpdse

@@ -11,12 +11,12 @@ from jpdse_hip.ops import Act
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=4)
-ap.add_argument('--fast', type=int, default=1)
+ap.add_argument('--fast', type=str, default='1', help='comma list of fast-path modes to A/B in one process')
 ap.add_argument('--filter', default='')
 ap.add_argument('--iters', type=int, default=10)
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
-lib().jpdse_debug_set_fast_path(args.fast)
+modes = [int(x) for x in args.fast.split(',')]
 B = args.batch
 # name, H, W, C, K, k, stride, pad, mode, transposed
 LAYERS = [
@@ -45,10 +45,30 @@ def timeit(fn, iters):
   e1.record(); torch.cuda.synchronize()
   return e0.elapsed_time(e1) / iters
 
+def _bench_one(name, layer, H, W, C, K, k, tr):
+  x = Act(torch.randn(B, H, W, (C + 7) // 8 * 8, device=dev).bfloat16(), C)
+  y, ctx = layer.fwd(x)
+  dy = Act(torch.randn_like(y.t.float()).bfloat16(), y.C)
+  macs = B * H * W * C * K * 9 if tr else B * y.H * y.W * K * C * k * k
+  fl = 2.0 * macs
+  ts = []
+  for rep in range(2):      # interleaved repeats: take the best of two
+    t_f = timeit(lambda: layer.fwd(x), args.iters)
+    t_d = timeit(lambda: layer.bwd(ctx, dy, True, False), args.iters)
+    t_w = timeit(lambda: layer.bwd(ctx, dy, False, True), args.iters)
+    ts.append((t_f, t_d, t_w))
+  t_f, t_d, t_w = (min(t[i] for t in ts) for i in range(3))
+  print('%-34s %5.0f %5.2f %5.0f %5.2f %5.0f %5.2f' % (name, fl / t_f / 1e9, t_f, fl / t_d / 1e9, t_d, fl / t_w / 1e9, t_w))
+
 print('%-34s %10s %10s %10s   (TFLOP/s, ms)' % ('layer', 'fwd', 'dgrad', 'wgrad'))
 for (name, H, W, C, K, k, st, pad, mode, tr) in LAYERS:
   if args.filter and args.filter not in name: continue
-  layer = HipConv2d(C, K, k, st, pad, mode, apply_bias=False, transposed=tr, dtype=BF16, device=dev)
+  for fm in modes:
+   lib().jpdse_debug_set_fast_path(fm)
+   layer = HipConv2d(C, K, k, st, pad, mode, apply_bias=False, transposed=tr, dtype=BF16, device=dev)
+   name_m = '%s [m%d]' % (name[:28], fm)
+   _bench_one(name_m, layer, H, W, C, K, k, tr)
+  continue
   if tr:
     x = Act(torch.randn(B, H, W, (C + 7) // 8 * 8, device=dev).bfloat16(), C)
   else:
