@@ -890,8 +890,10 @@ static bool g_fast_enabled = true;   // jpdse_debug_set_fast_path(0) forces the 
 // the 256 CUs many times over or be an exact multiple of them; in between (e.g. the 288 tiles of the
 // ResnetBlock data gradient) the generic 128x128 kernel with 3 co-resident blocks per CU wins
 // (measured: scripts/bench_conv.py, profiles/r01_conv_layers_*.log).
-static bool fast_pays(int M, int Ks) {
+static bool fast_pays(int M, int Ks, int k_tiles) {
   if (!g_fast_enabled) return false;
+  if (k_tiles < 8) return false;   // short reductions (stride-2 sub-pixel phases of 2x2 taps x 64 ch) do not fill the 3-stage ring
+  if (Ks <= 32) return false;   // measured: the generic 256x32 kernel beats the 8-wave 256x32 fast config
   const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32);
   const long long tiles = (long long)((M + 255) / 256) * ((Ks + bn - 1) / bn);
   return tiles >= 448 || (tiles >= 256 && tiles % 256 == 0);
@@ -901,7 +903,7 @@ template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
                       const float* bias, void* y, void* ws, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    if (p.Cs % 64 == 0 && fast_pays(d->N * p.OH * p.OW, p.Ks)) {
+    if (p.Cs % 64 == 0 && fast_pays(d->N * p.OH * p.OW, p.Ks, d->R * d->S * p.Cs / 64)) {
       FastArgs f = {};
       f.X = reinterpret_cast<const bf16_t*>(x);
       f.B = reinterpret_cast<const bf16_t*>(pack);
@@ -974,7 +976,8 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   if constexpr (sizeof(T) == 2) {
     fast = p.Ks % 64 == 0;
     for (int i = 0; i < p.nph && fast; ++i)
-      if (p.ph[i].cnth > 0 && p.ph[i].cntw > 0) fast = fast_pays(d->N * p.ph[i].cnth * p.ph[i].cntw, p.Cs);
+      if (p.ph[i].cnth > 0 && p.ph[i].cntw > 0)
+        fast = fast_pays(d->N * p.ph[i].cnth * p.ph[i].cntw, p.Cs, p.ph[i].Uh * p.ph[i].Uw * p.Ks / 64);
   }
   int rc = JPDSE_OK;
   if (!fast) {
@@ -1084,7 +1087,8 @@ static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
     configured = true;
   }
   a.chunks_total = (a.M + 63) / 64;
-  const int tiles = ((a.Ks + BM - 1) / BM) * a.R * a.S * ((a.Cs + BN - 1) / BN);
+  const int tiles = ((a.Ks + BM - 1) / BM) * (a.run_mode ? a.R : a.R * a.S) *
+                    (((a.run_mode ? a.run_len : a.Cs) + BN - 1) / BN);
   // stream-K partition: the tiles x chunks iteration space is cut into equal contiguous shares, one
   // per block, two blocks per CU.  A tile whose chunks all fall into one share is stored; a tile
   // straddling shares is accumulated with fp32 atomics into the zeroed gradient.
@@ -1107,7 +1111,7 @@ static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
 }
 
 static int launch_wgrad_fast(const FastWgArgs& a, hipStream_t s) {
-  const bool m2 = a.Ks >= 128, n2 = a.Cs >= 128;
+  const bool m2 = a.Ks >= 128, n2 = (a.run_mode ? a.run_len : a.Cs) >= 128;
   if (m2 && n2) return launch_wgrad_fast_cfg<2, 2>(a, s);
   if (m2) return launch_wgrad_fast_cfg<2, 1>(a, s);
   if (n2) return launch_wgrad_fast_cfg<1, 2>(a, s);
@@ -1118,16 +1122,43 @@ template <typename T>
 static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* dy, float* dw,
                         void* ws, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    if (g_fast_enabled && p.Cs % 64 == 0 && p.Ks % 64 == 0) {
+    const int kexp = d->K * d->R * d->S, kexp_s = round_up(kexp, 64);
+    if (g_fast_enabled && p.Ks == 8 && d->stride == 1 && p.Cs % 64 == 0 && kexp_s <= 256) {
+      // few output channels: dense 1x1 weight gradient over the tap-expanded dy (see expand_dy_taps_kernel)
+      if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+        return rc;
+      bf16_t* dz = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ws) + p.xpad_bytes);
+      const long long tv = (long long)d->N * p.Hp * p.Wp * (kexp_s / 8);
+      hipLaunchKernelGGL(expand_dy_taps_kernel, dim3(ew_blocks(tv)), dim3(256), 0, s,
+                         reinterpret_cast<const bf16_t*>(dy), dz, p.OH, p.OW, p.Ks, d->K, d->R, d->S, p.Hp, p.Wp,
+                         kexp_s, tv);
+      if (int rc = check_launch("expand_dy_taps_kernel")) return rc;
       FastWgArgs f = {};
-      f.X = reinterpret_cast<const bf16_t*>(x);
+      f.X = reinterpret_cast<const bf16_t*>(ws);
+      f.DY = dz;
+      f.DW = dw;
+      f.M = d->N * p.Hp * p.Wp;
+      f.OH = p.Hp;
+      f.OW = p.Wp;
+      f.IH = p.Hp;
+      f.IW = p.Wp;
+      f.Cs = p.Cs;
+      f.C = d->C;
+      f.Ks = kexp_s;
+      f.K = kexp;
+      f.R = f.S = 1;
+      f.sy = f.sx = 1;
+      f.py = f.px = 0;
+      f.reflect = 0;
+      return launch_wgrad_fast(f, s);
+    }
+    if (g_fast_enabled && p.Ks % 64 == 0) {
+      FastWgArgs f = {};
       f.DY = reinterpret_cast<const bf16_t*>(dy);
       f.DW = dw;
       f.M = d->N * p.OH * p.OW;
       f.OH = p.OH;
       f.OW = p.OW;
-      f.IH = d->H;
-      f.IW = d->W;
       f.Cs = p.Cs;
       f.C = d->C;
       f.Ks = p.Ks;
@@ -1135,8 +1166,24 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       f.R = d->R;
       f.S = d->S;
       f.sy = f.sx = d->stride;
-      f.py = f.px = d->pad;
-      f.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+      if (p.Cs % 64 == 0) {
+        f.X = reinterpret_cast<const bf16_t*>(x);
+        f.IH = d->H;
+        f.IW = d->W;
+        f.py = f.px = d->pad;
+        f.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+      } else {
+        // run mode over the materially padded input (40-channel network inputs, 8-channel images)
+        if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+          return rc;
+        f.X = reinterpret_cast<const bf16_t*>(ws);
+        f.IH = p.Hp;
+        f.IW = p.Wp;
+        f.py = f.px = 0;
+        f.reflect = 0;
+        f.run_mode = 1;
+        f.run_len = d->S * p.Cs;
+      }
       return launch_wgrad_fast(f, s);
     }
   }
@@ -1267,7 +1314,9 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   if (validate(d)) return 0;
   ConvPlan p;
   make_plan(d, &p);
-  const size_t fwd = p.xpad_bytes;
+  const size_t kexp_s = (size_t)round_up(d->K * d->R * d->S, 64);
+  const size_t dz = (p.Ks == 8 && kexp_s <= 256) ? align_up((size_t)d->N * p.Hp * p.Wp * kexp_s * 2, 256) : 0;
+  const size_t fwd = p.xpad_bytes + dz;     // wgrad: padded x (+ tap-expanded dy for few-output-channel layers)
   const size_t dgrad = p.dypad_bytes + p.dxp_bytes;
   return fwd > dgrad ? fwd : dgrad;
 }
@@ -1339,7 +1388,7 @@ int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, fl
   JPDSE_REQUIRE(x && dy && dw, "conv_wgrad: null pointer");
   ConvPlan p;
   make_plan(d, &p);
-  if (ws == nullptr || ws_bytes < p.xpad_bytes)
+  if (ws == nullptr || ws_bytes < jpdse_conv_workspace_size(d))
     return set_error(JPDSE_EWORKSPACE, "conv_wgrad: workspace %zu < %zu", ws_bytes, p.xpad_bytes);
   return d->dtype == JPDSE_BF16 ? conv_wgrad_t<bf16_t>(d, p, x, dy, dw, ws, as_stream(stream))
                                 : conv_wgrad_t<float>(d, p, x, dy, dw, ws, as_stream(stream));

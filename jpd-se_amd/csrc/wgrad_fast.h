@@ -30,6 +30,10 @@ struct FastWgArgs {
   int R, S, sy, sx, py, px, reflect;
   int chunks_total, iters_per_block, atomic;
   long long total_iters;   // tiles * chunks_total
+  // run mode (input channels not a multiple of 64, e.g. the 40-channel network inputs): X is the
+  // materially padded input, a tile's columns are 64*TN consecutive elements of the S*Cs run under
+  // filter row r (consecutive taps s are consecutive pixels), taps iterate over r only.
+  int run_mode, run_len;
 };
 
 template <int ROWB> __device__ __forceinline__ int trswz(int pix) {
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
 
-  const int c_tiles = (a.Cs + BN - 1) / BN;
+  const int c_tiles = ((a.run_mode ? a.run_len : a.Cs) + BN - 1) / BN;
+  const int n_taps = a.run_mode ? a.R : a.R * a.S;
   long long it0 = (long long)blockIdx.x * a.iters_per_block;
   long long it1 = it0 + a.iters_per_block;
   it1 = it1 < a.total_iters ? it1 : a.total_iters;
@@ -74,9 +79,9 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
   // tile -> (k tile, tap, c tile)
   const int ct = tile % c_tiles;
   const int t1 = tile / c_tiles;
-  const int tap = t1 % (a.R * a.S);
-  const int kt = t1 / (a.R * a.S);
-  const int r = tap / a.S, s = tap - r * a.S;
+  const int tap = t1 % n_taps;
+  const int kt = t1 / n_taps;
+  const int r = a.run_mode ? tap : tap / a.S, s = a.run_mode ? 0 : tap - r * a.S;
   const int k0 = kt * BM, c0 = ct * BN;
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
     const int pix = u * B_PPU + pl;
     b_pix[i] = pix;
     int ch = c0 + ((slot ^ trswz<B_ROWB>(pix)) << 3);
-    ch = ch + 8 <= a.Cs ? ch : a.Cs - 8;
+    if (!a.run_mode) ch = ch + 8 <= a.Cs ? ch : a.Cs - 8;   // run mode: overhang reads the zeroed slack
     b_soff[i] = ch;
     b_lds[i] = A_STAGE + u * 1024;
     int p = ch_begin * BKP + pix;
@@ -156,7 +161,9 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
     for (int i = 0; i < BU; ++i) {
       int ih = boh[i] * a.sy + r - a.py, iw = bow[i] * a.sx + s - a.px;
       bool ok = true;
-      if (a.reflect) {
+      if (a.run_mode) {
+        // already padded: (ih, iw) is in range by construction
+      } else if (a.reflect) {
         ih = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
         iw = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
       } else {
@@ -206,7 +213,13 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
   // ---- epilogue: scatter into the KRSC master-layout gradient -------------------------------
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int cc = c0 + (wn * TN + j) * 32 + (lane & 31);
+    int cc = c0 + (wn * TN + j) * 32 + (lane & 31);
+    int s_out = s;
+    if (a.run_mode) {               // column of the run -> (tap s, channel c)
+      if (cc >= a.run_len) continue;
+      s_out = cc / a.Cs;
+      cc -= s_out * a.Cs;
+    }
     if (cc >= a.C) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int k = k0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (k >= a.K) continue;
-        float* dst = a.DW + (((long long)k * a.R + r) * a.S + s) * a.C + cc;
+        float* dst = a.DW + (((long long)k * a.R + r) * a.S + s_out) * a.C + cc;
         if (!whole_tile) atomicAdd(dst, acc[i][j][e]);
         else *dst = acc[i][j][e];
       }
@@ -222,6 +235,38 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
   }
   __syncthreads();   // the next segment re-uses the LDS stages
   }  // stream-K segment loop
+}
+
+// dz[p'][k*R*S + r*S + s] = dy[p' - (r,s)][k]  (zero outside): with it the weight gradient of a conv with
+// very few output channels (the 64->3 head, the 512->1 PatchGAN map) becomes a dense 1x1 weight
+// gradient  dW[(k,r,s)][c] = sum_p' dz[p'][(k,r,s)] * xpad[p'][c]  whose row order is already the KRSC
+// master layout -- no 32-row MFMA tile wasted on 3 live rows.  Stride 1 only.
+__global__ void expand_dy_taps_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dz, int OH, int OW, int Ks,
+                                      int K, int R, int S, int Hp, int Wp, int Kexp_s, long long total_vec) {
+  const int cv = Kexp_s / 8;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % cv);
+    long long t = idx / cv;
+    const int wp = (int)(t % Wp);
+    t /= Wp;
+    const int hp = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = v * 8 + e;
+      const int k = ch / (R * S), tap = ch - k * (R * S);
+      const int r = tap / S, s = tap - r * S;
+      const int oh = hp - r, ow = wp - s;
+      uint32_t val = 0;
+      if (k < K && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW)
+        val = dy[(((long long)n * OH + oh) * OW + ow) * Ks + k];
+      w[e >> 1] |= val << ((e & 1) * 16);
+    }
+    u32x4 o = {w[0], w[1], w[2], w[3]};
+    *reinterpret_cast<u32x4*>(dz + idx * 8) = o;
+  }
 }
 
 }  // namespace jpdse
