@@ -847,13 +847,13 @@ static int launch_wgrad(const GemmWgradArgs& a, hipStream_t s) {
 
 static int g_fast_variant = 0;   // A/B (scripts/bench_conv.py): the simple schedule is as fast or faster
 
-template <int WM, int WN, int TM, int TN, int VAR>
+template <int WM, int WN, int TM, int TN, int VAR, int STAGES = 3>
 static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int lds = 3 * 2 * (BM + BN) * 64;
+  constexpr int lds = STAGES * 2 * (BM + BN) * 64;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<WM, WN, TM, TN, VAR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<WM, WN, TM, TN, VAR, STAGES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_fast: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -863,7 +863,7 @@ static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN, VAR>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN, VAR, STAGES>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
@@ -872,8 +872,19 @@ static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
   return check_launch("gemm_fast_kernel");
 }
 
+static bool prefer_320(int M, int Ks) {
+  // one round of 320-row tiles beats two rounds of 256-row tiles (e.g. the ResnetBlock data gradient
+  // on the reflect-padded domain: M = 8976 -> 232 tiles instead of 288 on 256 CUs)
+  if (Ks <= 64) return false;
+  const long long nt = (Ks + 127) / 128;
+  const long long t256 = (long long)((M + 255) / 256) * nt, t320 = (long long)((M + 319) / 320) * nt;
+  const long long c256 = ((t256 + 255) / 256) * 256, c320 = ((t320 + 255) / 256) * 320;
+  return c320 < c256;
+}
+
 template <int VAR>
 static int launch_fast_v(const FastArgs& a, hipStream_t s) {
+  if (prefer_320(a.M, a.Ks)) return launch_fast_cfg<2, 4, 5, 1, VAR, 2>(a, s);   // 320 x 128, 2 stages
   if (a.Ks > 64) return launch_fast_cfg<4, 2, 2, 2, VAR>(a, s);   // 256 x 128
   if (a.Ks > 32) return launch_fast_cfg<4, 2, 2, 1, VAR>(a, s);   // 256 x 64
   return launch_fast_cfg<8, 1, 1, 1, VAR>(a, s);                  // 256 x 32
@@ -890,12 +901,17 @@ static bool g_fast_enabled = true;   // jpdse_debug_set_fast_path(0) forces the 
 // the 256 CUs many times over or be an exact multiple of them; in between (e.g. the 288 tiles of the
 // ResnetBlock data gradient) the generic 128x128 kernel with 3 co-resident blocks per CU wins
 // (measured: scripts/bench_conv.py, profiles/r01_conv_layers_*.log).
+static bool prefer_320(int M, int Ks);
 static bool fast_pays(int M, int Ks, int k_tiles) {
   if (!g_fast_enabled) return false;
   if (k_tiles < 8) return false;   // short reductions (stride-2 sub-pixel phases of 2x2 taps x 64 ch) do not fill the 3-stage ring
   if (Ks <= 32) return false;   // measured: the generic 256x32 kernel beats the 8-wave 256x32 fast config
   const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32);
   const long long tiles = (long long)((M + 255) / 256) * ((Ks + bn - 1) / bn);
+  if (prefer_320(M, Ks)) {
+    const long long t320 = (long long)((M + 319) / 320) * ((Ks + 127) / 128);
+    if (t320 % 256 == 0 || t320 % 256 >= 192 || t320 >= 448) return true;   // well-filled rounds
+  }
   return tiles >= 448 || (tiles >= 256 && tiles % 256 == 0);
 }
 

@@ -48,11 +48,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // VAR selects the inner-loop schedule (A/B-able in one process via jpdse_debug_set_fast_path):
 //   0: DMA issue right after the barrier, then 4 x {4 ds_read_b128, 4 MFMA}
 //   1: fragment reads of k-step g+1 requested before the MFMAs of step g, DMA issued behind group 0
-template <int WM, int WN, int TM, int TN, int VAR>
+// STAGES = 3: ring with one tile in flight across the barrier (counted vmcnt).  STAGES = 2 (used by
+// the 320-row tile, whose 3-stage ring would not fit 160 KiB): next tile issued right after the barrier,
+// vmcnt(0) at the following one.
+template <int WM, int WN, int TM, int TN, int VAR, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs a) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int STAGES = 3;
   constexpr int A_HALF = BM * 64, B_HALF = BN * 64;
   constexpr int STAGE_BYTES = 2 * (A_HALF + B_HALF);
   constexpr int A_RG = BM / 16, B_RG = BN / 16;     // 16-row groups per half
@@ -176,11 +178,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs 
     istage = istage == STAGES - 1 ? 0 : istage + 1;
   };
 
+  constexpr int AHEAD = STAGES - 1;       // tiles issued before tile t is consumed
   issue();
-  if (T_total > 1) issue();
+  if (AHEAD > 1 && T_total > 1) issue();
   int cstage = 0;
   for (int t = 0; t < T_total; ++t) {
-    if (t + 1 < T_total) {
+    if (AHEAD > 1 && t + 1 < T_total) {
       if (LW == AU + BU) wait_vmcnt<AU + BU>();
       else wait_vmcnt<AU + (BU > 0 ? BU - 1 : 0)>();
     } else {
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs 
     __builtin_amdgcn_s_barrier();
     const char* const st = smem + cstage * STAGE_BYTES;
     if constexpr (VAR == 0) {
-      if (t + 2 < T_total) issue();
+      if (t + AHEAD < T_total) issue();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs 
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        if (g == 0 && t + 2 < T_total) issue();
+        if (g == 0 && t + AHEAD < T_total) issue();
       }
     }
     cstage = cstage == STAGES - 1 ? 0 : cstage + 1;

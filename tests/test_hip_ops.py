@@ -56,6 +56,10 @@ CONV_CASES = [
     ('vgg_conv1_1',   1, 16, 24, 3,    64,  3, 1,  1,  PAD_ZERO,    ACT_RELU),
     ('vgg_conv3',     1, 8,  12, 128,  256, 3, 1,  1,  PAD_ZERO,    ACT_RELU),
     ('local_32ch',    1, 14, 22, 39,   32,  7, 1,  3,  PAD_REFLECT, ACT_NONE),
+    # M = 33024: 129 tiles of 256 rows x 2 -> the dispatcher picks the 320-row / 2-stage fast tile (208 tiles)
+    ('tile320_path',  1, 128, 258, 64, 256, 3, 1,  1,  PAD_ZERO,    ACT_NONE),
+    # stream-K wgrad with tiles straddling blocks, 256-row fast fwd tiles, K-tile count 36
+    ('fast_256_tiles', 2, 64, 128, 256, 128, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
 ]
 
 
