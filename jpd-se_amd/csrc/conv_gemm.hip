@@ -68,6 +68,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 
 }  // namespace jpdse
 #include "gemm_fast.h"
+#include "gemm_halo.h"
 #include "wgrad_fast.h"
 namespace jpdse {
 
@@ -662,6 +663,45 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ o
   }
 }
 
+// Fast paths (channel counts that are multiples of 8, i.e. every layer but the network inputs):
+// the forward panel is then the plain compute-dtype cast of the KRSC master (8 elements per lane), and
+// a data-gradient panel is a [k][c] -> [c][k] transpose per filter tap, done through an LDS tile so
+// that both the fp32 reads (along c) and the 16-bit writes (along k) are coalesced.
+template <typename T>
+__global__ void pack_fwd_cast_kernel(const float* __restrict__ w, T* __restrict__ out, long long total8) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total8;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + idx * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(w + idx * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ElemOps<T>::st(out + idx * 8 + e, a[e]);
+      ElemOps<T>::st(out + idx * 8 + 4 + e, b[e]);
+    }
+  }
+}
+
+// out[c][up][wp*Ks + k] = w[k][r(up)][s(wp)][c];  grid = (c tiles of 64, k tiles of 64, Uh*Uw taps)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_dgrad_tile_kernel(const float* __restrict__ w, T* __restrict__ out, int K,
+                                                             int Ks, int C, int Cs, int R, int S, int st, int qh,
+                                                             int qw, int Uh, int Uw, int Lk) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int up = blockIdx.z / Uw, wp = blockIdx.z % Uw;
+  const int r = qh + st * (Uh - 1 - up), s = qw + st * (Uw - 1 - wp);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  for (int kk = ty; kk < 64; kk += 4) {
+    const int k = k0 + kk, c = c0 + tx;
+    tile[kk][tx] = (k < K && c < C) ? w[(((long long)k * R + r) * S + s) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, k = k0 + tx;
+    if (c < Cs && k < Ks) ElemOps<T>::st(out + ((long long)c * Uh + up) * Lk + wp * Ks + k, tile[tx][cc]);
+  }
+}
+
 // =========================================================================================
 // host side: planning and launch
 // =========================================================================================
@@ -915,10 +955,83 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
   return tiles >= 448 || (tiles >= 256 && tiles % 256 == 0);
 }
 
+static int g_halo_enabled = 1;
+static int g_halo_abl = 0;
+
+template <int TN, int ABL = 0>
+static int launch_halo_cfg(const HaloArgs& a, hipStream_t s) {
+  constexpr int BN = 2 * TN * 32;
+  constexpr int UH = ((4 + 2) * (64 + 2) + 15) / 16;
+  constexpr int lds = 2 * 2 * UH * 1024 + 3 * 2 * BN * 64;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  const int tiles = a.N * (a.OH / 4) * (a.OW / 64) * ((a.Ks + BN - 1) / BN);
+  const long long kdim = 9LL * a.Cs;
+  const int M = a.N * a.OH * a.OW;
+  const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
+                     (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL>), dim3(tiles), dim3(512), lds, s, a);
+  if (timed) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
+    g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
+    ++g_prof.used;
+  }
+  return check_launch("gemm_halo_kernel");
+}
+
+// 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
+// gradient of the zero-padded ones): LDS-resident input halo, see gemm_halo.h
+static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_out) {
+  return g_fast_enabled && g_halo_enabled && R == 3 && S == 3 && stride == 1 && OH % 4 == 0 && OW % 64 == 0 &&
+         Cs_in % 64 == 0 && Ks_out > 32;
+}
+
 template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
                       const float* bias, void* y, void* ws, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks)) {
+      HaloArgs h = {};
+      h.X = reinterpret_cast<const bf16_t*>(x);
+      h.B = reinterpret_cast<const bf16_t*>(pack);
+      h.bias = bias;
+      h.Y = reinterpret_cast<bf16_t*>(y);
+      h.N = d->N;
+      h.OH = p.OH;
+      h.OW = p.OW;
+      h.IH = d->H;
+      h.IW = d->W;
+      h.Cs = p.Cs;
+      h.py = h.px = d->pad;
+      h.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+      h.Kout = d->K;
+      h.Ks = p.Ks;
+      h.b_rows = p.Ks;
+      h.out_sn = (long long)p.OH * p.OW * p.Ks;
+      h.out_sh = (long long)p.OW * p.Ks;
+      h.out_sw = p.Ks;
+      h.out_base = 0;
+      h.act = d->act;
+      h.slope = d->slope;
+      if (g_halo_abl && p.Ks > 64) {      // timing-only ablations (scripts/bench_conv.py --fast 11..)
+        switch (g_halo_abl) {
+          case 1: return launch_halo_cfg<2, 1>(h, s);
+          case 2: return launch_halo_cfg<2, 2>(h, s);
+          case 4: return launch_halo_cfg<2, 4>(h, s);
+          case 9: return launch_halo_cfg<2, 9>(h, s);
+          case 11: return launch_halo_cfg<2, 11>(h, s);
+          case 15: return launch_halo_cfg<2, 15>(h, s);
+          default: break;
+        }
+      }
+      return p.Ks > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
+    }
     if (p.Cs % 64 == 0 && fast_pays(d->N * p.OH * p.OW, p.Ks, d->R * d->S * p.Cs / 64)) {
       FastArgs f = {};
       f.X = reinterpret_cast<const bf16_t*>(x);
@@ -988,6 +1101,35 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   void* dxp = wsb + p.dypad_bytes;
   const bool refl = d->pad_mode == JPDSE_PAD_REFLECT;
   const int st = d->stride;
+  if constexpr (sizeof(T) == 2) {
+    if (!refl && p.nph == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W &&
+        halo_ok(p.ph[0].Uh, p.ph[0].Uw, st, d->H, d->W, p.Ks, p.Cs)) {
+      const Phase& f = p.ph[0];
+      HaloArgs h = {};
+      h.X = reinterpret_cast<const bf16_t*>(dy);
+      h.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
+      h.bias = nullptr;
+      h.Y = reinterpret_cast<bf16_t*>(dx);
+      h.N = d->N;
+      h.OH = d->H;
+      h.OW = d->W;
+      h.IH = p.OH;
+      h.IW = p.OW;
+      h.Cs = p.Ks;
+      h.py = (f.Uh - 1) - f.i0h;
+      h.px = (f.Uw - 1) - f.i0w;
+      h.reflect = 0;
+      h.Kout = d->C;
+      h.Ks = p.Cs;
+      h.b_rows = p.Cs;
+      h.out_sn = (long long)d->H * d->W * p.Cs;
+      h.out_sh = (long long)d->W * p.Cs;
+      h.out_sw = p.Cs;
+      h.out_base = 0;
+      h.act = JPDSE_ACT_NONE;
+      return p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
+    }
+  }
   bool fast = false;
   if constexpr (sizeof(T) == 2) {
     fast = p.Ks % 64 == 0;
@@ -1253,6 +1395,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   // 0: generic kernels only; 1: fast kernels (default schedule 0); 2: fast kernels, alternative schedule 1
   g_fast_enabled = enable != 0;
   g_fast_variant = enable == 2 ? 1 : 0;
+  g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
+  g_halo_abl = enable >= 100 ? enable - 100 : 0;   // 100+bits: halo kernel timing ablations (wrong results)
   return JPDSE_OK;
 }
 
@@ -1344,7 +1488,17 @@ int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w, void* fwd_
   ConvPlan p;
   make_plan(d, &p);
   hipStream_t s = as_stream(stream);
-  if (fwd_pack) {
+  const bool plain = (d->C == p.Cs) && (d->K == p.Ks) && (p.Lk_fwd == d->S * p.Cs);
+  if (fwd_pack && plain) {
+    const long long total8 = (long long)p.Ks * d->R * p.Lk_fwd / 8;
+    if (d->dtype == JPDSE_BF16)
+      hipLaunchKernelGGL((pack_fwd_cast_kernel<bf16_t>), dim3(ew_blocks(total8)), dim3(256), 0, s, w,
+                         reinterpret_cast<bf16_t*>(fwd_pack), total8);
+    else
+      hipLaunchKernelGGL((pack_fwd_cast_kernel<float>), dim3(ew_blocks(total8)), dim3(256), 0, s, w,
+                         reinterpret_cast<float*>(fwd_pack), total8);
+    if (int rc = check_launch("pack_fwd_cast_kernel")) return rc;
+  } else if (fwd_pack) {
     const long long total = (long long)p.Ks * d->R * p.Lk_fwd;
     if (d->dtype == JPDSE_BF16)
       hipLaunchKernelGGL((pack_fwd_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
@@ -1360,6 +1514,17 @@ int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w, void* fwd_
       const long long total = (long long)p.Cs * f.Uh * f.Lk;
       if (total == 0) continue;
       char* out = reinterpret_cast<char*>(dgrad_pack) + f.pack_off;
+      if (f.Lk == f.Uw * p.Ks && p.Cs * p.Ks >= 64 * 64) {     // no K padding inside the panel: tiled transpose
+        const dim3 grid((p.Cs + 63) / 64, (p.Ks + 63) / 64, f.Uh * f.Uw);
+        if (d->dtype == JPDSE_BF16)
+          hipLaunchKernelGGL((pack_dgrad_tile_kernel<bf16_t>), grid, dim3(256), 0, s, w, reinterpret_cast<bf16_t*>(out),
+                             d->K, p.Ks, d->C, p.Cs, d->R, d->S, d->stride, f.qh, f.qw, f.Uh, f.Uw, f.Lk);
+        else
+          hipLaunchKernelGGL((pack_dgrad_tile_kernel<float>), grid, dim3(256), 0, s, w, reinterpret_cast<float*>(out),
+                             d->K, p.Ks, d->C, p.Cs, d->R, d->S, d->stride, f.qh, f.qw, f.Uh, f.Uw, f.Lk);
+        if (int rc = check_launch("pack_dgrad_tile_kernel")) return rc;
+        continue;
+      }
       if (d->dtype == JPDSE_BF16)
         hipLaunchKernelGGL((pack_dgrad_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
                            reinterpret_cast<bf16_t*>(out), d->K, p.Ks, d->C, p.Cs, d->R, d->S, d->stride, f.qh,

@@ -1,0 +1,241 @@
+// 3x3 stride-1 convolution (forward, and the data gradient of zero-padded 3x3 convs) with an
+// LDS-resident input halo -- the kernel for the ResnetBlock convs and VGG19.
+//
+// Why: hardware counters on gemm_fast_kernel show 0 LDS bank conflicts, the MFMA pipe ~42 % busy and
+// waves parked ~43 % of the time at s_waitcnt/s_barrier: a 256x128x64 K-tile needs 48 KiB of L2->LDS
+// fill per 1024 MFMA cycles, above what one CU's LDS-DMA path sustains (~70 GB/s, MI355X_MICROARCH.md
+// "Indexed rows: gather into LDS").  2/3 of that fill is the activation tile, and for a 3x3 filter
+// the nine taps read the SAME pixels shifted by one.  Here a block owns a TH x 64 output patch of one
+// image: per 64-channel slab it stages the (TH+2) x 66 input patch ONCE (padding resolved while
+// loading), then loops over the 9 taps streaming only the 16 KiB weight tile; the A fragments are
+// read from the patch at tap-shifted addresses.  Fill traffic per tap: 21.6 KiB instead of 48 KiB.
+//
+// Pipeline: weight tiles in a 3-stage ring (counted vmcnt, one raw barrier per tap); the NEXT slab's
+// patch is double buffered and its DMA units are spread over taps 0..6 of the current slab.
+#pragma once
+#include "common.h"
+#include "gemm_fast.h"
+
+namespace jpdse {
+
+struct HaloArgs {
+  const bf16_t* X;   // [N][IH][IW][Cs]
+  const bf16_t* B;   // panel [b_rows][9*Cs]
+  const float* bias;
+  bf16_t* Y;
+  int N, OH, OW;     // output grid; requires OH % TH == 0, OW % 64 == 0
+  int IH, IW, Cs;
+  int py, px, reflect;
+  int Kout, Ks, b_rows;
+  long long out_sn, out_sh, out_sw, out_base;
+  int act;
+  float slope;
+};
+
+// ABL: timing-only ablation bits (results are wrong when non-zero): 1 = no DMA after the prologue,
+// 2 = no barrier, 4 = fragments read once per tap-group only (no per-k-step LDS reads), 8 = no vmcnt waits
+template <int TH, int TN, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
+  constexpr int R = 3, S = 3, TAPS = 9;
+  constexpr int NW = 8, WN = 2;                       // waves: TH (=4) x 2
+  static_assert(TH == 4, "8 waves = 4 image rows x 2 channel halves");
+  constexpr int BN = WN * TN * 32;
+  constexpr int PH = TH + R - 1, PW = 64 + S - 1, NP = PH * PW;
+  constexpr int UH = (NP + 15) / 16;                  // 1 KiB DMA units per 32-channel half of the patch
+  constexpr int HALO_HALF = UH * 1024, HALO = 2 * HALO_HALF;
+  constexpr int B_HALF = BN * 64, B_STAGE = 2 * B_HALF;
+  constexpr int B_RG = BN / 16, B_UNITS = 2 * B_RG, BU = (B_UNITS + NW - 1) / NW;
+  constexpr int HU = (2 * UH + NW - 1) / NW;          // patch units per wave (7 for 50 units / 8 waves)
+  static_assert(HU <= TAPS - 2, "patch units of the next slab are spread over taps 0..HU-1");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const halo0 = smem;
+  char* const bring = smem + 2 * HALO;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int tiles_w = a.OW / 64, tiles_h = a.OH / TH;
+  const int tiles_m = a.N * tiles_h * tiles_w;
+  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+  const int tw_i = tile_m % tiles_w, t1 = tile_m / tiles_w;
+  const int th_i = t1 % tiles_h, n = t1 / tiles_h;
+  const int oh0 = th_i * TH, ow0 = tw_i * 64, n0 = tile_n * BN;
+  const int lrow = lane >> 2, lslot = lane & 3;
+  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+  // ---- patch DMA units of this wave: element offset of the lane's 16 bytes (slab 0), or -1 -> zero page
+  long long h_off[HU];
+  int h_lds[HU];
+  int n_hu = 0;
+#pragma unroll
+  for (int i = 0; i < HU; ++i) {
+    const int u = wid + i * NW;
+    const bool on = u < 2 * UH;
+    n_hu += on ? 1 : 0;
+    const int uu = on ? u : 0;
+    const int half = uu / UH, ug = uu % UH;
+    int p = ug * 16 + lrow;
+    const int swz_p = p;                              // the swizzle uses the LDS pixel index, also for clamped lanes
+    p = p < NP ? p : NP - 1;
+    const int hr = p / PW, wc = p - hr * PW;
+    int ih = oh0 - a.py + hr, iw = ow0 - a.px + wc;
+    bool ok = true;
+    if (a.reflect) {
+      ih = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
+      iw = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
+    } else {
+      ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
+    }
+    const int chunk = (lslot ^ (swz_p >> 3)) & 3;
+    h_off[i] = ok ? (((long long)n * a.IH + ih) * a.IW + iw) * a.Cs + half * 32 + chunk * 8 : -1;
+    h_lds[i] = half * HALO_HALF + ug * 1024;
+  }
+  // ---- weight tile DMA units
+  const bf16_t* b_ptr[BU];
+  int b_lds[BU];
+  bool b_on[BU];
+  const long long ktot = (long long)TAPS * a.Cs;
+#pragma unroll
+  for (int j = 0; j < BU; ++j) {
+    const int u = wid + j * NW;
+    b_on[j] = u < B_UNITS;
+    const int uu = b_on[j] ? u : 0;
+    const int half = uu / B_RG, rg = uu % B_RG;
+    const int row = rg * 16 + lrow;
+    int br = n0 + row;
+    br = br < a.b_rows ? br : a.b_rows - 1;
+    b_ptr[j] = a.B + (long long)br * ktot + half * 32 + ((lslot ^ (row >> 3)) & 3) * 8;
+    b_lds[j] = half * B_HALF + rg * 1024;
+  }
+  int n_b = 0;
+#pragma unroll
+  for (int j = 0; j < BU; ++j) n_b += b_on[j] ? 1 : 0;
+
+  // ---- fragment addressing
+  int pb[2];                                          // patch pixel of this lane's row for tap (0,0), per 32-row block
+#pragma unroll
+  for (int i = 0; i < 2; ++i) pb[i] = wm * PW + i * 32 + (lane & 31);
+  const int hsel = lane >> 5;
+  int b_rd[TN][2];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * TN * 32 + j * 32 + (lane & 31);
+    b_rd[j][0] = swz(row, hsel);
+    b_rd[j][1] = swz(row, 2 + hsel);
+  }
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int CC = a.Cs >> 6;
+  const int T_total = CC * TAPS;
+
+  auto issue_patch_unit = [&](int i, int slab) {      // i: compile-time after unrolling at the call sites
+    char* const dst = halo0 + (slab & 1) * HALO + h_lds[i];
+    const bf16_t* src = h_off[i] >= 0 ? a.X + h_off[i] + slab * 64 : zero;
+    glds16(src, dst);
+  };
+  auto issue_b = [&](int tile) {                      // tile = slab*9 + tap -> K offset tap*Cs + slab*64
+    const int slab = tile / TAPS, tap = tile - slab * TAPS;
+    char* const st = bring + (tile % 3) * B_STAGE;
+    const long long koff = (long long)tap * a.Cs + slab * 64;
+#pragma unroll
+    for (int j = 0; j < BU; ++j)
+      if (b_on[j]) glds16(b_ptr[j] + koff, st + b_lds[j]);
+  };
+
+  // prologue: whole patch of slab 0, then weight tiles 0 and 1
+#pragma unroll
+  for (int i = 0; i < HU; ++i)
+    if (i < n_hu) issue_patch_unit(i, 0);
+  issue_b(0);
+  if (T_total > 1) issue_b(1);
+
+  int slab = 0, tap = 0;
+  for (int t = 0; t < T_total; ++t) {
+    // loads allowed to stay in flight: the group issued in iteration t-1 = [patch unit?, weight tile t+1]
+    if (ABL & 8) {
+    } else if (t + 1 < T_total) {
+      const int ptap = tap == 0 ? TAPS - 1 : tap - 1;           // tap index of iteration t-1
+      const int pslab = tap == 0 ? slab - 1 : slab;
+      const bool had_patch = t > 0 && ptap < n_hu && pslab + 1 < CC;
+      if (had_patch) {
+        if (n_b == BU) wait_vmcnt<BU + 1>(); else wait_vmcnt<BU>();
+      } else {
+        if (n_b == BU) wait_vmcnt<BU>(); else wait_vmcnt<(BU > 0 ? BU - 1 : 0)>();
+      }
+    } else {
+      wait_vmcnt<0>();
+    }
+    if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+    // issue group t+2: one patch unit of the NEXT slab (only from the slab's first tap on: its buffer was
+    // being read until the previous slab ended), then weight tile t+2
+    if (!(ABL & 1)) {
+      if (tap < n_hu && slab + 1 < CC) {
+#pragma unroll
+        for (int i = 0; i < HU; ++i)
+          if (i == tap) issue_patch_unit(i, slab + 1);
+      }
+      if (t + 2 < T_total) issue_b(t + 2);
+    }
+
+    const char* const hb = halo0 + (slab & 1) * HALO;
+    const char* const st = bring + (t % 3) * B_STAGE;
+    const int r = tap / S, s = tap - r * S;
+    const int tapoff = r * PW + s;
+    int a_base[2], a_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pt = pb[i] + tapoff;
+      a_base[i] = pt << 6;
+      a_sw[i] = ((pt >> 3) & 3) << 4;
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        s16x8 af[2], bf[TN];
+        const int hh_r = (ABL & 4) ? 0 : hh, u_r = (ABL & 4) ? 0 : u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[i] = *reinterpret_cast<const s16x8*>(hb + hh_r * HALO_HALF + a_base[i] + ((((2 * u_r + hsel) << 4)) ^ a_sw[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + hh_r * B_HALF + b_rd[j][u_r]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (++tap == TAPS) { tap = 0; ++slab; }
+  }
+
+  // ---- epilogue: wave wm owns image row oh0+wm; 2 x 32 consecutive pixels
+  const long long row_base = a.out_base + n * a.out_sn + (long long)(oh0 + wm) * a.out_sh + (long long)ow0 * a.out_sw;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+    if (col >= a.Ks) continue;
+    const bool live = col < a.Kout;
+    const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int tw = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const float v = live ? apply_act(acc[i][j][e] + bv, a.act, a.slope) : 0.f;
+        a.Y[row_base + (long long)tw * a.out_sw + col] = f2bf(v);
+      }
+    }
+  }
+}
+
+}  // namespace jpdse

@@ -60,6 +60,9 @@ CONV_CASES = [
     ('tile320_path',  1, 128, 258, 64, 256, 3, 1,  1,  PAD_ZERO,    ACT_NONE),
     # stream-K wgrad with tiles straddling blocks, 256-row fast fwd tiles, K-tile count 36
     ('fast_256_tiles', 2, 64, 128, 256, 128, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    # halo kernel: 64-wide N tile, zero pad (fwd and data gradient), 2 slabs; and 128-wide with ReLU epilogue
+    ('halo_vgg_64',   2, 8,  64,  128, 64,  3, 1, 1,  PAD_ZERO,    ACT_RELU),
+    ('halo_vgg_256',  1, 12, 128, 64,  256, 3, 1, 1,  PAD_ZERO,    ACT_RELU),
 ]
 
 
