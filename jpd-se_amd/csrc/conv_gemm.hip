@@ -556,35 +556,40 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_kernel(const GemmWgra
 // =========================================================================================
 // padding (materialises the padded NHWC input + zeroed slack) and its reflect adjoint
 // =========================================================================================
+// One block per padded row (n, hp): the source row is resolved once, lanes own a channel-vector
+// column and walk the row's pixels -- no integer division in the copy loop.
 template <typename T>
-__global__ void pad_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W, int Cs,
-                           int pt, int pl, int Hp, int Wp, int mode, long long total_vec,
-                           long long slack_vec) {
+__global__ __launch_bounds__(256) void pad_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W,
+                                                 int Cs, int pt, int pl, int Hp, int Wp, int mode, int tx_shift,
+                                                 long long total_vec, long long slack_vec) {
   constexpr int VE = 16 / sizeof(T);
   const int cv = Cs / VE;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec + slack_vec;
-       idx += (long long)gridDim.x * blockDim.x) {
-    u32x4 v = zero4;
-    if (idx < total_vec) {
-      const int c = (int)(idx % cv);
-      long long t = idx / cv;
-      const int wp = (int)(t % Wp);
-      t /= Wp;
-      const int hp = (int)(t % Hp);
-      const int n = (int)(t / Hp);
-      int h = hp - pt, w = wp - pl;
-      bool ok = true;
-      if (mode == JPDSE_PAD_REFLECT) {
-        h = h < 0 ? -h : (h >= H ? 2 * (H - 1) - h : h);
-        w = w < 0 ? -w : (w >= W ? 2 * (W - 1) - w : w);
-      } else {
-        ok = (h >= 0) & (h < H) & (w >= 0) & (w < W);
+  const int TX = 1 << tx_shift, TY = 256 >> tx_shift;
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> tx_shift;
+  const int rows = N * Hp;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / Hp, hp = row - n * Hp;
+    int h = hp - pt;
+    bool row_ok = true;
+    if (mode == JPDSE_PAD_REFLECT) h = h < 0 ? -h : (h >= H ? 2 * (H - 1) - h : h);
+    else row_ok = (h >= 0) & (h < H);
+    const T* srow = src + ((long long)n * H + (row_ok ? h : 0)) * W * Cs;
+    T* drow = dst + (long long)row * Wp * Cs;
+    for (int c = tx; c < cv; c += TX) {
+      for (int wp = ty; wp < Wp; wp += TY) {
+        int w = wp - pl;
+        bool ok = row_ok;
+        if (mode == JPDSE_PAD_REFLECT) w = w < 0 ? -w : (w >= W ? 2 * (W - 1) - w : w);
+        else ok = ok & (w >= 0) & (w < W);
+        u32x4 v = zero4;
+        if (ok) v = *reinterpret_cast<const u32x4*>(srow + (long long)w * Cs + c * VE);
+        *reinterpret_cast<u32x4*>(drow + (long long)wp * Cs + c * VE) = v;
       }
-      if (ok) v = *reinterpret_cast<const u32x4*>(src + (((long long)n * H + h) * W + w) * Cs + c * VE);
     }
-    *reinterpret_cast<u32x4*>(dst + idx * VE) = v;
   }
+  if (blockIdx.x == 0)
+    for (long long i = threadIdx.x; i < slack_vec; i += 256) *reinterpret_cast<u32x4*>(dst + (total_vec + i) * VE) = zero4;
 }
 
 // dx[h][w] = sum over the padded-domain aliases of (h,w) of dxp (adjoint of ReflectionPad2d(p))
@@ -810,9 +815,13 @@ static int launch_pad(const void* src, void* dst, int N, int H, int W, int Cs, i
   const int VE = 16 / (int)sizeof(T);
   const long long total_vec = (long long)N * Hp * Wp * (Cs / VE);
   const long long slack_vec = kSlackBytes / 16;
-  hipLaunchKernelGGL((pad_kernel<T>), dim3(ew_blocks(total_vec + slack_vec)), dim3(256), 0, s,
+  int tx_shift = 0;
+  while ((1 << tx_shift) < Cs / VE && tx_shift < 8) ++tx_shift;
+  int grid = N * Hp;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL((pad_kernel<T>), dim3(grid), dim3(256), 0, s,
                      reinterpret_cast<const T*>(src), reinterpret_cast<T*>(dst), N, H, W, Cs, pt, pl, Hp, Wp,
-                     mode, total_vec, slack_vec);
+                     mode, tx_shift, total_vec, slack_vec);
   return check_launch("pad_kernel");
 }
 

@@ -11,7 +11,8 @@ namespace jpdse {
 
 struct MomentGeom {
   int N, HW, Cs, cv;      // cv = Cs / VE vector columns
-  int TX, TY;             // threads across columns / pixels (TX*TY = 256)
+  int TX, TY;             // threads across columns / pixels (TX*TY = 256), TX a power of two
+  int tx_shift;           // log2(TX)
   int splits, pix_per_split;
 };
 
@@ -21,6 +22,8 @@ static MomentGeom moment_geom(int N, int HW, int Cs, int VE) {
   int tx = 1;
   while (tx < g.cv && tx < 256) tx <<= 1;
   g.TX = tx; g.TY = 256 / tx;
+  g.tx_shift = 0;
+  while ((1 << g.tx_shift) < tx) ++g.tx_shift;
   // aim for ~2048 blocks in total, at least 8 pixels per thread row
   const int col_blocks = (g.cv + g.TX - 1) / g.TX;
   long long want = 2048 / ((long long)N * col_blocks);
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void moment_kernel(const T* __restrict__ x, co
                                                     float* __restrict__ partial, MomentGeom g) {
   constexpr int VE = Vec16<T>::N;
   __shared__ float red[256 * 2 * VE];
-  const int tx = threadIdx.x % g.TX, ty = threadIdx.x / g.TX;
+  const int tx = threadIdx.x & (g.TX - 1), ty = threadIdx.x >> g.tx_shift;
   const int col_blocks = (g.cv + g.TX - 1) / g.TX;
   const int cb = blockIdx.x % col_blocks;
   const int split = (blockIdx.x / col_blocks) % g.splits;
@@ -192,58 +195,86 @@ __global__ void finalize_bwd_kernel(const float* __restrict__ partial, float* __
   sums[2 * idx + 1] = b * inv;
 }
 
+// Apply kernels: same block decomposition as the moment kernel (one 16-byte channel-vector column per
+// lane, pixels walked with stride TY), so the per-channel constants are loaded once per thread and the
+// inner loop has no integer division; coalescing is along the contiguous channel axis.
 template <typename T>
-__global__ void inorm_apply_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-                                       const float* __restrict__ stats, int HW, int Cs, int act, float slope,
-                                       long long total_vec) {
+__global__ __launch_bounds__(256) void inorm_apply_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                            T* __restrict__ y, const float* __restrict__ stats,
+                                                            int act, float slope, MomentGeom g) {
   constexpr int VE = Vec16<T>::N;
-  const int cv = Cs / VE;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int col = (int)(idx % cv);
-    const long long pix = idx / cv;
-    const int n = (int)(pix / HW);
-    const float* st = stats + ((long long)n * Cs + col * VE) * 2;
+  const int tx = threadIdx.x & (g.TX - 1), ty = threadIdx.x >> g.tx_shift;
+  const int col_blocks = (g.cv + g.TX - 1) / g.TX;
+  const int cb = blockIdx.x % col_blocks;
+  const int split = (blockIdx.x / col_blocks) % g.splits;
+  const int n = blockIdx.x / (col_blocks * g.splits);
+  const int col = cb * g.TX + tx;
+  if (col >= g.cv) return;
+  const int c0 = col * VE;
+  float mean[VE], rstd[VE];
+  const float* st = stats + ((long long)n * g.Cs + c0) * 2;
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { mean[e] = st[2 * e]; rstd[e] = st[2 * e + 1]; }
+  const int p0 = split * g.pix_per_split;
+  int p1 = p0 + g.pix_per_split;
+  p1 = p1 < g.HW ? p1 : g.HW;
+  const long long base = (long long)n * g.HW * g.Cs + c0;
+  for (int p = p0 + ty; p < p1; p += g.TY) {
+    const long long off = base + (long long)p * g.Cs;
     float v[VE], r[VE];
-    Vec16<T>::load(x + idx * VE, v);
-    if (res != nullptr) Vec16<T>::load(res + idx * VE, r);
+    Vec16<T>::load(x + off, v);
+    if (res != nullptr) Vec16<T>::load(res + off, r);
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      float t = (v[e] - st[2 * e]) * st[2 * e + 1];
+      float t = (v[e] - mean[e]) * rstd[e];
       if (act == JPDSE_ACT_RELU) t = t > 0.f ? t : 0.f;
       else if (act == JPDSE_ACT_LRELU) t = t > 0.f ? t : t * slope;
       if (res != nullptr) t += r[e];
       v[e] = t;
     }
-    Vec16<T>::store(y + idx * VE, v);
+    Vec16<T>::store(y + off, v);
   }
 }
 
 template <typename T>
-__global__ void inorm_apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
-                                       const float* __restrict__ stats, const float* __restrict__ sums, int HW,
-                                       int Cs, int act, float slope, long long total_vec) {
+__global__ __launch_bounds__(256) void inorm_apply_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            T* __restrict__ dx, const float* __restrict__ stats,
+                                                            const float* __restrict__ sums, int act, float slope,
+                                                            MomentGeom g) {
   constexpr int VE = Vec16<T>::N;
-  const int cv = Cs / VE;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int col = (int)(idx % cv);
-    const long long pix = idx / cv;
-    const int n = (int)(pix / HW);
-    const long long sidx = ((long long)n * Cs + col * VE) * 2;
-    const float* st = stats + sidx;
-    const float* sm = sums + sidx;
-    float v[VE], g[VE];
-    Vec16<T>::load(x + idx * VE, v);
-    Vec16<T>::load(dy + idx * VE, g);
+  const int tx = threadIdx.x & (g.TX - 1), ty = threadIdx.x >> g.tx_shift;
+  const int col_blocks = (g.cv + g.TX - 1) / g.TX;
+  const int cb = blockIdx.x % col_blocks;
+  const int split = (blockIdx.x / col_blocks) % g.splits;
+  const int n = blockIdx.x / (col_blocks * g.splits);
+  const int col = cb * g.TX + tx;
+  if (col >= g.cv) return;
+  const int c0 = col * VE;
+  float mean[VE], rstd[VE], s1[VE], s2[VE];
+  const long long sidx = ((long long)n * g.Cs + c0) * 2;
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    mean[e] = stats[sidx + 2 * e];
+    rstd[e] = stats[sidx + 2 * e + 1];
+    s1[e] = sums[sidx + 2 * e];
+    s2[e] = sums[sidx + 2 * e + 1];
+  }
+  const int p0 = split * g.pix_per_split;
+  int p1 = p0 + g.pix_per_split;
+  p1 = p1 < g.HW ? p1 : g.HW;
+  const long long base = (long long)n * g.HW * g.Cs + c0;
+  for (int p = p0 + ty; p < p1; p += g.TY) {
+    const long long off = base + (long long)p * g.Cs;
+    float v[VE], gr[VE];
+    Vec16<T>::load(x + off, v);
+    Vec16<T>::load(dy + off, gr);
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
-      const float rstd = st[2 * e + 1];
-      const float yh = (v[e] - st[2 * e]) * rstd;
-      const float dz = g[e] * act_grad(yh, act, slope);
-      v[e] = rstd * (dz - sm[2 * e] - yh * sm[2 * e + 1]);
+      const float yh = (v[e] - mean[e]) * rstd[e];
+      const float dz = gr[e] * act_grad(yh, act, slope);
+      v[e] = rstd[e] * (dz - s1[e] - yh * s2[e]);
     }
-    Vec16<T>::store(dx + idx * VE, v);
+    Vec16<T>::store(dx + off, v);
   }
 }
 
@@ -278,10 +309,9 @@ static int inorm_fwd_t(const jpdse_inorm_desc* d, const void* x, const void* res
   hipLaunchKernelGGL((finalize_fwd_kernel<T>), dim3((d->N * Cs * 8 + 255) / 256), dim3(256), 0, s,
                      reinterpret_cast<const T*>(x), partial, stats, d->N, HW, Cs, g.splits, d->eps);
   if (int rc = check_launch("inorm finalize fwd")) return rc;
-  const long long total_vec = (long long)d->N * HW * g.cv;
-  hipLaunchKernelGGL((inorm_apply_fwd_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s,
+  hipLaunchKernelGGL((inorm_apply_fwd_kernel<T>), dim3(d->N * g.splits * col_blocks), dim3(256), 0, s,
                      reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(res), reinterpret_cast<T*>(y), stats,
-                     HW, Cs, d->act, d->slope, total_vec);
+                     d->act, d->slope, g);
   return check_launch("inorm apply fwd");
 }
 
@@ -302,10 +332,9 @@ static int inorm_bwd_t(const jpdse_inorm_desc* d, const void* x, const float* st
   hipLaunchKernelGGL(finalize_bwd_kernel, dim3((d->N * Cs * 8 + 255) / 256), dim3(256), 0, s, partial, sums, d->N, HW,
                      Cs, g.splits);
   if (int rc = check_launch("inorm finalize bwd")) return rc;
-  const long long total_vec = (long long)d->N * HW * g.cv;
-  hipLaunchKernelGGL((inorm_apply_bwd_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s,
+  hipLaunchKernelGGL((inorm_apply_bwd_kernel<T>), dim3(d->N * g.splits * col_blocks), dim3(256), 0, s,
                      reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx), stats,
-                     sums, HW, Cs, d->act, d->slope, total_vec);
+                     sums, d->act, d->slope, g);
   return check_launch("inorm apply bwd");
 }
 
