@@ -129,7 +129,7 @@ class OracleTrainer(object):
     return input_label, real, src
 
   def generate(self, input_label, src):
-    return nets.generator(self.G, torch.cat((input_label, src), dim=1), self.cfg)
+    return nets.generator(self.G, nets.q(torch.cat((input_label, src), dim=1)), self.cfg)
 
   def netD(self, x):
     return nets.multiscale_d(self.D, x, self.opt.num_D, self.opt.n_layers_D)
@@ -144,6 +144,7 @@ class OracleTrainer(object):
     opt = self.opt
     input_label, real, src = self._inputs(x_dict)
     fake = self.generate(input_label, src)
+    real = nets.q(real)            # no-op unless bf16-storage emulation is on (nets.storage_bf16)
     pred_fake_pool = self.netD(torch.cat((input_label.detach(), fake.detach()), dim=1))
     loss_D_fake = nets.gan_loss(pred_fake_pool, False)
     pred_real = self.netD(torch.cat((input_label.detach(), real.detach()), dim=1))

@@ -29,6 +29,43 @@ VGG_LOSS_WEIGHTS = (1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0)  # networks.py:13
 
 
 # --------------------------------------------------------------------------- #
+# optional bf16-STORAGE emulation (no reference counterpart: SURVEY.md §2.2)
+# --------------------------------------------------------------------------- #
+# The product's bf16 mode stores every activation AND every activation gradient in bf16 (fp32
+# accumulation inside a kernel, fp32 weight gradients).  With `storage_bf16(True)` the oracle rounds at
+# the same points -- the output of every conv (pre-norm), of every norm+activation(+residual), of every
+# pool, and the gradients flowing back through those points -- and rounds the weights each conv sees,
+# so the GPU bf16 path has a like-for-like CPU yardstick instead of only a loose bound against fp32.
+class _RoundBF16(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+  @staticmethod
+  def backward(ctx, g):
+    return g.to(torch.bfloat16).to(g.dtype)
+
+
+_STORAGE_BF16 = [False]
+
+
+def storage_bf16(on):
+  _STORAGE_BF16[0] = bool(on)
+
+
+def q(x):
+  """Round an activation (and, in backward, its gradient) to bf16 storage when emulation is on."""
+  return _RoundBF16.apply(x) if _STORAGE_BF16[0] else x
+
+
+def qw(w):
+  """Weights as the packed bf16 GEMM panels see them; the fp32 master keeps the full gradient."""
+  if not _STORAGE_BF16[0]:
+    return w
+  return w + (w.detach().to(torch.bfloat16).to(w.dtype) - w.detach())
+
+
+# --------------------------------------------------------------------------- #
 # primitive layers
 # --------------------------------------------------------------------------- #
 def inorm(x):
@@ -37,15 +74,15 @@ def inorm(x):
 
 
 def conv_reflect(x, w, b, pad):
-  return F.conv2d(F.pad(x, (pad, pad, pad, pad), mode='reflect'), w, b)
+  return q(F.conv2d(F.pad(x, (pad, pad, pad, pad), mode='reflect'), qw(w), b))
 
 
 def resblock(sd, prefix, x):
   """x + IN(conv3(reflpad(ReLU(IN(conv3(reflpad(x)))))))   networks.py:271-305"""
   h = conv_reflect(x, sd[prefix + '.conv_block.1.weight'], sd[prefix + '.conv_block.1.bias'], 1)
-  h = F.relu(inorm(h))
+  h = q(F.relu(inorm(h)))
   h = conv_reflect(h, sd[prefix + '.conv_block.5.weight'], sd[prefix + '.conv_block.5.bias'], 1)
-  return x + inorm(h)
+  return q(x + inorm(h))
 
 
 # --------------------------------------------------------------------------- #
@@ -68,15 +105,15 @@ def global_trunk(sd, x, n_down, n_blocks, prefix='model'):
   """GlobalGenerator without its last [ReflPad3, Conv7, Tanh] (networks.py:153)."""
   first, down, res, up, _ = global_layout(n_down, n_blocks)
   p = lambda i, s: '%s.%d.%s' % (prefix, i, s)
-  h = F.relu(inorm(conv_reflect(x, sd[p(first, 'weight')], sd[p(first, 'bias')], 3)))
+  h = q(F.relu(inorm(conv_reflect(x, sd[p(first, 'weight')], sd[p(first, 'bias')], 3))))
   for i in down:
-    h = F.relu(inorm(F.conv2d(h, sd[p(i, 'weight')], sd[p(i, 'bias')], stride=2, padding=1)))
+    h = q(F.relu(inorm(q(F.conv2d(h, qw(sd[p(i, 'weight')]), sd[p(i, 'bias')], stride=2, padding=1)))))
   for i in res:
     h = resblock(sd, '%s.%d' % (prefix, i), h)
   for i in up:
-    h = F.conv_transpose2d(h, sd[p(i, 'weight')], sd[p(i, 'bias')],
-                           stride=2, padding=1, output_padding=1)
-    h = F.relu(inorm(h))
+    h = q(F.conv_transpose2d(h, qw(sd[p(i, 'weight')]), sd[p(i, 'bias')],
+                             stride=2, padding=1, output_padding=1))
+    h = q(F.relu(inorm(h)))
   return h
 
 
@@ -84,13 +121,13 @@ def global_generator(sd, x, n_down=4, n_blocks=9):
   """networks.py:249-251 (mode='get_continuous_img')."""
   last = global_layout(n_down, n_blocks)[4]
   h = global_trunk(sd, x, n_down, n_blocks)
-  h = conv_reflect(h, sd['model.%d.weight' % last], sd['model.%d.bias' % last], 3)
-  return torch.tanh(h)
+  h = F.conv2d(F.pad(h, (3, 3, 3, 3), mode='reflect'), qw(sd['model.%d.weight' % last]), sd['model.%d.bias' % last])
+  return q(torch.tanh(h))     # bias + tanh are fused in the conv epilogue: one rounding
 
 
 def avgpool3s2(x):
   """nn.AvgPool2d(3, stride=2, padding=[1,1], count_include_pad=False)  networks.py:180,387"""
-  return F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+  return q(F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False))
 
 
 def local_enhancer(sd, x, n_down=4, n_blocks=9, n_local=1, n_blocks_local=3):
@@ -102,19 +139,19 @@ def local_enhancer(sd, x, n_down=4, n_blocks=9, n_local=1, n_blocks_local=3):
   for n in range(1, n_local + 1):
     d, u = 'model%d_1' % n, 'model%d_2' % n
     xi = pyramid[n_local - n]
-    h = F.relu(inorm(conv_reflect(xi, sd[d + '.1.weight'], sd[d + '.1.bias'], 3)))
-    h = F.relu(inorm(F.conv2d(h, sd[d + '.4.weight'], sd[d + '.4.bias'], stride=2, padding=1)))
-    h = h + out
+    h = q(F.relu(inorm(conv_reflect(xi, sd[d + '.1.weight'], sd[d + '.1.bias'], 3))))
+    h = q(F.relu(inorm(q(F.conv2d(h, qw(sd[d + '.4.weight']), sd[d + '.4.bias'], stride=2, padding=1)))))
+    h = q(h + out)
     for b in range(n_blocks_local):
       h = resblock(sd, '%s.%d' % (u, b), h)
     k = n_blocks_local
-    h = F.conv_transpose2d(h, sd['%s.%d.weight' % (u, k)], sd['%s.%d.bias' % (u, k)],
-                           stride=2, padding=1, output_padding=1)
-    h = F.relu(inorm(h))
+    h = q(F.conv_transpose2d(h, qw(sd['%s.%d.weight' % (u, k)]), sd['%s.%d.bias' % (u, k)],
+                             stride=2, padding=1, output_padding=1))
+    h = q(F.relu(inorm(h)))
     out = h
     if n == n_local:
-      out = torch.tanh(conv_reflect(h, sd['%s.%d.weight' % (u, k + 4)],
-                                    sd['%s.%d.bias' % (u, k + 4)], 3))
+      out = q(torch.tanh(F.conv2d(F.pad(h, (3, 3, 3, 3), mode='reflect'),
+                                  qw(sd['%s.%d.weight' % (u, k + 4)]), sd['%s.%d.bias' % (u, k + 4)])))
   return out
 
 
@@ -137,11 +174,12 @@ def nlayer_d(sd, prefix, x, n_layers=3):
   for j in range(n_layers + 2):
     w, b = sd['%s_layer%d.0.weight' % (prefix, j)], sd['%s_layer%d.0.bias' % (prefix, j)]
     stride = 2 if j < n_layers else 1
-    h = F.conv2d(h, w, b, stride=stride, padding=2)
+    h = F.conv2d(h, qw(w), b, stride=stride, padding=2)
     if 0 < j <= n_layers:
-      h = inorm(h)
+      h = inorm(q(h))
     if j <= n_layers:
       h = F.leaky_relu(h, LRELU_SLOPE)
+    h = q(h)
     feats.append(h)
   return feats
 
@@ -167,7 +205,7 @@ def vgg19_features(sd, x):
     if item == 'M':
       h = F.max_pool2d(h, 2, 2)
       continue
-    h = F.relu(F.conv2d(h, sd['vgg.%d.weight' % ci], sd['vgg.%d.bias' % ci], padding=1))
+    h = q(F.relu(F.conv2d(h, qw(sd['vgg.%d.weight' % ci]), sd['vgg.%d.bias' % ci], padding=1)))
     if ci in VGG_TAPS:
       maps.append(h)
     ci += 1

@@ -139,3 +139,23 @@ def test_three_train_steps_local(golden_dir):
 
 def test_two_train_steps_full_width(golden_dir):
   _run_steps(golden_dir, 'step_global_ngf64_full')
+
+
+def test_bf16_storage_emulation_is_opt_in():
+  """nets.storage_bf16(False) (the default) must leave the pinned fp32 oracle untouched; when on,
+  every produced activation is bf16-representable and gradients still flow to the fp32 masters."""
+  cfg = dict(netG='global', ngf=8, n_downsample_global=2, n_blocks_global=1, n_local_enhancers=1, n_blocks_local=3)
+  torch.manual_seed(3)
+  sd = _leaf(nets.init_generator(cfg, 39, 3))
+  x = torch.rand(1, 39, 16, 32) - 0.5
+  y0 = nets.generator(sd, x, cfg)
+  nets.storage_bf16(True)
+  try:
+    y1 = nets.generator(sd, x, cfg)
+    y1.sum().backward()
+  finally:
+    nets.storage_bf16(False)
+  y2 = nets.generator(sd, x, cfg)
+  assert torch.equal(y0, y2)
+  assert torch.equal(y1, y1.to(torch.bfloat16).float()) and not torch.equal(y0, y1)
+  assert all(v.grad is not None and v.grad.dtype == torch.float32 for k, v in sd.items() if k.endswith('.weight'))
