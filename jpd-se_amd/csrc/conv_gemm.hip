@@ -1242,13 +1242,16 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   return rc;
 }
 
-template <int TM, int TN>
+static int g_wgrad_abl = 0;
+
+template <int WM, int WN, int TM, int TN, int ABL = 0>
 static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int lds = 2 * 64 * 2 * (BM + BN);
+  constexpr int blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<TM, TN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<WM, WN, TM, TN, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_fast: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
@@ -1260,7 +1263,7 @@ static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
   // per block, two blocks per CU.  A tile whose chunks all fall into one share is stored; a tile
   // straddling shares is accumulated with fp32 atomics into the zeroed gradient.
   const long long total = (long long)tiles * a.chunks_total;
-  long long nblocks = 512;
+  long long nblocks = 256 * blocks_per_cu;
   if (total < nblocks * 8) nblocks = (total + 7) / 8;
   if (nblocks < 1) nblocks = 1;
   a.iters_per_block = (int)((total + nblocks - 1) / nblocks);
@@ -1273,16 +1276,26 @@ static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
   }
   const int splits = 1;
   const int tiles_grid = (int)nblocks;
-  hipLaunchKernelGGL((wgrad_fast_kernel<TM, TN>), dim3(tiles_grid, splits), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, ABL>), dim3(tiles_grid, splits), dim3(64 * WM * WN), lds, s, a);
   return check_launch("wgrad_fast_kernel");
 }
 
 static int launch_wgrad_fast(const FastWgArgs& a, hipStream_t s) {
-  const bool m2 = a.Ks >= 128, n2 = (a.run_mode ? a.run_len : a.Cs) >= 128;
-  if (m2 && n2) return launch_wgrad_fast_cfg<2, 2>(a, s);
-  if (m2) return launch_wgrad_fast_cfg<2, 1>(a, s);
-  if (n2) return launch_wgrad_fast_cfg<1, 2>(a, s);
-  return launch_wgrad_fast_cfg<1, 1>(a, s);
+  const int cols = a.run_mode ? a.run_len : a.Cs;
+  const bool m2 = a.Ks >= 128, n2 = cols >= 128;
+  if (a.Ks >= 256 && cols >= 256 && a.Ks % 256 == 0 && cols % 256 == 0 && !a.run_mode) {
+    switch (g_wgrad_abl) {           // non-zero: timing-only ablations
+      case 1: return launch_wgrad_fast_cfg<2, 4, 4, 2, 1>(a, s);
+      case 4: return launch_wgrad_fast_cfg<2, 4, 4, 2, 4>(a, s);
+      case 15: return launch_wgrad_fast_cfg<2, 4, 4, 2, 15>(a, s);
+      case 32: break;                // 232: force the 128 x 128 tile (A/B)
+      default: return launch_wgrad_fast_cfg<2, 4, 4, 2>(a, s);     // 256 x 256, 8 waves
+    }
+  }
+  if (m2 && n2) return launch_wgrad_fast_cfg<2, 2, 2, 2>(a, s);
+  if (m2) return launch_wgrad_fast_cfg<2, 2, 2, 1>(a, s);
+  if (n2) return launch_wgrad_fast_cfg<2, 2, 1, 2>(a, s);
+  return launch_wgrad_fast_cfg<2, 2, 1, 1>(a, s);
 }
 
 template <typename T>
@@ -1405,7 +1418,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_fast_enabled = enable != 0;
   g_fast_variant = enable == 2 ? 1 : 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
-  g_halo_abl = enable >= 100 ? enable - 100 : 0;   // 100+bits: halo kernel timing ablations (wrong results)
+  g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
+  g_wgrad_abl = enable >= 200 ? enable - 200 : 0;   // 200+bits: fast wgrad timing ablations   // 100+bits: halo kernel timing ablations (wrong results)
   return JPDSE_OK;
 }
 

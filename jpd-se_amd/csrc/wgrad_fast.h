@@ -37,7 +37,7 @@ struct FastWgArgs {
 };
 
 template <int ROWB> __device__ __forceinline__ int trswz(int pix) {
-  return ROWB == 256 ? ((pix & 3) << 2) : (((pix >> 1) & 1) << 2);
+  return ROWB >= 256 ? ((pix & 3) << 2) : (((pix >> 1) & 1) << 2);
 }
 
 __device__ __forceinline__ s16x8 tr_frag(const char* p, int row4_bytes) {
@@ -46,22 +46,30 @@ __device__ __forceinline__ s16x8 tr_frag(const char* p, int row4_bytes) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// TM, TN in {1,2}: tile = (64*TM) k-channels x (64*TN) c-channels; 4 waves as 2x2, wave tile 32*TM x 32*TN
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
+// Tile = (WM*TM*32) k-channels x (WN*TN*32) c-channels, WM x WN waves, wave tile 32*TM x 32*TN.
+//   <2,2,TM,TN>  64..128 square-ish tiles, 4 waves, 2 blocks per CU (small layers)
+//   <2,4,4,2>    256 x 256, 8 waves, 1 block per CU: 2x the FLOPs per staged byte -- the kernel is bound
+//                by the L2->LDS fill (ablation: no DMA => 2.2x), and the stream-K partition keeps the
+//                256 CUs evenly loaded whatever the tile count.
+// ABL: timing-only ablation bits (wrong results when non-zero): 1 = no DMA after the first chunk,
+// 2 = no barrier, 4 = fragments read once per chunk, 8 = no vmcnt waits
+template <int WM, int WN, int TM, int TN, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_fast_kernel(const FastWgArgs a) {
+  constexpr int NW = WM * WN;
   constexpr int BKP = 64;                         // pixels per chunk
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A_ROWB = BM * 2, B_ROWB = BN * 2; // 128 or 256 bytes per pixel row
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_ROWB = BM * 2, B_ROWB = BN * 2; // 128, 256 or 512 bytes per pixel row
   constexpr int A_STAGE = BKP * A_ROWB, B_STAGE = BKP * B_ROWB;
   constexpr int STAGE = A_STAGE + B_STAGE;
   constexpr int A_PPU = 1024 / A_ROWB, B_PPU = 1024 / B_ROWB;   // pixels per 1 KiB DMA unit
   constexpr int A_UNITS = BKP / A_PPU, B_UNITS = BKP / B_PPU;
-  constexpr int AU = A_UNITS / 4, BU = B_UNITS / 4;             // per wave
+  constexpr int AU = A_UNITS / NW, BU = B_UNITS / NW;           // per wave
+  static_assert(A_UNITS % NW == 0 && B_UNITS % NW == 0, "DMA units must divide evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
 
   const int c_tiles = ((a.run_mode ? a.run_len : a.Cs) + BN - 1) / BN;
   const int n_taps = a.run_mode ? a.R : a.R * a.S;
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
   int a_pix[AU], a_soff[AU], a_lds[AU];
 #pragma unroll
   for (int i = 0; i < AU; ++i) {
-    const int u = wid + 4 * i;
+    const int u = wid + NW * i;
     const int pl = lane / (A_ROWB / 16), slot = lane % (A_ROWB / 16);
     const int pix = u * A_PPU + pl;
     a_pix[i] = pix;
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
   int bn[BU], boh[BU], bow[BU];                          // cursor of the unit's pixel: (n, oh, ow)
 #pragma unroll
   for (int i = 0; i < BU; ++i) {
-    const int u = wid + 4 * i;
+    const int u = wid + NW * i;
     const int pl = lane / (B_ROWB / 16), slot = lane % (B_ROWB / 16);
     const int pix = u * B_PPU + pl;
     b_pix[i] = pix;
@@ -188,16 +196,17 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   for (int c = ch_begin; c < ch_end; ++c) {
-    if (c + 1 < ch_end) issue(stage ^ 1);
+    if (c + 1 < ch_end && !(ABL & 1)) issue(stage ^ 1);
     const char* const st = smem + stage * STAGE;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < BKP / 16; ++ks) {
       s16x8 af[TM], bf[TN];
+      const int ks_r = (ABL & 4) ? 0 : ks;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = tr_frag(st + a_tr[i] + ks * 16 * A_ROWB, 4 * A_ROWB);
+      for (int i = 0; i < TM; ++i) af[i] = tr_frag(st + a_tr[i] + ks_r * 16 * A_ROWB, 4 * A_ROWB);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = tr_frag(st + b_tr[j] + ks * 16 * B_ROWB, 4 * B_ROWB);
+      for (int j = 0; j < TN; ++j) bf[j] = tr_frag(st + b_tr[j] + ks_r * 16 * B_ROWB, 4 * B_ROWB);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -205,8 +214,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const FastWgArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    if (!(ABL & 8)) wait_vmcnt<0>();
+    if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
     stage ^= 1;
   }
 
