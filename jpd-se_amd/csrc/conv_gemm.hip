@@ -899,7 +899,7 @@ static int g_fast_variant = 0;   // A/B (scripts/bench_conv.py): the simple sche
 template <int WM, int WN, int TM, int TN, int VAR, int STAGES = 3>
 static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int lds = STAGES * 2 * (BM + BN) * 64;
+  constexpr int lds = STAGES * (BM + BN) * 128;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<WM, WN, TM, TN, VAR, STAGES>),
@@ -970,8 +970,8 @@ static int g_halo_abl = 0;
 template <int TN, int ABL = 0>
 static int launch_halo_cfg(const HaloArgs& a, hipStream_t s) {
   constexpr int BN = 2 * TN * 32;
-  constexpr int UH = ((4 + 2) * (64 + 2) + 15) / 16;
-  constexpr int lds = 2 * 2 * UH * 1024 + 3 * 2 * BN * 64;
+  constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
+  constexpr int lds = 2 * UH * 1024 + 3 * BN * 128;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL>),

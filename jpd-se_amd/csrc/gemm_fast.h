@@ -41,13 +41,18 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS tile [rows][128 B] (one row = 64 bf16 of K): the eight 16-byte slots of a row are XOR-swizzled
+// with (row >> 1) & 7, which makes ds_read_b128 conflict free (rows of equal parity in a 16-lane read
+// group get distinct slots) while every DMA instruction moves 8 FULL 128-byte lines (fragment-shaped
+// 64-byte pieces cost 12-28 %: cdna_hip_programming.md, "x through LDS in full 128-B lines").
+__device__ __forceinline__ int swz128(int row, int slot) { return (row << 7) + (((slot ^ (row >> 1)) & 7) << 4); }
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// VAR selects the inner-loop schedule (A/B-able in one process via jpdse_debug_set_fast_path):
-//   0: DMA issue right after the barrier, then 4 x {4 ds_read_b128, 4 MFMA}
-//   1: fragment reads of k-step g+1 requested before the MFMAs of step g, DMA issued behind group 0
+// VAR is kept as an A/B hook (a software-pipelined fragment schedule was measured 2-3 % SLOWER than the
+// plain one in the same process and removed).
 // STAGES = 3: ring with one tile in flight across the barrier (counted vmcnt).  STAGES = 2 (used by
 // the 320-row tile, whose 3-stage ring would not fit 160 KiB): next tile issued right after the barrier,
 // vmcnt(0) at the following one.
@@ -55,10 +60,9 @@ template <int WM, int WN, int TM, int TN, int VAR, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs a) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int A_HALF = BM * 64, B_HALF = BN * 64;
-  constexpr int STAGE_BYTES = 2 * (A_HALF + B_HALF);
-  constexpr int A_RG = BM / 16, B_RG = BN / 16;     // 16-row groups per half
-  constexpr int A_UNITS = 2 * A_RG, B_UNITS = 2 * B_RG;
+  constexpr int A_TILE = BM * 128, B_TILE = BN * 128;
+  constexpr int STAGE_BYTES = A_TILE + B_TILE;
+  constexpr int A_UNITS = BM / 8, B_UNITS = BN / 8;   // 1 KiB DMA units: 8 rows x 128 B
   constexpr int AU = (A_UNITS + NW - 1) / NW, BU = (B_UNITS + NW - 1) / NW;
   static_assert(A_UNITS % NW == 0, "every wave stages the same number of A units");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs 
   const int tiles_m = (a.M + BM - 1) / BM;
   const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int lrow = lane >> 2, lslot = lane & 3;
+  const int lrow = lane >> 3, lslot = lane & 7;
 
   // ---- per-unit staging state -------------------------------------------------------------
   long long a_nbase[AU];
@@ -77,16 +81,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs 
 #pragma unroll
   for (int i = 0; i < AU; ++i) {
     const int u = wid + i * NW;
-    const int half = u / A_RG, rg = u % A_RG;
-    const int row = rg * 16 + lrow;
+    const int row = u * 8 + lrow;
     int m = m0 + row;
     m = m < a.M ? m : a.M - 1;
     const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
     a_nbase[i] = (long long)n * a.IH * a.IW * a.Cs;
     a_oh[i] = oh * a.sy - a.py;
     a_ow[i] = ow * a.sx - a.px;
-    a_choff[i] = half * 32 + ((lslot ^ (row >> 3)) & 3) * 8;
-    a_lds[i] = half * A_HALF + rg * 1024;
+    a_choff[i] = ((lslot ^ (row >> 1)) & 7) * 8;
+    a_lds[i] = u * 1024;
   }
   const bf16_t* b_ptr[BU];
   int b_lds[BU];
@@ -97,32 +100,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs 
     const int u = wid + j * NW;
     b_on[j] = u < B_UNITS;
     const int uu = b_on[j] ? u : 0;
-    const int half = uu / B_RG, rg = uu % B_RG;
-    const int row = rg * 16 + lrow;
+    const int row = uu * 8 + lrow;
     int br = n0 + row;
     br = br < a.b_rows ? br : a.b_rows - 1;
-    b_ptr[j] = a.B + (long long)br * ktot + half * 32 + ((lslot ^ (row >> 3)) & 3) * 8;
-    b_lds[j] = 2 * A_HALF + half * B_HALF + rg * 1024;
+    b_ptr[j] = a.B + (long long)br * ktot + ((lslot ^ (row >> 1)) & 7) * 8;
+    b_lds[j] = A_TILE + uu * 1024;
   }
   int n_b = 0;
 #pragma unroll
   for (int j = 0; j < BU; ++j) n_b += b_on[j] ? 1 : 0;   // wave-uniform
   const int LW = AU + n_b;                               // DMA instructions per wave per K-tile
 
-  int a_rd[TM][2], b_rd[TN][2];
+  int a_rd[TM][4], b_rd[TN][4];       // byte offset of the lane's fragment for each of the 4 k16-steps
   {
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wm * TM * 32 + i * 32 + r;
-      a_rd[i][0] = swz(row, h);
-      a_rd[i][1] = swz(row, 2 + h);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a_rd[i][ks] = swz128(row, 2 * ks + h);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = wn * TN * 32 + j * 32 + r;
-      b_rd[j][0] = 2 * A_HALF + swz(row, h);
-      b_rd[j][1] = 2 * A_HALF + swz(row, 2 + h);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) b_rd[j][ks] = A_TILE + swz128(row, 2 * ks + h);
     }
   }
 
@@ -191,52 +193,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs 
     }
     __builtin_amdgcn_s_barrier();
     const char* const st = smem + cstage * STAGE_BYTES;
-    if constexpr (VAR == 0) {
-      if (t + AHEAD < T_total) issue();
-      __builtin_amdgcn_s_setprio(1);
+    if (t + AHEAD < T_total) issue();
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
+    for (int ks = 0; ks < 4; ++ks) {
+      s16x8 af[TM], bf[TN];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          s16x8 af[TM], bf[TN];
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(st + a_rd[i][ks]);
 #pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(st + hh * A_HALF + a_rd[i][u]);
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + b_rd[j][ks]);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + hh * B_HALF + b_rd[j][u]);
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-    } else {
-      s16x8 af[2][TM], bf[2][TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const s16x8*>(st + a_rd[i][0]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const s16x8*>(st + b_rd[j][0]);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cur = g & 1, nxt = cur ^ 1;
-        if (g < 3) {
-          const int hh = (g + 1) >> 1, u = (g + 1) & 1;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const s16x8*>(st + hh * A_HALF + a_rd[i][u]);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const s16x8*>(st + hh * B_HALF + b_rd[j][u]);
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (g == 0 && t + AHEAD < T_total) issue();
-      }
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     cstage = cstage == STAGES - 1 ? 0 : cstage + 1;
   }
 

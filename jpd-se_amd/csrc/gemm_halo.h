@@ -6,7 +6,7 @@
 // fill per 1024 MFMA cycles, above what one CU's LDS-DMA path sustains (~70 GB/s, MI355X_MICROARCH.md
 // "Indexed rows: gather into LDS").  2/3 of that fill is the activation tile, and for a 3x3 filter
 // the nine taps read the SAME pixels shifted by one.  Here a block owns a TH x 64 output patch of one
-// image: per 64-channel slab it stages the (TH+2) x 66 input patch ONCE (padding resolved while
+// image: per 64-channel slab it stages the (TH+2) x 66 input patch ONCE (rows of 128 B = full lines) (padding resolved while
 // loading), then loops over the 9 taps streaming only the 16 KiB weight tile; the A fragments are
 // read from the patch at tap-shifted addresses.  Fill traffic per tap: 21.6 KiB instead of 48 KiB.
 //
@@ -41,11 +41,11 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   static_assert(TH == 4, "8 waves = 4 image rows x 2 channel halves");
   constexpr int BN = WN * TN * 32;
   constexpr int PH = TH + R - 1, PW = 64 + S - 1, NP = PH * PW;
-  constexpr int UH = (NP + 15) / 16;                  // 1 KiB DMA units per 32-channel half of the patch
-  constexpr int HALO_HALF = UH * 1024, HALO = 2 * HALO_HALF;
-  constexpr int B_HALF = BN * 64, B_STAGE = 2 * B_HALF;
-  constexpr int B_RG = BN / 16, B_UNITS = 2 * B_RG, BU = (B_UNITS + NW - 1) / NW;
-  constexpr int HU = (2 * UH + NW - 1) / NW;          // patch units per wave (7 for 50 units / 8 waves)
+  constexpr int UH = (NP + 7) / 8;                    // 1 KiB DMA units of the patch: 8 pixels x 128 B (64 channels)
+  constexpr int HALO = UH * 1024;
+  constexpr int B_STAGE = BN * 128;
+  constexpr int B_UNITS = BN / 8, BU = (B_UNITS + NW - 1) / NW;
+  constexpr int HU = (UH + NW - 1) / NW;              // patch units per wave (7 for 50 units / 8 waves)
   static_assert(HU <= TAPS - 2, "patch units of the next slab are spread over taps 0..HU-1");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo0 = smem;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   const int tw_i = tile_m % tiles_w, t1 = tile_m / tiles_w;
   const int th_i = t1 % tiles_h, n = t1 / tiles_h;
   const int oh0 = th_i * TH, ow0 = tw_i * 64, n0 = tile_n * BN;
-  const int lrow = lane >> 2, lslot = lane & 3;
+  const int lrow = lane >> 3, lslot = lane & 7;
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
   // ---- patch DMA units of this wave: element offset of the lane's 16 bytes (slab 0), or -1 -> zero page
@@ -70,11 +70,10 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
 #pragma unroll
   for (int i = 0; i < HU; ++i) {
     const int u = wid + i * NW;
-    const bool on = u < 2 * UH;
+    const bool on = u < UH;
     n_hu += on ? 1 : 0;
-    const int uu = on ? u : 0;
-    const int half = uu / UH, ug = uu % UH;
-    int p = ug * 16 + lrow;
+    const int ug = on ? u : 0;
+    int p = ug * 8 + lrow;
     const int swz_p = p;                              // the swizzle uses the LDS pixel index, also for clamped lanes
     p = p < NP ? p : NP - 1;
     const int hr = p / PW, wc = p - hr * PW;
@@ -86,9 +85,9 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     } else {
       ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
     }
-    const int chunk = (lslot ^ (swz_p >> 3)) & 3;
-    h_off[i] = ok ? (((long long)n * a.IH + ih) * a.IW + iw) * a.Cs + half * 32 + chunk * 8 : -1;
-    h_lds[i] = half * HALO_HALF + ug * 1024;
+    const int chunk = (lslot ^ (swz_p >> 1)) & 7;
+    h_off[i] = ok ? (((long long)n * a.IH + ih) * a.IW + iw) * a.Cs + chunk * 8 : -1;
+    h_lds[i] = ug * 1024;
   }
   // ---- weight tile DMA units
   const bf16_t* b_ptr[BU];
@@ -100,12 +99,11 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     const int u = wid + j * NW;
     b_on[j] = u < B_UNITS;
     const int uu = b_on[j] ? u : 0;
-    const int half = uu / B_RG, rg = uu % B_RG;
-    const int row = rg * 16 + lrow;
+    const int row = uu * 8 + lrow;
     int br = n0 + row;
     br = br < a.b_rows ? br : a.b_rows - 1;
-    b_ptr[j] = a.B + (long long)br * ktot + half * 32 + ((lslot ^ (row >> 3)) & 3) * 8;
-    b_lds[j] = half * B_HALF + rg * 1024;
+    b_ptr[j] = a.B + (long long)br * ktot + ((lslot ^ (row >> 1)) & 7) * 8;
+    b_lds[j] = uu * 1024;
   }
   int n_b = 0;
 #pragma unroll
@@ -116,12 +114,12 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) pb[i] = wm * PW + i * 32 + (lane & 31);
   const int hsel = lane >> 5;
-  int b_rd[TN][2];
+  int b_rd[TN][4];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int row = wn * TN * 32 + j * 32 + (lane & 31);
-    b_rd[j][0] = swz(row, hsel);
-    b_rd[j][1] = swz(row, 2 + hsel);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b_rd[j][ks] = swz128(row, 2 * ks + hsel);
   }
 
   f32x16 acc[2][TN];
@@ -192,27 +190,24 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pt = pb[i] + tapoff;
-      a_base[i] = pt << 6;
-      a_sw[i] = ((pt >> 3) & 3) << 4;
+      a_base[i] = pt << 7;
+      a_sw[i] = ((pt >> 1) & 7) << 4;
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int ks = 0; ks < 4; ++ks) {
+      s16x8 af[2], bf[TN];
+      const int ks_r = (ABL & 4) ? 0 : ks;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        s16x8 af[2], bf[TN];
-        const int hh_r = (ABL & 4) ? 0 : hh, u_r = (ABL & 4) ? 0 : u;
+      for (int i = 0; i < 2; ++i)
+        af[i] = *reinterpret_cast<const s16x8*>(hb + a_base[i] + (((2 * ks_r + hsel) << 4) ^ a_sw[i]));
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          af[i] = *reinterpret_cast<const s16x8*>(hb + hh_r * HALO_HALF + a_base[i] + ((((2 * u_r + hsel) << 4)) ^ a_sw[i]));
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + b_rd[j][ks_r]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + hh_r * B_HALF + b_rd[j][u_r]);
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
     if (++tap == TAPS) { tap = 0; ++slab; }
