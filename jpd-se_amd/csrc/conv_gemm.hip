@@ -897,7 +897,7 @@ static int launch_wgrad(const GemmWgradArgs& a, hipStream_t s) {
 static int g_fast_variant = 0;   // A/B (scripts/bench_conv.py): the simple schedule is as fast or faster
 
 template <int WM, int WN, int TM, int TN, int VAR, int STAGES = 3>
-static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
+static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int lds = STAGES * (BM + BN) * 128;
   static bool configured = false;
@@ -907,15 +907,23 @@ static int launch_fast_cfg(const FastArgs& a, hipStream_t s) {
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_fast: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
   }
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Ks + BN - 1) / BN;
-  const long long kdim = (long long)a.R * a.S * a.Cs;
-  const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
-                     (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
+  int total = 0;
+  double flops = 0.0;
+  bool timed = g_prof.on && (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
+  for (int i = 0; i < b.n; ++i) {
+    const FastArgs& a = b.p[i];
+    b.first_tile[i] = total;
+    total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN);
+    const long long kdim = (long long)a.R * a.S * a.Cs;
+    flops += 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
+    timed = timed && b.n == 1 && a.Ks == g_prof.Ks && kdim == g_prof.kdim;
+  }
+  for (int i = b.n; i < 5; ++i) b.first_tile[i] = total;
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN, VAR, STAGES>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN, VAR, STAGES>), dim3(total), dim3(64 * WM * WN), lds, s, b);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
-    g_prof.flops[g_prof.used] = 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
+    g_prof.flops[g_prof.used] = flops;
     ++g_prof.used;
   }
   return check_launch("gemm_fast_kernel");
@@ -931,17 +939,21 @@ static bool prefer_320(int M, int Ks) {
   return c320 < c256;
 }
 
-template <int VAR>
-static int launch_fast_v(const FastArgs& a, hipStream_t s) {
-  if (prefer_320(a.M, a.Ks)) return launch_fast_cfg<2, 4, 5, 1, VAR, 2>(a, s);   // 320 x 128, 2 stages
-  if (a.Ks > 64) return launch_fast_cfg<4, 2, 2, 2, VAR>(a, s);   // 256 x 128
-  if (a.Ks > 32) return launch_fast_cfg<4, 2, 2, 1, VAR>(a, s);   // 256 x 64
-  return launch_fast_cfg<8, 1, 1, 1, VAR>(a, s);                  // 256 x 32
+static int launch_fast_batch(FastBatch& b, hipStream_t s) {
+  if (b.n <= 0) return JPDSE_OK;
+  const int Ks = b.p[0].Ks;
+  if (b.n == 1 && prefer_320(b.p[0].M, Ks)) return launch_fast_cfg<2, 4, 5, 1, 0, 2>(b, s);   // 320 x 128, 2 stages
+  if (Ks > 64) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // 256 x 128
+  if (Ks > 32) return launch_fast_cfg<4, 2, 2, 1, 0>(b, s);   // 256 x 64
+  return launch_fast_cfg<8, 1, 1, 1, 0>(b, s);                // 256 x 32
 }
 
 static int launch_fast(const FastArgs& a, hipStream_t s) {
   if (a.M <= 0) return JPDSE_OK;
-  return g_fast_variant == 0 ? launch_fast_v<0>(a, s) : launch_fast_v<1>(a, s);
+  FastBatch b = {};
+  b.p[0] = a;
+  b.n = 1;
+  return launch_fast_batch(b, s);
 }
 
 static bool g_fast_enabled = true;   // jpdse_debug_set_fast_path(0) forces the generic kernels (A/B tests)
@@ -1141,11 +1153,24 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   }
   bool fast = false;
   if constexpr (sizeof(T) == 2) {
+    // all stride phases go into ONE launch of the fast kernel: judge the merged grid
     fast = p.Ks % 64 == 0;
-    for (int i = 0; i < p.nph && fast; ++i)
-      if (p.ph[i].cnth > 0 && p.ph[i].cntw > 0)
-        fast = fast_pays(d->N * p.ph[i].cnth * p.ph[i].cntw, p.Cs, p.ph[i].Uh * p.ph[i].Uw * p.Ks / 64);
+    long long tiles = 0;
+    int kt_max = 0, nlive = 0, m_single = 0;
+    const int bn = p.Cs > 64 ? 128 : (p.Cs > 32 ? 64 : 32);
+    for (int i = 0; i < p.nph; ++i) {
+      if (p.ph[i].cnth <= 0 || p.ph[i].cntw <= 0) continue;
+      const int Mi = d->N * p.ph[i].cnth * p.ph[i].cntw;
+      tiles += (long long)((Mi + 255) / 256) * ((p.Cs + bn - 1) / bn);
+      const int kt = p.ph[i].Uh * p.ph[i].Uw * p.Ks / 64;
+      kt_max = kt > kt_max ? kt : kt_max;
+      m_single = Mi;
+      ++nlive;
+    }
+    if (nlive == 1) fast = fast && fast_pays(m_single, p.Cs, kt_max);
+    else fast = fast && g_fast_enabled && p.Cs > 32 && kt_max >= 16 && tiles >= 384;   // short K loops: generic wins
   }
+  FastBatch batch = {};
   int rc = JPDSE_OK;
   if (!fast) {
     rc = launch_pad<T>(dy, dyp, d->N, p.OH, p.OW, p.Ks, p.PT, p.PB, p.PL, p.PR, JPDSE_PAD_ZERO, s);
@@ -1190,8 +1215,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         }
         g.act = JPDSE_ACT_NONE;
         g.slope = 0.f;
-        rc = launch_fast(g, s);
-        if (rc) return rc;
+        batch.p[batch.n++] = g;
         continue;
       }
     }
@@ -1229,6 +1253,10 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     a.act = JPDSE_ACT_NONE;
     a.slope = 0.f;
     rc = launch_fwd<T>(a, s);
+    if (rc) return rc;
+  }
+  if (batch.n > 0) {
+    rc = launch_fast_batch(batch, s);
     if (rc) return rc;
   }
   if (refl) {
@@ -1416,7 +1444,6 @@ int jpdse_conv_out_shape(const jpdse_conv_desc* d, int32_t* OH, int32_t* OW) {
 int jpdse_debug_set_fast_path(int32_t enable) {
   // 0: generic kernels only; 1: fast kernels (default schedule 0); 2: fast kernels, alternative schedule 1
   g_fast_enabled = enable != 0;
-  g_fast_variant = enable == 2 ? 1 : 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_wgrad_abl = enable >= 200 ? enable - 200 : 0;   // 200+bits: fast wgrad timing ablations   // 100+bits: halo kernel timing ablations (wrong results)

@@ -36,6 +36,14 @@ struct FastArgs {
   float slope;
 };
 
+// Up to 4 independent problems in one launch (the stride-2 sub-pixel phases of a data gradient /
+// ConvTranspose2d forward): block b belongs to problem q with first_tile[q] <= b < first_tile[q+1].
+struct FastBatch {
+  FastArgs p[4];
+  int first_tile[5];
+  int n;
+};
+
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -57,7 +65,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // the 320-row tile, whose 3-stage ring would not fit 160 KiB): next tile issued right after the barrier,
 // vmcnt(0) at the following one.
 template <int WM, int WN, int TM, int TN, int VAR, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch batch) {
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < batch.n && (int)blockIdx.x >= batch.first_tile[i]) q = i;
+  const FastArgs& a = batch.p[q];
+  const int block_id = (int)blockIdx.x - batch.first_tile[q];
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_TILE = BM * 128, B_TILE = BN * 128;
@@ -71,7 +85,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastArgs 
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
   const int tiles_m = (a.M + BM - 1) / BM;
-  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+  const int tile_m = block_id % tiles_m, tile_n = block_id / tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int lrow = lane >> 3, lslot = lane & 7;
 
