@@ -47,6 +47,9 @@ def parse():
   ap.add_argument('--batch', type=int, default=4, help='images per GPU')
   ap.add_argument('--netG', default='global', choices=['global', 'local'])
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+  ap.add_argument('--no-vgg', action='store_true',
+                  help='BASELINE config 2: GlobalGenerator + 2-scale PatchGAN step without the VGG loss '
+                       '(no_vgg_loss + skip_unused_losses: VGG is not run at all)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   return ap.parse_args()
 
@@ -55,6 +58,8 @@ def make_opt(args, device_index):
   from oracle.ctu_cpu.model import default_opt     # only the opt namespace (field list), no compute
   kw = dict(gpu_ids=[device_index], print_losses=False, compute_dtype=args.dtype, use_compressed=True,
             netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch)
+  if args.no_vgg:
+    kw.update(no_vgg_loss=True, skip_unused_losses=True)
   return default_opt(**kw)
 
 
@@ -145,6 +150,8 @@ def main():
                   avg_launch_ms=round(ms.value / n.value, 4),
                   flops_per_launch=fl.value / n.value)
     f_alg = F_ALG_GFLOP.get((args.netG, args.width, args.height))
+    if args.no_vgg and f_alg:      # minus VGG's 3 passes (2 fwd + 1 dgrad), SURVEY.md 8d config 2
+      f_alg = round(f_alg - 6 * 189.4 * (args.width * args.height) / (1024.0 * 512.0), 1)
     out = {
         'metric': 'training images/sec at 1024x512 (G+D+VGG step)' if (args.width, args.height) == (1024, 512)
                   else 'training images/sec at %dx%d (G+D+VGG step)' % (args.width, args.height),
@@ -152,8 +159,9 @@ def main():
         'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
         'data': 'synthetic',
-        'config': {'workload': 'JPD-SE train step %dx%d, netG=%s ngf=%d (39-ch input), num_D=2, VGG19+feat+L1, '
-                               'Adam x2, batch %d/GPU' % (args.width, args.height, args.netG, opt.ngf, args.batch),
+        'config': {'workload': 'JPD-SE train step %dx%d, netG=%s ngf=%d (39-ch input), num_D=2, %sfeat+L1, '
+                               'Adam x2, batch %d/GPU' % (args.width, args.height, args.netG, opt.ngf,
+                                                          '' if args.no_vgg else 'VGG19+', args.batch),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                    'step_mfma_frac': (round(f_alg * value / 1e3 / peak, 4) if f_alg else None),
                    'f_alg_gflop_per_image': f_alg},

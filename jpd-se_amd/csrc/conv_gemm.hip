@@ -750,6 +750,7 @@ struct ConvPlan {
   int DH, DW;          // padded dy dims
   size_t dgrad_pack_bytes;
   size_t xpad_bytes, dypad_bytes, dxp_bytes;
+  size_t splitk_off, splitk_bytes;   // fp32 partial slabs of the split-K fast path (behind the other regions)
 };
 
 static void phase_axis(int st, int q, int Rf, int lo, int hi, int& U, int& i0, int& cnt) {
@@ -759,6 +760,18 @@ static void phase_axis(int st, int q, int Rf, int lo, int hi, int& U, int& i0, i
   const int i1 = ceil_div(hi - q, st);
   cnt = i1 - i0;
   if (cnt < 0) cnt = 0;
+}
+
+// Split-K factor of the fast 256x128 kernel for a GEMM of M rows, Ks output channels and k_tiles
+// 64-wide K-tiles: only when the tiles alone would leave most of the 256 CUs idle.
+static int splitk_for(int M, int Ks, int k_tiles) {
+  if (Ks <= 64 || k_tiles < 32 || M <= 0) return 1;
+  const long long tiles = (long long)((M + 255) / 256) * ((Ks + 127) / 128);
+  if (tiles > 128) return 1;
+  int sp = (int)(256 / tiles);
+  if (sp > k_tiles / 16) sp = k_tiles / 16;
+  if (sp > 8) sp = 8;
+  return sp < 2 ? 1 : sp;
 }
 
 static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
@@ -806,6 +819,19 @@ static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
   p->xpad_bytes = align_up((size_t)d->N * p->Hp * p->Wp * p->Cs * p->ES + kSlackBytes, 256);
   p->dypad_bytes = align_up((size_t)d->N * p->DH * p->DW * p->Ks * p->ES + kSlackBytes, 256);
   p->dxp_bytes = refl ? align_up((size_t)d->N * p->Hp * p->Wp * p->Cs * p->ES, 256) : 0;
+  p->splitk_off = p->xpad_bytes > p->dypad_bytes + p->dxp_bytes ? p->xpad_bytes : p->dypad_bytes + p->dxp_bytes;
+  p->splitk_bytes = 0;
+  if (p->ES == 2) {
+    const int sf = splitk_for(d->N * p->OH * p->OW, p->Ks, d->R * d->S * p->Cs / 64);
+    const size_t fwd = sf > 1 ? (size_t)sf * d->N * p->OH * p->OW * p->Ks * 4 : 0;
+    size_t dgr = 0;
+    if (p->nph == 1 && p->ph[0].cnth > 0 && p->ph[0].cntw > 0) {
+      const int Md = d->N * p->ph[0].cnth * p->ph[0].cntw;
+      const int sd = splitk_for(Md, p->Cs, p->ph[0].Uh * p->ph[0].Uw * p->Ks / 64);
+      dgr = sd > 1 ? (size_t)sd * Md * p->Cs * 4 : 0;
+    }
+    p->splitk_bytes = align_up(fwd > dgr ? fwd : dgr, 256);
+  }
 }
 
 template <typename T>
@@ -913,7 +939,7 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   for (int i = 0; i < b.n; ++i) {
     const FastArgs& a = b.p[i];
     b.first_tile[i] = total;
-    total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN);
+    total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN) * (a.splits > 1 ? a.splits : 1);
     const long long kdim = (long long)a.R * a.S * a.Cs;
     flops += 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
     timed = timed && b.n == 1 && a.Ks == g_prof.Ks && kdim == g_prof.kdim;
@@ -921,6 +947,10 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   for (int i = b.n; i < 5; ++i) b.first_tile[i] = total;
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
   hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN, VAR, STAGES>), dim3(total), dim3(64 * WM * WN), lds, s, b);
+  if (b.n == 1 && b.p[0].splits > 1) {
+    const long long total_vec = (long long)b.p[0].M * (b.p[0].Ks / 8);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(ew_blocks(total_vec)), dim3(256), 0, s, b.p[0], total_vec);
+  }
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = flops;
@@ -942,6 +972,9 @@ static bool prefer_320(int M, int Ks) {
 static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   if (b.n <= 0) return JPDSE_OK;
   const int Ks = b.p[0].Ks;
+  if (b.n == 1 && b.p[0].splits > 1) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // split-K: 256 x 128 only
+  for (int i = 0; i < b.n; ++i)
+    if (b.n > 1) b.p[i].splits = 1;
   if (b.n == 1 && prefer_320(b.p[0].M, Ks)) return launch_fast_cfg<2, 4, 5, 1, 0, 2>(b, s);   // 320 x 128, 2 stages
   if (Ks > 64) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // 256 x 128
   if (Ks > 32) return launch_fast_cfg<4, 2, 2, 1, 0>(b, s);   // 256 x 64
@@ -967,6 +1000,7 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
   if (!g_fast_enabled) return false;
   if (k_tiles < 8) return false;   // short reductions (stride-2 sub-pixel phases of 2x2 taps x 64 ch) do not fill the 3-stage ring
   if (Ks <= 32) return false;   // measured: the generic 256x32 kernel beats the 8-wave 256x32 fast config
+  if (splitk_for(M, Ks, k_tiles) > 1) return true;
   const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32);
   const long long tiles = (long long)((M + 255) / 256) * ((Ks + bn - 1) / bn);
   if (prefer_320(M, Ks)) {
@@ -1079,6 +1113,8 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       f.out_base = 0;
       f.act = d->act;
       f.slope = d->slope;
+      f.splits = splitk_for(f.M, p.Ks, d->R * d->S * p.Cs / 64);
+      f.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + p.splitk_off);
       return launch_fast(f, s);
     }
   }
@@ -1152,6 +1188,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     }
   }
   bool fast = false;
+  int nlive_phases = 0;
   if constexpr (sizeof(T) == 2) {
     // all stride phases go into ONE launch of the fast kernel: judge the merged grid
     fast = p.Ks % 64 == 0;
@@ -1167,6 +1204,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       m_single = Mi;
       ++nlive;
     }
+    nlive_phases = nlive;
     if (nlive == 1) fast = fast && fast_pays(m_single, p.Cs, kt_max);
     else fast = fast && g_fast_enabled && p.Cs > 32 && kt_max >= 16 && tiles >= 384;   // short K loops: generic wins
   }
@@ -1215,6 +1253,8 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         }
         g.act = JPDSE_ACT_NONE;
         g.slope = 0.f;
+        g.splits = nlive_phases == 1 ? splitk_for(g.M, p.Cs, f.Uh * f.Uw * p.Ks / 64) : 1;
+        g.partial = reinterpret_cast<float*>(wsb + p.splitk_off);
         batch.p[batch.n++] = g;
         continue;
       }
@@ -1528,7 +1568,9 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   const size_t dz = (p.Ks == 8 && kexp_s <= 256) ? align_up((size_t)d->N * p.Hp * p.Wp * kexp_s * 2, 256) : 0;
   const size_t fwd = p.xpad_bytes + dz;     // wgrad: padded x (+ tap-expanded dy for few-output-channel layers)
   const size_t dgrad = p.dypad_bytes + p.dxp_bytes;
-  return fwd > dgrad ? fwd : dgrad;
+  const size_t sk = p.splitk_off + p.splitk_bytes;
+  const size_t m = fwd > dgrad ? fwd : dgrad;
+  return m > sk ? m : sk;
 }
 
 int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w, void* fwd_pack, void* dgrad_pack,
@@ -1595,8 +1637,9 @@ int jpdse_conv_fwd(const jpdse_conv_desc* d, const void* x, const void* fwd_pack
   JPDSE_REQUIRE(x && fwd_pack && y, "conv_fwd: null pointer");
   ConvPlan p;
   make_plan(d, &p);
-  if (ws == nullptr || ws_bytes < p.xpad_bytes)
-    return set_error(JPDSE_EWORKSPACE, "conv_fwd: workspace %zu < %zu", ws_bytes, p.xpad_bytes);
+  const size_t need = jpdse_conv_workspace_size(d);
+  if (ws == nullptr || ws_bytes < need)
+    return set_error(JPDSE_EWORKSPACE, "conv_fwd: workspace %zu < %zu", ws_bytes, need);
   return d->dtype == JPDSE_BF16 ? conv_fwd_t<bf16_t>(d, p, x, fwd_pack, bias, y, ws, as_stream(stream))
                                 : conv_fwd_t<float>(d, p, x, fwd_pack, bias, y, ws, as_stream(stream));
 }
@@ -1607,7 +1650,7 @@ int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad
   JPDSE_REQUIRE(dy && dgrad_pack && dx, "conv_dgrad: null pointer");
   ConvPlan p;
   make_plan(d, &p);
-  const size_t need = p.dypad_bytes + p.dxp_bytes;
+  const size_t need = jpdse_conv_workspace_size(d);
   if (ws == nullptr || ws_bytes < need) return set_error(JPDSE_EWORKSPACE, "conv_dgrad: workspace %zu < %zu", ws_bytes, need);
   return d->dtype == JPDSE_BF16 ? conv_dgrad_t<bf16_t>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream))
                                 : conv_dgrad_t<float>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream));

@@ -34,6 +34,11 @@ struct FastArgs {
   long long out_sn, out_sh, out_sw, out_base;
   int act;
   float slope;
+  // split-K (small M: too few tiles for 256 CUs): block (tile, split) reduces K-tiles
+  // [T*split/splits, T*(split+1)/splits) and stores its fp32 partial tile into slab `split` of
+  // `partial` ([splits][M][Ks]); splitk_finish_kernel sums the slabs in a fixed order (deterministic).
+  int splits;
+  float* partial;
 };
 
 // Up to 4 independent problems in one launch (the stride-2 sub-pixel phases of a data gradient /
@@ -85,7 +90,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
   const int tiles_m = (a.M + BM - 1) / BM;
-  const int tile_m = block_id % tiles_m, tile_n = block_id / tiles_m;
+  const int ntiles = tiles_m * ((a.Ks + BN - 1) / BN);
+  const int split = a.splits > 1 ? block_id / ntiles : 0;
+  const int tile_id = a.splits > 1 ? block_id - split * ntiles : block_id;
+  const int tile_m = tile_id % tiles_m, tile_n = tile_id / tiles_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int lrow = lane >> 3, lslot = lane & 7;
 
@@ -151,12 +159,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int CC = a.Cs >> 6;
-  const int T_total = a.R * a.S * CC;
+  const int T_all = a.R * a.S * CC;
+  const int t_begin = a.splits > 1 ? (int)((long long)T_all * split / a.splits) : 0;
+  const int t_end = a.splits > 1 ? (int)((long long)T_all * (split + 1) / a.splits) : T_all;
+  const int T_total = t_end - t_begin;
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
   // K-tile cursor of the NEXT tile to issue.  The padded source address of a tap is resolved only
   // when the tap (r,s) changes; within a tap consecutive K-tiles advance the pointer by 64 channels.
-  int ir = 0, is = 0, ic = 0, it = 0, istage = 0;
+  int it = t_begin, istage = 0;
+  int ic = t_begin % CC, is = (t_begin / CC) % a.S, ir = (t_begin / CC) / a.S;
   const bf16_t* a_src[AU];
   int a_step[AU];
   auto retap = [&]() {
@@ -194,6 +206,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     istage = istage == STAGES - 1 ? 0 : istage + 1;
   };
 
+  if (ic != 0) {                          // split-K range starting inside a tap
+    retap();
+#pragma unroll
+    for (int i = 0; i < AU; ++i) a_src[i] += ic * a_step[i];
+  }
   constexpr int AHEAD = STAGES - 1;       // tiles issued before tile t is consumed
   issue();
   if (AHEAD > 1 && T_total > 1) issue();
@@ -227,6 +244,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   }
 
   // ---- epilogue --------------------------------------------------------------------------
+  if (a.splits > 1) {
+    float* const slab = a.partial + (long long)split * a.M * a.Ks;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+      if (col >= a.Ks) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          if (m < a.M) slab[(long long)m * a.Ks + col] = acc[i][j][e];
+        }
+      }
+    }
+    return;
+  }
   __syncthreads();
   long long* const row_off = reinterpret_cast<long long*>(smem);
   for (int row = tid; row < BM; row += 64 * NW) {
@@ -257,6 +291,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
       }
     }
   }
+}
+
+// Sum of the split-K slabs + bias + activation -> bf16 output (8 channels per thread).
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const FastArgs a, long long total_vec) {
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= total_vec) return;
+  const int vpr = a.Ks >> 3;
+  const int m = (int)(v / vpr), c0 = (int)(v % vpr) * 8;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int sidx = 0; sidx < a.splits; ++sidx) {
+    const float4* src = reinterpret_cast<const float4*>(a.partial + ((long long)sidx * a.M + m) * a.Ks + c0);
+    const float4 lo = src[0], hi = src[1];
+    acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w;
+    acc[4] += hi.x; acc[5] += hi.y; acc[6] += hi.z; acc[7] += hi.w;
+  }
+  const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
+  const long long off = a.out_base + n * a.out_sn + oh * a.out_sh + ow * a.out_sw;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int col = c0 + e;
+    const bool live = col < a.Kout;
+    const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
+    o[e] = live ? apply_act(acc[e] + bv, a.act, a.slope) : 0.f;
+  }
+  Vec16<bf16_t>::store(a.Y + off + c0, o);
 }
 
 }  // namespace jpdse

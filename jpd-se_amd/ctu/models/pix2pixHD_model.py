@@ -60,6 +60,10 @@ class Pix2PixHDModel(BaseModel):
       a('--no_%s_loss' % f, action='store_true')
     a('--data_type', default=32, type=int, choices=[8, 16, 32])
     a('--fp16', action='store_true', default=False)
+    a('--skip_unused_losses', action='store_true',
+      help='extension (SURVEY 8f-4): do not run D / VGG at all when every loss they feed is switched off by '
+           '--no_*_loss (the reference runs them and discards the result, pix2pixHD_trainer.py:48-56); '
+           'the skipped losses are reported as 0')
     a('--compute_dtype', type=str, default='fp32', choices=['fp32', 'bf16'],
       help='MFMA input type of the HIP kernels (fp32 accumulate either way)')
     a('--local_rank', type=int, default=0)
@@ -283,27 +287,36 @@ class Pix2PixHDModel(BaseModel):
     B = base.N
     fake, g_ctx = self.netG.fwd(self._with_image(base, src))
 
-    # one batched discriminator pass: [label|fake ; label|real]  (model.py:717,722,733)
-    d_in = Act.empty(2 * B, base.H, base.W, base.C, self.cdtype, dev)
-    self._with_image(base, fake, out=d_in.batch_slice(0, B))
-    self._with_image(base, real, out=d_in.batch_slice(B, 2 * B))
-    pred, d_ctx = self.netD.fwd(d_in)
+    skip = bool(getattr(opt, 'skip_unused_losses', False))
+    run_d = not (skip and opt.no_g_gan_loss and opt.no_gan_feat_loss and opt.no_d_gan_loss)
+    run_vgg = not (skip and opt.no_vgg_loss)
 
-    vgg = self.criterionVGG.vgg
-    vf, v_ctx = vgg.fwd(fake, save=True)
-    vr, _ = vgg.fwd(real, save=False)
+    # one batched discriminator pass: [label|fake ; label|real]  (model.py:717,722,733)
+    pred, d_ctx = None, None
+    if run_d:
+      d_in = Act.empty(2 * B, base.H, base.W, base.C, self.cdtype, dev)
+      self._with_image(base, fake, out=d_in.batch_slice(0, B))
+      self._with_image(base, real, out=d_in.batch_slice(B, 2 * B))
+      pred, d_ctx = self.netD.fwd(d_in)
+
+    vf, vr, v_ctx = [], [], None
+    n_vgg = len(networks.VGGLoss.weights)
+    if run_vgg:
+      vgg = self.criterionVGG.vgg
+      vf, v_ctx = vgg.fwd(fake, save=not opt.no_vgg_loss)
+      vr, _ = vgg.fwd(real, save=False)
 
     nD, nF = opt.num_D, opt.n_layers_D + 1
     layout = dict(D_fake=list(range(0, nD)), D_real=list(range(nD, 2 * nD)), G_GAN=list(range(2 * nD, 3 * nD)))
     o = 3 * nD
     layout['feat'] = [[o + i * nF + j for j in range(nF)] for i in range(nD)]
     o += nD * nF
-    layout['vgg'] = list(range(o, o + len(vf)))
-    o += len(vf)
+    layout['vgg'] = list(range(o, o + n_vgg))
+    o += n_vgg
     layout['dist'] = o
     slots = torch.zeros(o + 1, dtype=torch.float32, device=dev)
     s = lambda i: slots[i:i + 1]
-    for i in range(nD):
+    for i in range(nD if run_d else 0):
       p = pred[i][-1]
       ops.mse_const_fwd(p.batch_slice(0, B), 0.0, s(layout['D_fake'][i]))
       ops.mse_const_fwd(p.batch_slice(B, 2 * B), 1.0, s(layout['D_real'][i]))
@@ -347,7 +360,7 @@ class Pix2PixHDModel(BaseModel):
     one = self._ones(state['fake'].t.device)
     fake, real = state['fake'], state['real']
     d_fake = None
-    if w_gan != 0.0 or w_feat != 0.0:
+    if (w_gan != 0.0 or w_feat != 0.0) and state['pred'] is not None:
       dres = []
       for i in range(opt.num_D):
         row = []
@@ -361,7 +374,7 @@ class Pix2PixHDModel(BaseModel):
       d_in = self.netD.bwd(state['d_ctx'], dres, need_dx=True, need_dw=False, batch=(0, B))
       d_fake = Act(torch.zeros_like(fake.t), fake.C)
       ops.channel_copy(d_in, self.label_nc, d_fake, 0, fake.C)
-    if w_vgg != 0.0:
+    if w_vgg != 0.0 and state['v_ctx'] is not None:
       wk = networks.VGGLoss.weights
       dmaps = [ops.l1_bwd(state['vf'][k], state['vr'][k], one, w_vgg * wk[k]) for k in range(len(wk))]
       dv = self.criterionVGG.vgg.bwd(state['v_ctx'], dmaps)
@@ -377,7 +390,7 @@ class Pix2PixHDModel(BaseModel):
 
   def backward_D(self, state, w_d):
     """d(loss_D)/d(netD params), loss_D = w_d * (D_fake + D_real)  (w_d = 0.5 in the trainer)."""
-    if w_d == 0.0:
+    if w_d == 0.0 or state['pred'] is None:
       return False
     opt, B = self.opt, state['B']
     one = self._ones(state['fake'].t.device)

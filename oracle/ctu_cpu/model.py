@@ -45,7 +45,8 @@ def default_opt(**over):
       lambda_distortion=10.0, anneal_lambda=False, anneal_interval=5000, anneal_factor=5.0,
       no_d_gan_loss=False, no_g_gan_loss=False, no_vgg_loss=False, no_gan_feat_loss=False,
       no_distortion_loss=False, fp16=False, tf_log=False, schedule_lr=False,
-      lr_decay_factor=0.1, lr_decay_patience=5, verbose=False, batch_size=1)
+      lr_decay_factor=0.1, lr_decay_patience=5, verbose=False, batch_size=1,
+      skip_unused_losses=False)
   o.update(over)
   return types.SimpleNamespace(**o)
 

@@ -63,6 +63,10 @@ CONV_CASES = [
     # halo kernel: 64-wide N tile, zero pad (fwd and data gradient), 2 slabs; and 128-wide with ReLU epilogue
     ('halo_vgg_64',   2, 8,  64,  128, 64,  3, 1, 1,  PAD_ZERO,    ACT_RELU),
     ('halo_vgg_256',  1, 12, 128, 64,  256, 3, 1, 1,  PAD_ZERO,    ACT_RELU),
+    # split-K fast path (few tiles, long reduction): M = 480 -> 2x2 tiles, 36 K-tiles in 2 splits starting
+    # inside a tap; reflect (fwd + data gradient on the padded domain) and zero pad with bias + LeakyReLU
+    ('splitk_reflect', 1, 15, 32, 256, 256, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    ('splitk_lrelu',   2, 9,  20, 192, 200, 4, 1, 2,  PAD_ZERO,    ACT_LRELU),
 ]
 
 

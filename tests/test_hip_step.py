@@ -187,6 +187,28 @@ def test_loss_flags_zero_terms():
     assert torch.equal(v, d_before[k]), 'D must not move when no_d_gan_loss is set'
 
 
+def test_skip_unused_losses_same_update_less_work():
+  """Extension flag: with every D / VGG fed loss switched off, not running D and
+  VGG at all gives the same G update as the reference schedule; a VGG-only skip keeps the GAN terms."""
+  kw = dict(ngf=8, ndf=8, n_blocks_global=1, no_g_gan_loss=True, no_d_gan_loss=True, no_vgg_loss=True,
+            no_gan_feat_loss=True, skip_unused_losses=True)
+  tr, ora, opt = _paired(kw)
+  xd = omodel.synthetic_batch(2, 32, 64, seed=3)
+  tr.step(xd)
+  ora.step(xd)
+  _check_weights(tr, ora, WEIGHT_TOL, 'phase-3 with skipping')
+  assert tr.last_losses['G_VGG'] == 0.0 and tr.last_losses['D_real'] == 0.0
+  assert abs(tr.last_losses['G_Distortion'] - ora.last_losses['G_Distortion']) <= LOSS_TOL * ora.last_losses['G_Distortion']
+  kw = dict(ngf=8, ndf=8, n_blocks_global=1, no_vgg_loss=True, skip_unused_losses=True)   # BASELINE config 2
+  tr, ora, opt = _paired(kw)
+  tr.step(xd)
+  ora.step(xd)
+  _check_weights(tr, ora, WEIGHT_TOL, 'no-VGG with skipping')
+  for k in omodel.LOSS_NAMES:
+    if k != 'G_VGG':
+      assert abs(tr.last_losses[k] - ora.last_losses[k]) <= LOSS_TOL * max(abs(ora.last_losses[k]), 1e-6), k
+
+
 def test_checkpoint_roundtrip_reference_layout(tmp_path):
   kw = dict(ngf=8, ndf=8, n_blocks_global=1)
   tr, ora, opt = _paired(kw)
