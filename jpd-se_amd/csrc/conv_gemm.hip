@@ -70,6 +70,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "gemm_fast.h"
 #include "gemm_halo.h"
 #include "wgrad_fast.h"
+#include "wgrad_thin.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1366,12 +1367,60 @@ static int launch_wgrad_fast(const FastWgArgs& a, hipStream_t s) {
   return launch_wgrad_fast_cfg<2, 2, 1, 1>(a, s);
 }
 
+template <int TM, int NW, int NT, int RR = 1, int WM = 1>
+static int launch_wgrad_thin_cfg(ThinWgArgs a, hipStream_t s) {
+  const int pitch = a.st * a.Cs;
+  a.x_units = (126 * pitch + 64 * NW * NT + 1023) / 1024;
+  const int lds = 2 * (TM * WM * 64 * 64 + RR * a.x_units * 1024);
+  if (lds > 64 * 1024) return set_error(JPDSE_ELAUNCH, "wgrad_thin: strip of %d B does not fit", lds);
+  a.chunks_per_row = (a.OW + 63) / 64;
+  a.strips_total = a.N * a.OH * a.chunks_per_row;
+  const int row_groups = (a.R + RR - 1) / RR;
+  int P = 1024 / row_groups;               // ~4 blocks per CU over the filter-row groups
+  if (P < 1) P = 1;
+  if (P > a.strips_total) P = a.strips_total;
+  a.strips_per_block = (a.strips_total + P - 1) / P;
+  P = (a.strips_total + a.strips_per_block - 1) / a.strips_per_block;
+  hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), s);
+  if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR>), dim3(P, row_groups), dim3(64 * WM * NW), lds, s, a);
+  return check_launch("wgrad_thin_kernel");
+}
+
+static bool wgrad_thin_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
+  const int n_tiles = (d->S * p.Cs + 31) / 32;
+  return g_fast_enabled && p.Cs % 64 != 0 && (p.Ks == 32 || p.Ks == 64) && n_tiles <= 12 &&
+         (126 * d->stride * p.Cs + 64 * 12) <= 20 * 1024;
+}
+
+static int launch_wgrad_thin(const ThinWgArgs& a, hipStream_t s) {
+  const int n_tiles = (a.S * a.Cs + 31) / 32;
+  if (a.Ks == 64) {
+    if (n_tiles <= 6) return launch_wgrad_thin_cfg<2, 2, 3>(a, s);
+    if (n_tiles <= 9) return launch_wgrad_thin_cfg<2, 3, 3>(a, s);
+    return launch_wgrad_thin_cfg<2, 4, 3>(a, s);
+  }
+  if (n_tiles <= 6) return launch_wgrad_thin_cfg<1, 2, 3>(a, s);
+  if (n_tiles <= 9) return launch_wgrad_thin_cfg<1, 3, 3>(a, s);
+  return launch_wgrad_thin_cfg<1, 4, 3>(a, s);
+}
+
+// heads with <= 8 output channels on a 32- / 64-channel input, stride 1 (64->3, 32->3 7x7)
+static bool wgrad_head_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
+  return g_fast_enabled && p.Ks == 8 && d->stride == 1 && (p.Cs == 32 || p.Cs == 64) && d->S * 8 <= 64 && d->R <= 7;
+}
+
+static int launch_wgrad_head(const ThinWgArgs& a, hipStream_t s) {
+  // 2 waves x 1 run tile (S*8 <= 64 columns), all R <= 7 filter rows per block
+  return a.Ks == 64 ? launch_wgrad_thin_cfg<1, 2, 1, 7, 2>(a, s) : launch_wgrad_thin_cfg<1, 2, 1, 7>(a, s);
+}
+
 template <typename T>
 static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* dy, float* dw,
                         void* ws, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     const int kexp = d->K * d->R * d->S, kexp_s = round_up(kexp, 64);
-    if (g_fast_enabled && p.Ks == 8 && d->stride == 1 && p.Cs % 64 == 0 && kexp_s <= 256) {
+    if (g_fast_enabled && !wgrad_head_ok(d, p) && p.Ks == 8 && d->stride == 1 && p.Cs % 64 == 0 && kexp_s <= 256) {
       // few output channels: dense 1x1 weight gradient over the tap-expanded dy (see expand_dy_taps_kernel)
       if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
         return rc;
@@ -1399,6 +1448,56 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       f.py = f.px = 0;
       f.reflect = 0;
       return launch_wgrad_fast(f, s);
+    }
+    if (wgrad_head_ok(d, p)) {
+      // roles swapped (see wgrad_thin.h): A = padded input, run operand = dy zero-padded by (R-1, S-1)
+      if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+        return rc;
+      bf16_t* dyp = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ws) + p.xpad_bytes);
+      if (int rc = launch_pad<T>(dy, dyp, d->N, p.OH, p.OW, 8, d->R - 1, d->R - 1, d->S - 1, d->S - 1, JPDSE_PAD_ZERO, s))
+        return rc;
+      ThinWgArgs t = {};
+      t.XP = dyp;
+      t.DY = reinterpret_cast<const bf16_t*>(ws);
+      t.DW = dw;
+      t.N = d->N;
+      t.OH = p.Hp;
+      t.OW = p.Wp;
+      t.Hp = p.OH + 2 * (d->R - 1);
+      t.Wp = p.OW + 2 * (d->S - 1);
+      t.Cs = 8;
+      t.C = d->K;
+      t.Ks = p.Cs;
+      t.K = d->C;
+      t.R = d->R;
+      t.S = d->S;
+      t.st = 1;
+      t.x_limit = (long long)d->N * t.Hp * t.Wp * 8 + (long long)(kSlackBytes / 2);
+      t.transposed = 1;
+      return launch_wgrad_head(t, s);
+    }
+    if (wgrad_thin_ok(d, p)) {
+      // thin inputs (40-channel network inputs): input strips staged once, see wgrad_thin.h
+      if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+        return rc;
+      ThinWgArgs t = {};
+      t.XP = reinterpret_cast<const bf16_t*>(ws);
+      t.DY = reinterpret_cast<const bf16_t*>(dy);
+      t.DW = dw;
+      t.N = d->N;
+      t.OH = p.OH;
+      t.OW = p.OW;
+      t.Hp = p.Hp;
+      t.Wp = p.Wp;
+      t.Cs = p.Cs;
+      t.C = d->C;
+      t.Ks = p.Ks;
+      t.K = d->K;
+      t.R = d->R;
+      t.S = d->S;
+      t.st = d->stride;
+      t.x_limit = (long long)d->N * p.Hp * p.Wp * p.Cs + (long long)(kSlackBytes / 2);
+      return launch_wgrad_thin(t, s);
     }
     if (g_fast_enabled && p.Ks % 64 == 0) {
       FastWgArgs f = {};
@@ -1565,7 +1664,11 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   ConvPlan p;
   make_plan(d, &p);
   const size_t kexp_s = (size_t)round_up(d->K * d->R * d->S, 64);
-  const size_t dz = (p.Ks == 8 && kexp_s <= 256) ? align_up((size_t)d->N * p.Hp * p.Wp * kexp_s * 2, 256) : 0;
+  size_t dz = (p.Ks == 8 && kexp_s <= 256) ? align_up((size_t)d->N * p.Hp * p.Wp * kexp_s * 2, 256) : 0;
+  if (p.Ks == 8 && d->stride == 1) {      // zero-padded dy of the head weight gradient (wgrad_thin.h, transposed)
+    const size_t dyp = align_up((size_t)d->N * (p.OH + 2 * (d->R - 1)) * (p.OW + 2 * (d->S - 1)) * 8 * 2 + kSlackBytes, 256);
+    dz = dz > dyp ? dz : dyp;
+  }
   const size_t fwd = p.xpad_bytes + dz;     // wgrad: padded x (+ tap-expanded dy for few-output-channel layers)
   const size_t dgrad = p.dypad_bytes + p.dxp_bytes;
   const size_t sk = p.splitk_off + p.splitk_bytes;

@@ -37,7 +37,7 @@ struct FastWgArgs {
 };
 
 template <int ROWB> __device__ __forceinline__ int trswz(int pix) {
-  return ROWB >= 256 ? ((pix & 3) << 2) : (((pix >> 1) & 1) << 2);
+  return ROWB >= 256 ? ((pix & 3) << 2) : (ROWB == 128 ? (((pix >> 1) & 1) << 2) : 0);   // 64-B rows: 4 rows = 256 contiguous bytes
 }
 
 __device__ __forceinline__ s16x8 tr_frag(const char* p, int row4_bytes) {

@@ -1,0 +1,203 @@
+// bf16 weight gradient of the convs fed by a THIN input (the 40-channel network inputs of G / D, and
+// any input whose channel storage is not a multiple of 64) with 32 or 64 output channels:
+//     dW[k][r][s][c] = sum_{n,oh,ow} dy[n,oh,ow,k] * xpad[n, oh*st + r, ow*st + s, c]
+//
+// In the materially padded NHWC input the S*Cs values under filter row r of output pixel ow are ONE
+// contiguous run starting at pixel ow*st, and the runs of neighbouring output pixels overlap.  The
+// generic / run-mode kernels stage every pixel's run separately (S-fold redundant L2->LDS traffic,
+// the resource these kernels are bound by).  Here a block owns one filter row r and walks over
+// strips of 64 output pixels of one output row: the strip's input pixels are copied ONCE, densely
+// ([pixel][Cs], no padding, no swizzle) by LDS-DMA, and the GEMM B operand
+//     B[pix][j] = lds[pix * st*Cs + j],   j in [0, S*Cs)  (column j <-> tap s = j / Cs, channel j % Cs)
+// is formed by the per-lane addresses of ds_read_b64_tr_b16 (overlapping rows cost nothing).  dy is
+// staged as in wgrad_fast.h.  M = Ks (32*TM) output channels, N = S*Cs run columns in NW*NT 32-wide
+// tiles (wave w owns NT of them), reduction over the strip's 64 pixels per step; 2 LDS stages.
+// Blocks accumulate their strips in registers and add the result into the zeroed fp32 gradient.
+//
+// RR > 1: one block handles RR filter rows (run strips of RR input rows next to ONE dy strip).
+// `transposed`: the roles are swapped for convs with <= 8 OUTPUT channels (the 64->3 / 32->3 heads):
+// the "dy" operand is the padded conv input (M = its 32/64 channels) and the run operand is dy,
+// zero-padded by (R-1, S-1), 8 channels per pixel: G[c][r'][s'*8 + k] = sum_p xpad[p][c] *
+// dypad[p + (r', s')][k] is the gradient of tap (R-1-r', S-1-s').  All R rows share the x strip
+// (RR = R), so the input is staged once instead of R times.
+#pragma once
+#include "common.h"
+#include "gemm_fast.h"
+#include "wgrad_fast.h"
+
+namespace jpdse {
+
+struct ThinWgArgs {
+  const bf16_t* XP;    // padded input [N][Hp][Wp][Cs]
+  const bf16_t* DY;    // [N][OH][OW][Ks]
+  float* DW;           // fp32 KRSC
+  int N, OH, OW, Hp, Wp, Cs, C, Ks, K, R, S, st;
+  int chunks_per_row, strips_total, strips_per_block;
+  int x_units;         // 1 KiB DMA units per input strip
+  long long x_limit;   // elements of XP that may be read (tensor + zeroed slack)
+  int transposed;
+};
+
+// TM m-tiles per wave, WM x WN waves (M = 32*TM*WM channels of the dy operand, WN*NT run tiles)
+template <int TM, int WM, int WN, int NT, int RR>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgArgs a) {
+  constexpr int NW = WM * WN;
+  constexpr int A_ROWB = TM * WM * 64;            // bytes per dy pixel row (Ks = 32*TM*WM channels)
+  constexpr int A_STAGE = 64 * A_ROWB;
+  constexpr int A_UNITS = A_STAGE / 1024;
+  constexpr int A_PPU = 1024 / A_ROWB;            // pixels per DMA unit
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int stage_bytes = A_STAGE + RR * a.x_units * 1024;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int r0 = blockIdx.y * RR;
+  const int s_begin = blockIdx.x * a.strips_per_block;
+  int s_end = s_begin + a.strips_per_block;
+  s_end = s_end < a.strips_total ? s_end : a.strips_total;
+  if (s_begin >= s_end) return;
+  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const int pitch = a.st * a.Cs;                  // elements between consecutive output pixels' runs
+  const int units = A_UNITS + RR * a.x_units;
+
+  // transposed fragment offsets (lane roles as in wgrad_fast.h)
+  int a_tr[TM], b_tr[NT];
+  {
+    const int g = lane >> 4, li = lane & 15, h = g >> 1, cb = g & 1, q = li >> 2, p = li & 3;
+    const int pix = 8 * h + q;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ch = (wm * TM + i) * 32 + cb * 16 + 4 * p;
+      a_tr[i] = pix * A_ROWB + ((((ch >> 3) ^ trswz<A_ROWB>(pix)) << 4) | ((ch & 7) << 1));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      b_tr[j] = A_STAGE + (pix * pitch + (wn * NT + j) * 32 + cb * 16 + 4 * p) * 2;
+  }
+  const int pb16 = 16 * pitch * 2, pb4 = 4 * pitch * 2;
+  const int xs_bytes = a.x_units * 1024;
+
+  f32x16 acc[RR][TM][NT];
+#pragma unroll
+  for (int rr = 0; rr < RR; ++rr)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rr][i][j][e] = 0.f;
+
+  auto issue = [&](int strip, int stage) {
+    char* const st = smem + stage * stage_bytes;
+    const int chunk = strip % a.chunks_per_row;
+    const int row = strip / a.chunks_per_row;       // n*OH + oh
+    const int oh = row % a.OH, n = row / a.OH;
+    const int ow0 = chunk * 64;
+    const long long dy_base = ((long long)row * a.OW + ow0) * a.Ks;
+    const long long x_base = (((long long)n * a.Hp + oh * a.st + r0) * a.Wp + (long long)ow0 * a.st) * a.Cs;
+    const long long x_row = (long long)a.Wp * a.Cs;
+    for (int u = wid; u < units; u += NW) {
+      const bf16_t* src;
+      if (u < A_UNITS) {
+        const int pl = lane / (A_ROWB / 16), slot = lane % (A_ROWB / 16);
+        const int pix = u * A_PPU + pl;
+        src = ow0 + pix < a.OW ? a.DY + dy_base + (long long)pix * a.Ks + ((slot ^ trswz<A_ROWB>(pix)) << 3) : zero;
+      } else {
+        const int ub = u - A_UNITS, rr = ub / a.x_units, uu = ub - rr * a.x_units;
+        const long long e = x_base + rr * x_row + ((long long)uu * 64 + lane) * 8;
+        src = (e + 8 <= a.x_limit && r0 + rr < a.R) ? a.XP + e : zero;
+      }
+      glds16(src, st + u * 1024);
+    }
+  };
+
+  int stage = 0;
+  issue(s_begin, 0);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  for (int sidx = s_begin; sidx < s_end; ++sidx) {
+    if (sidx + 1 < s_end) issue(sidx + 1, stage ^ 1);
+    const char* const st = smem + stage * stage_bytes;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s16x8 af[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = tr_frag(st + a_tr[i] + ks * 16 * A_ROWB, 4 * A_ROWB);
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) {
+        s16x8 bf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = tr_frag(st + rr * xs_bytes + b_tr[j] + ks * pb16, pb4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[rr][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[rr][i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    stage ^= 1;
+  }
+
+  const int run = a.S * a.Cs;
+  if (a.transposed) {
+    // The gradient row of one (output channel c, tap) is the M = a.K contiguous floats of the conv's input
+    // channels: transpose each filter row's tile through LDS so that one atomic instruction covers a
+    // contiguous row instead of 64 scattered cache lines.
+    constexpr int MROWS = 32 * TM * WM, COLS = 32 * WN * NT, PITCH = MROWS + 1;
+    float* const tbuf = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      const int r = r0 + rr;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = (wn * NT + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int k = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            tbuf[col * PITCH + k] = acc[rr][i][j][e];
+          }
+      }
+      __syncthreads();
+      if (r >= a.R) continue;
+      for (int idx = tid; idx < a.S * a.C * MROWS; idx += 64 * NW) {
+        const int k = idx % MROWS, sc = idx / MROWS;
+        const int s_out = sc / a.C, c = sc - s_out * a.C;
+        if (k >= a.K) continue;
+        atomicAdd(a.DW + (((long long)c * a.R + (a.R - 1 - r)) * a.S + (a.S - 1 - s_out)) * a.K + k,
+                  tbuf[(s_out * a.Cs + c) * PITCH + k]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int rr = 0; rr < RR; ++rr) {
+    const int r = r0 + rr;
+    if (r >= a.R) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = (wn * NT + j) * 32 + (lane & 31);
+      if (col >= run) continue;
+      const int s_out = col / a.Cs, c = col - s_out * a.Cs;
+      if (c >= a.C) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int k = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          if (k >= a.K) continue;
+          atomicAdd(a.DW + (((long long)k * a.R + r) * a.S + s_out) * a.C + c, acc[rr][i][j][e]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace jpdse

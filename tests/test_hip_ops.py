@@ -67,6 +67,12 @@ CONV_CASES = [
     # inside a tap; reflect (fwd + data gradient on the padded domain) and zero pad with bias + LeakyReLU
     ('splitk_reflect', 1, 15, 32, 256, 256, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
     ('splitk_lrelu',   2, 9,  20, 192, 200, 4, 1, 2,  PAD_ZERO,    ACT_LRELU),
+    # thin-input weight gradient (wgrad_thin.h): several 64-pixel strips per row with a ragged last one
+    ('thin_ragged',    2, 10, 150, 39, 64,  7, 1, 3,  PAD_REFLECT, ACT_NONE),
+    ('thin_s2_k32',    1, 8,  260, 39, 32,  4, 2, 2,  PAD_ZERO,    ACT_LRELU),
+    # head weight gradient (wgrad_thin.h, transposed roles): 32-channel input (LocalEnhancer), ragged strips
+    ('head_local32',   2, 9,  70,  32, 3,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
+    ('head_3x3_zero',  1, 6,  130, 64, 5,   3, 1, 1,  PAD_ZERO,    ACT_NONE),
 ]
 
 
