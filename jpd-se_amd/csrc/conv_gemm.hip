@@ -38,6 +38,7 @@ struct GemmFwdArgs {
   long long out_sn, out_sh, out_sw, out_base;
   int act;
   float slope;
+  int col_mod, k_real;   // col_mod > 0: GEMM column -> channel (col % col_mod), live when < k_real (Toeplitz head)
 };
 
 struct GemmWgradArgs {
@@ -300,8 +301,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArg
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
     if (col >= a.Ks) continue;
-    const bool live = col < a.Kout;
-    const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
+    const int kk = a.col_mod > 0 ? col % a.col_mod : col;
+    const bool live = a.col_mod > 0 ? kk < a.k_real : col < a.Kout;
+    const float bv = (a.bias != nullptr && live) ? a.bias[kk] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -648,6 +650,27 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ out
   }
 }
 
+// Toeplitz panel of a stride-1 conv with <= 8 output channels (the 64->3 / 32->3 heads): GEMM column
+// (dl, k) = output pixel ow4*4 + dl, channel k, so that a 32-wide MFMA tile carries 4 pixels x 8 channels
+// instead of 8 channels + 24 dead columns; K-dim = (r, s', c) over the S+3 input pixels the 4 outputs share:
+//   out[(dl*8 + k)][r][s'*Cs + c] = w[k][r][s' - dl][c]   (0 outside the filter)
+template <typename T>
+__global__ void pack_fwd_toep_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int C, int Cs,
+                                     int R, int S, int Lk, long long total) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % Lk);
+    long long t = idx / Lk;
+    const int r = (int)(t % R);
+    const int row = (int)(t / R);
+    const int dl = row >> 3, k = row & 7;
+    const int sp = j / Cs, c = j - sp * Cs, s = sp - dl;
+    float v = 0.f;
+    if (k < K && s >= 0 && s < S && c < C) v = w[(((long long)k * R + r) * S + s) * C + c];
+    ElemOps<T>::st(out + idx, v);
+  }
+}
+
 // one stride phase of the data-gradient panel: rows = input channels c, K-dim = (u', w', k)
 template <typename T>
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int Ks, int C, int Cs,
@@ -752,6 +775,8 @@ struct ConvPlan {
   size_t dgrad_pack_bytes;
   size_t xpad_bytes, dypad_bytes, dxp_bytes;
   size_t splitk_off, splitk_bytes;   // fp32 partial slabs of the split-K fast path (behind the other regions)
+  int toep, Lk_toep;                 // bf16 head (<= 8 output channels, stride 1): extra Toeplitz forward panel
+  size_t fwd_pack_plain_bytes, fwd_pack_bytes;
 };
 
 static void phase_axis(int st, int q, int Rf, int lo, int hi, int& U, int& i0, int& cnt) {
@@ -820,6 +845,14 @@ static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
   p->xpad_bytes = align_up((size_t)d->N * p->Hp * p->Wp * p->Cs * p->ES + kSlackBytes, 256);
   p->dypad_bytes = align_up((size_t)d->N * p->DH * p->DW * p->Ks * p->ES + kSlackBytes, 256);
   p->dxp_bytes = refl ? align_up((size_t)d->N * p->Hp * p->Wp * p->Cs * p->ES, 256) : 0;
+  p->fwd_pack_plain_bytes = align_up((size_t)p->Ks * d->R * p->Lk_fwd * p->ES, 256);
+  p->toep = (p->ES == 2 && p->Ks == 8 && st == 1) ? 1 : 0;
+  p->Lk_toep = p->toep ? round_up((d->S + 3) * p->Cs, p->BKE) : 0;
+  p->fwd_pack_bytes = p->fwd_pack_plain_bytes + (p->toep ? align_up((size_t)32 * d->R * p->Lk_toep * p->ES, 256) : 0);
+  if (p->toep) {
+    // the Toeplitz rows of the last pixel group read (S+3)*Cs rounded up to a chunk: keep that inside the slack
+    p->xpad_bytes = align_up(p->xpad_bytes + (size_t)p->BKE * p->ES, 256);
+  }
   p->splitk_off = p->xpad_bytes > p->dypad_bytes + p->dxp_bytes ? p->xpad_bytes : p->dypad_bytes + p->dxp_bytes;
   p->splitk_bytes = 0;
   if (p->ES == 2) {
@@ -1123,6 +1156,38 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
   if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
     return rc;
   const void* xin = ws;
+  if (p.toep && g_fast_enabled && p.OW % 4 == 0) {
+    // head: 4 output pixels x 8 channels per 32-wide GEMM row (see pack_fwd_toep_kernel); the [M/4][32]
+    // result IS the NHWC output
+    GemmFwdArgs a = {};
+    a.A = xin;
+    a.B = reinterpret_cast<const char*>(pack) + p.fwd_pack_plain_bytes;
+    a.bias = bias;
+    a.Y = y;
+    a.M = d->N * p.OH * (p.OW / 4);
+    a.OH = p.OH;
+    a.OW = p.OW / 4;
+    a.Kout = 32;
+    a.Ks = 32;
+    a.R = d->R;
+    a.cpr = p.Lk_toep / p.BKE;
+    a.b_rows = 32;
+    a.b_row_stride = (long long)d->R * p.Lk_toep;
+    a.in_sn = (long long)p.Hp * p.Wp * p.Cs;
+    a.in_sh = (long long)p.Wp * p.Cs;
+    a.in_sw = 4LL * p.Cs;
+    a.in_sr = (long long)p.Wp * p.Cs;
+    a.in_base = 0;
+    a.out_sn = (long long)p.OH * p.OW * p.Ks;
+    a.out_sh = (long long)p.OW * p.Ks;
+    a.out_sw = 4LL * p.Ks;
+    a.out_base = 0;
+    a.act = d->act;
+    a.slope = d->slope;
+    a.col_mod = 8;
+    a.k_real = d->K;
+    return launch_fwd<T>(a, s);
+  }
   GemmFwdArgs a = {};
   a.A = xin;
   a.B = pack;
@@ -1649,7 +1714,7 @@ size_t jpdse_conv_fwd_pack_size(const jpdse_conv_desc* d) {
   if (validate(d)) return 0;
   ConvPlan p;
   make_plan(d, &p);
-  return align_up((size_t)p.Ks * d->R * p.Lk_fwd * p.ES, 256);
+  return p.fwd_pack_bytes;
 }
 
 size_t jpdse_conv_dgrad_pack_size(const jpdse_conv_desc* d) {
@@ -1702,6 +1767,13 @@ int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w, void* fwd_
       hipLaunchKernelGGL((pack_fwd_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
                          reinterpret_cast<float*>(fwd_pack), d->K, p.Ks, d->C, p.Cs, d->R, d->S, p.Lk_fwd, total);
     if (int rc = check_launch("pack_fwd_kernel")) return rc;
+  }
+  if (fwd_pack && p.toep) {
+    const long long total = (long long)32 * d->R * p.Lk_toep;
+    hipLaunchKernelGGL((pack_fwd_toep_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
+                       reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(fwd_pack) + p.fwd_pack_plain_bytes), d->K,
+                       d->C, p.Cs, d->R, d->S, p.Lk_toep, total);
+    if (int rc = check_launch("pack_fwd_toep_kernel")) return rc;
   }
   if (dgrad_pack) {
     for (int i = 0; i < p.nph; ++i) {

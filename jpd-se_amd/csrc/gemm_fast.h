@@ -60,6 +60,39 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 // 64-byte pieces cost 12-28 %: cdna_hip_programming.md, "x through LDS in full 128-B lines").
 __device__ __forceinline__ int swz128(int row, int slot) { return (row << 7) + (((slot ^ (row >> 1)) & 7) << 4); }
 
+// Epilogue staging: a wave's TM x TN accumulator tiles -> bias + activation -> bf16 into an LDS
+// tile [rows][pitch = BN*2 + 64 bytes] so that the global stores are 16-byte vectors along the
+// channel axis (the accumulator layout would give 2-byte stores, 64 B contiguous per 32 lanes).
+// Lane pairs exchange one value per two accumulator rows so that every LDS store is a packed
+// (col, col+1) dword; with the 64-byte pitch skew the even / odd lanes hit disjoint banks.
+template <int TM, int TN>
+__device__ __forceinline__ void acc_tile_to_lds(char* tile, int pitch, int wrow0, int wcol0, int n0, int lane,
+                                                const f32x16 (&acc)[TM][TN], const float* bias, int Kout, int act,
+                                                float slope) {
+  const int odd = lane & 1;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int lcol = wcol0 + j * 32 + (lane & 31);
+    const int col = n0 + lcol;
+    const bool live = col < Kout;
+    const float bv = (bias != nullptr && live) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int ep = 0; ep < 8; ++ep) {
+        const int e = 2 * ep;
+        const float v0 = live ? apply_act(acc[i][j][e] + bv, act, slope) : 0.f;
+        const float v1 = live ? apply_act(acc[i][j][e + 1] + bv, act, slope) : 0.f;
+        const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);
+        const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
+        const uint32_t word = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+        const int row = wrow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) + odd;
+        *reinterpret_cast<uint32_t*>(tile + row * pitch + (lcol - odd) * 2) = word;
+      }
+    }
+  }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -263,6 +296,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   }
   __syncthreads();
   long long* const row_off = reinterpret_cast<long long*>(smem);
+  char* const tile = smem + BM * 8;
+  constexpr int PITCH = BN * 2 + 64;
+  static_assert(BM * 8 + BM * PITCH <= STAGES * STAGE_BYTES, "epilogue tile fits the pipeline LDS");
   for (int row = tid; row < BM; row += 64 * NW) {
     const int m = m0 + row;
     long long off = -1;
@@ -272,24 +308,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     }
     row_off[row] = off;
   }
+  acc_tile_to_lds<TM, TN>(tile, PITCH, wm * TM * 32, wn * TN * 32, n0, lane, acc, a.bias, a.Kout, a.act, a.slope);
   __syncthreads();
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-    if (col >= a.Ks) continue;
-    const bool live = col < a.Kout;
-    const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const long long off = row_off[row];
-        if (off < 0) continue;
-        const float v = live ? apply_act(acc[i][j][e] + bv, a.act, a.slope) : 0.f;
-        a.Y[off + col] = f2bf(v);
-      }
-    }
+  constexpr int VPR = BN / 8;
+  for (int idx = tid; idx < BM * VPR; idx += 64 * NW) {
+    const int row = idx / VPR, v = idx - row * VPR;
+    const long long off = row_off[row];
+    if (off < 0 || n0 + v * 8 >= a.Ks) continue;
+    *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
   }
 }
 

@@ -213,23 +213,20 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     if (++tap == TAPS) { tap = 0; ++slab; }
   }
 
-  // ---- epilogue: wave wm owns image row oh0+wm; 2 x 32 consecutive pixels
-  const long long row_base = a.out_base + n * a.out_sn + (long long)(oh0 + wm) * a.out_sh + (long long)ow0 * a.out_sw;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-    if (col >= a.Ks) continue;
-    const bool live = col < a.Kout;
-    const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int tw = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const float v = live ? apply_act(acc[i][j][e] + bv, a.act, a.slope) : 0.f;
-        a.Y[row_base + (long long)tw * a.out_sw + col] = f2bf(v);
-      }
-    }
+  // ---- epilogue: wave wm owns image row oh0+wm (2 x 32 consecutive pixels); staged through LDS so that the
+  // global stores are 16-byte channel vectors (see acc_tile_to_lds)
+  __syncthreads();
+  constexpr int PITCH = BN * 2 + 64;
+  static_assert(TH * 64 * PITCH <= 2 * HALO + 3 * B_STAGE, "epilogue tile fits the pipeline LDS");
+  acc_tile_to_lds<2, TN>(smem, PITCH, wm * 64, wn * TN * 32, n0, lane, acc, a.bias, a.Kout, a.act, a.slope);
+  __syncthreads();
+  const long long blk_base = a.out_base + n * a.out_sn + (long long)oh0 * a.out_sh + (long long)ow0 * a.out_sw;
+  constexpr int VPR = BN / 8;
+  for (int idx = tid; idx < TH * 64 * VPR; idx += 512) {
+    const int row = idx / VPR, v = idx - row * VPR;
+    if (n0 + v * 8 >= a.Ks) continue;
+    const long long off = blk_base + (long long)(row >> 6) * a.out_sh + (long long)(row & 63) * a.out_sw;
+    *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);
   }
 }
 

@@ -73,6 +73,9 @@ CONV_CASES = [
     # head weight gradient (wgrad_thin.h, transposed roles): 32-channel input (LocalEnhancer), ragged strips
     ('head_local32',   2, 9,  70,  32, 3,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
     ('head_3x3_zero',  1, 6,  130, 64, 5,   3, 1, 1,  PAD_ZERO,    ACT_NONE),
+    # head forward as a Toeplitz GEMM (4 output pixels x 8 channels per MFMA row): needs OW % 4 == 0
+    ('head_toeplitz',  2, 9,  72,  64, 3,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
+    ('head_toep_3x3',  1, 5,  36,  24, 7,   3, 1, 1,  PAD_ZERO,    ACT_NONE),
 ]
 
 
