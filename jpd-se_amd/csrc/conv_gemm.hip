@@ -72,6 +72,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "gemm_halo.h"
 #include "wgrad_fast.h"
 #include "wgrad_thin.h"
+#include "wgrad_row.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1044,6 +1045,7 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
   return tiles >= 448 || (tiles >= 256 && tiles % 256 == 0);
 }
 
+static int g_wgrad_abl = 0;
 static int g_halo_enabled = 1;
 static int g_halo_abl = 0;
 
@@ -1376,8 +1378,6 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   return rc;
 }
 
-static int g_wgrad_abl = 0;
-
 template <int WM, int WN, int TM, int TN, int ABL = 0>
 static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -1470,6 +1470,47 @@ static int launch_wgrad_thin(const ThinWgArgs& a, hipStream_t s) {
   return launch_wgrad_thin_cfg<1, 4, 3>(a, s);
 }
 
+static int g_wgrad_row_enabled = 1;
+static bool wgrad_row_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
+  return g_fast_enabled && g_wgrad_row_enabled && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
+         p.OW % 64 == 0 && p.Ks % 256 == 0 && p.Cs % 128 == 0;
+}
+
+template <int ABL>
+static int launch_wgrad_row_cfg(RowWgArgs a, hipStream_t s) {
+  constexpr int lds = 3 * (64 * 512 + 17 * 1024);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_row_kernel<ABL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_row: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  a.chunks_per_row = a.W / 64;
+  a.chunks_total = a.N * a.H * a.chunks_per_row;
+  const int tiles = (a.Ks / 256) * 3 * (a.Cs / 128);
+  const long long total = (long long)tiles * a.chunks_total;
+  long long nblocks = 256;
+  if (total < nblocks * 8) nblocks = (total + 7) / 8;
+  if (nblocks < 1) nblocks = 1;
+  a.iters_per_block = (int)((total + nblocks - 1) / nblocks);
+  nblocks = (total + a.iters_per_block - 1) / a.iters_per_block;
+  a.total_iters = total;
+  const bool atomic = (a.iters_per_block % a.chunks_total) != 0 || nblocks * (long long)a.iters_per_block != total;
+  if (atomic) {
+    hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * 9 * a.C * sizeof(float), s);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(wgrad_row_kernel<ABL>, dim3((int)nblocks), dim3(512), lds, s, a);
+  return check_launch("wgrad_row_kernel");
+}
+
+static int launch_wgrad_row(const RowWgArgs& a, hipStream_t s) {
+  if (g_wgrad_abl == 1) return launch_wgrad_row_cfg<1>(a, s);
+  if (g_wgrad_abl == 2) return launch_wgrad_row_cfg<2>(a, s);
+  return launch_wgrad_row_cfg<0>(a, s);
+}
+
 // heads with <= 8 output channels on a 32- / 64-channel input, stride 1 (64->3, 32->3 7x7)
 static bool wgrad_head_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
   return g_fast_enabled && p.Ks == 8 && d->stride == 1 && (p.Cs == 32 || p.Cs == 64) && d->S * 8 <= 64 && d->R <= 7;
@@ -1513,6 +1554,21 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       f.py = f.px = 0;
       f.reflect = 0;
       return launch_wgrad_fast(f, s);
+    }
+    if (wgrad_row_ok(d, p)) {
+      RowWgArgs w = {};
+      w.X = reinterpret_cast<const bf16_t*>(x);
+      w.DY = reinterpret_cast<const bf16_t*>(dy);
+      w.DW = dw;
+      w.N = d->N;
+      w.H = d->H;
+      w.W = d->W;
+      w.Cs = p.Cs;
+      w.C = d->C;
+      w.Ks = p.Ks;
+      w.K = d->K;
+      w.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+      return launch_wgrad_row(w, s);
     }
     if (wgrad_head_ok(d, p)) {
       // roles swapped (see wgrad_thin.h): A = padded input, run operand = dy zero-padded by (R-1, S-1)
@@ -1650,6 +1706,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_fast_enabled = enable != 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
+  g_wgrad_row_enabled = enable != 4;  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
   g_wgrad_abl = enable >= 200 ? enable - 200 : 0;   // 200+bits: fast wgrad timing ablations   // 100+bits: halo kernel timing ablations (wrong results)
   return JPDSE_OK;
 }

@@ -46,6 +46,57 @@ __device__ __forceinline__ s16x8 tr_frag(const char* p, int row4_bytes) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// The same read as inline asm, for loops that keep LDS-DMA in flight: hipcc treats the tr-read BUILTIN as an
+// LDS load that may alias the pending global_load_lds and puts `s_waitcnt vmcnt(0)` in front of the first
+// one after every DMA issue (seen in the .s of every kernel using tr_frag: the DMA of the next chunk was
+// drained before the current chunk's MFMAs started).  The asm form is invisible to that analysis; the
+// caller orders it by hand: counted vmcnt + raw barrier before, tr_wait() (lgkmcnt(0) tied to the
+// fragment registers) between the reads and the MFMAs that consume them.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+}
+template <int OFF_LO, int OFF_HI>
+__device__ __forceinline__ s16x8 tr_frag_asm(uint32_t addr) {
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(lo), "=&v"(hi)
+               : "v"(addr), "n"(OFF_LO), "n"(OFF_HI));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// two runtime addresses (row pitch not a compile-time constant)
+__device__ __forceinline__ s16x8 tr_frag_asm2(uint32_t addr_lo, uint32_t addr_hi) {
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"
+               : "=&v"(lo), "=&v"(hi)
+               : "v"(addr_lo), "v"(addr_hi));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int N> __device__ __forceinline__ void tr_wait(s16x8 (&f)[N]) {
+  if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]));
+  else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
+  else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]));
+  else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+  else static_assert(N <= 4, "tr_wait: up to 4 fragments");
+}
+
+// one 16-pixel k-step of a wave tile: TM + TN transposed fragments (asm reads), then TM*TN MFMAs
+template <int TM, int TN, int A_ROWB, int B_ROWB, int KS>
+__device__ __forceinline__ void wg_mma_step(uint32_t sbase, const int (&a_tr)[TM], const int (&b_tr)[TN],
+                                            f32x16 (&acc)[TM][TN]) {
+  s16x8 af[TM], bf[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) af[i] = tr_frag_asm<KS * 16 * A_ROWB, KS * 16 * A_ROWB + 4 * A_ROWB>(sbase + a_tr[i]);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bf[j] = tr_frag_asm<KS * 16 * B_ROWB, KS * 16 * B_ROWB + 4 * B_ROWB>(sbase + b_tr[j]);
+  tr_wait(af);
+  tr_wait(bf);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+}
+
 // Tile = (WM*TM*32) k-channels x (WN*TN*32) c-channels, WM x WN waves, wave tile 32*TM x 32*TN.
 //   <2,2,TM,TN>  64..128 square-ish tiles, 4 waves, 2 blocks per CU (small layers)
 //   <2,4,4,2>    256 x 256, 8 waves, 1 block per CU: 2x the FLOPs per staged byte -- the kernel is bound
@@ -70,6 +121,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_fast_kernel(const FastWgAr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
+  const uint32_t lds0 = lds_addr_of(smem);
 
   const int c_tiles = ((a.run_mode ? a.run_len : a.Cs) + BN - 1) / BN;
   const int n_taps = a.run_mode ? a.R : a.R * a.S;
@@ -197,22 +249,12 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_fast_kernel(const FastWgAr
   __builtin_amdgcn_s_barrier();
   for (int c = ch_begin; c < ch_end; ++c) {
     if (c + 1 < ch_end && !(ABL & 1)) issue(stage ^ 1);
-    const char* const st = smem + stage * STAGE;
+    const uint32_t sbase = lds0 + stage * STAGE;
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < BKP / 16; ++ks) {
-      s16x8 af[TM], bf[TN];
-      const int ks_r = (ABL & 4) ? 0 : ks;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = tr_frag(st + a_tr[i] + ks_r * 16 * A_ROWB, 4 * A_ROWB);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = tr_frag(st + b_tr[j] + ks_r * 16 * B_ROWB, 4 * B_ROWB);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
+    wg_mma_step<TM, TN, A_ROWB, B_ROWB, 0>(sbase, a_tr, b_tr, acc);
+    wg_mma_step<TM, TN, A_ROWB, B_ROWB, (ABL & 4) ? 0 : 1>(sbase, a_tr, b_tr, acc);
+    wg_mma_step<TM, TN, A_ROWB, B_ROWB, (ABL & 4) ? 0 : 2>(sbase, a_tr, b_tr, acc);
+    wg_mma_step<TM, TN, A_ROWB, B_ROWB, (ABL & 4) ? 0 : 3>(sbase, a_tr, b_tr, acc);
     __builtin_amdgcn_s_setprio(0);
     if (!(ABL & 8)) wait_vmcnt<0>();
     if (!(ABL & 2)) __builtin_amdgcn_s_barrier();

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
+  const uint32_t lds0 = lds_addr_of(smem);
   const int r0 = blockIdx.y * RR;
   const int s_begin = blockIdx.x * a.strips_per_block;
   int s_end = s_begin + a.strips_per_block;
@@ -88,6 +89,29 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rr][i][j][e] = 0.f;
 
+  // one 16-pixel k-step: asm tr-reads (see tr_frag_asm: keeps the compiler from draining the DMA), MFMAs
+  auto thin_step = [&]<int KS>(uint32_t sbase) {
+    s16x8 af[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = tr_frag_asm<KS * 16 * A_ROWB, KS * 16 * A_ROWB + 4 * A_ROWB>(sbase + a_tr[i]);
+    tr_wait(af);
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      s16x8 bf[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const uint32_t lo = sbase + rr * xs_bytes + b_tr[j] + KS * pb16;
+        bf[j] = tr_frag_asm2(lo, lo + pb4);
+      }
+      tr_wait(bf);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[rr][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[rr][i][j], 0, 0, 0);
+    }
+  };
+
   auto issue = [&](int strip, int stage) {
     char* const st = smem + stage * stage_bytes;
     const int chunk = strip % a.chunks_per_row;
@@ -118,25 +142,12 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
   __builtin_amdgcn_s_barrier();
   for (int sidx = s_begin; sidx < s_end; ++sidx) {
     if (sidx + 1 < s_end) issue(sidx + 1, stage ^ 1);
-    const char* const st = smem + stage * stage_bytes;
+    const uint32_t sbase = lds0 + stage * stage_bytes;
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      s16x8 af[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = tr_frag(st + a_tr[i] + ks * 16 * A_ROWB, 4 * A_ROWB);
-#pragma unroll
-      for (int rr = 0; rr < RR; ++rr) {
-        s16x8 bf[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = tr_frag(st + rr * xs_bytes + b_tr[j] + ks * pb16, pb4);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[rr][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[rr][i][j], 0, 0, 0);
-      }
-    }
+    thin_step.template operator()<0>(sbase);
+    thin_step.template operator()<1>(sbase);
+    thin_step.template operator()<2>(sbase);
+    thin_step.template operator()<3>(sbase);
     __builtin_amdgcn_s_setprio(0);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();

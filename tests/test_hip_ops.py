@@ -76,6 +76,9 @@ CONV_CASES = [
     # head forward as a Toeplitz GEMM (4 output pixels x 8 channels per MFMA row): needs OW % 4 == 0
     ('head_toeplitz',  2, 9,  72,  64, 3,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
     ('head_toep_3x3',  1, 5,  36,  24, 7,   3, 1, 1,  PAD_ZERO,    ACT_NONE),
+    # per-filter-row weight gradient (wgrad_row.h): 3 taps share the staged dy / input row; stream-K segments
+    ('wgrad_row_refl', 1, 6,  64,  128, 256, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    ('wgrad_row_zero', 2, 5,  128, 256, 256, 3, 1, 1,  PAD_ZERO,    ACT_RELU),
 ]
 
 
