@@ -1620,7 +1620,10 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       t.x_limit = (long long)d->N * p.Hp * p.Wp * p.Cs + (long long)(kSlackBytes / 2);
       return launch_wgrad_thin(t, s);
     }
-    if (g_fast_enabled && p.Ks % 64 == 0) {
+    // the fast kernel's loader uses 32-bit element offsets
+    const bool fits32 = (long long)d->N * p.OH * p.OW * p.Ks < (1LL << 31) &&
+                        (long long)d->N * p.Hp * p.Wp * p.Cs < (1LL << 31);
+    if (g_fast_enabled && p.Ks % 64 == 0 && fits32) {
       FastWgArgs f = {};
       f.DY = reinterpret_cast<const bf16_t*>(dy);
       f.DW = dw;

@@ -207,36 +207,53 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_fast_kernel(const FastWgAr
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // Loader address arithmetic is incremental and 32-bit (element offsets < 2^31, checked on the host):
+  // with 64-bit multiplies per unit it cost 150-230 VALU slots per chunk against 8-32 MFMAs.
+  int a_off[AU], x_off[BU];
+#pragma unroll
+  for (int i = 0; i < AU; ++i) a_off[i] = (ch_begin * BKP + a_pix[i]) * a.Ks + a_soff[i];
+#pragma unroll
+  for (int i = 0; i < BU; ++i)
+    x_off[i] = ((bn[i] * a.IH + boh[i] * a.sy) * a.IW + bow[i] * a.sx) * a.Cs + b_soff[i];
+  const int tap_dh = r - a.py, tap_dw = s - a.px;
+  const int tap_off = (tap_dh * a.IW + tap_dw) * a.Cs;
+  const int row_el = a.IW * a.Cs;                        // elements per input row
+  const int adv_w = BKP * a.sx * a.Cs, wrap_w = a.OW * a.sx * a.Cs, adv_h = a.sy * row_el;
+  const int wrap_h = a.OH * a.sy * row_el - a.IH * row_el;   // leaving the last output row of an image
   int ich = ch_begin;       // next chunk to issue
   auto issue = [&](int stage) {
     char* const st = smem + stage * STAGE;
     const int pbase = ich * BKP;
 #pragma unroll
     for (int i = 0; i < AU; ++i) {
-      const int p = pbase + a_pix[i];
-      const bf16_t* src = p < a.M ? a.DY + (long long)p * a.Ks + a_soff[i] : zero;
+      const bf16_t* src = pbase + a_pix[i] < a.M ? a.DY + a_off[i] : zero;
       glds16(src, st + a_lds[i]);
+      a_off[i] += BKP * a.Ks;
     }
 #pragma unroll
     for (int i = 0; i < BU; ++i) {
-      int ih = boh[i] * a.sy + r - a.py, iw = bow[i] * a.sx + s - a.px;
+      const int ih = boh[i] * a.sy + tap_dh, iw = bow[i] * a.sx + tap_dw;
+      int off = x_off[i] + tap_off;
       bool ok = true;
       if (a.run_mode) {
         // already padded: (ih, iw) is in range by construction
       } else if (a.reflect) {
-        ih = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
-        iw = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
+        const int ih2 = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
+        const int iw2 = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
+        off += __mul24(ih2 - ih, row_el) + __mul24(iw2 - iw, a.Cs);
       } else {
         ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
       }
-      const bf16_t* src = ok ? a.X + (((long long)bn[i] * a.IH + ih) * a.IW + iw) * a.Cs + b_soff[i] : zero;
+      const bf16_t* src = ok ? a.X + off : zero;
       glds16(src, st + b_lds[i]);
       // advance the cursor by one chunk (clamped at the last pixel: its dy row is the zero page)
       if (pbase + BKP + b_pix[i] < a.M) {
         bow[i] += BKP;
+        x_off[i] += adv_w;
         while (bow[i] >= a.OW) {
           bow[i] -= a.OW;
-          if (++boh[i] == a.OH) { boh[i] = 0; ++bn[i]; }
+          x_off[i] += adv_h - wrap_w;
+          if (++boh[i] == a.OH) { boh[i] = 0; x_off[i] -= wrap_h; }
         }
       }
     }
