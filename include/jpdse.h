@@ -108,6 +108,12 @@ int jpdse_conv_fwd(const jpdse_conv_desc* d, const void* x, const void* fwd_pack
 /* dx = d(loss)/d(x) given dy = d(loss)/d(pre-activation output) */
 int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, void* dx,
                      void* ws, size_t ws_bytes, void* stream);
+/* dx = conv_dgrad(dy) * (x > 0): `x` is this conv's own INPUT [N,H,W,CPAD(C)], which must be a
+ * ReLU output (or a max-pool of one).  Equals jpdse_conv_dgrad followed by the backward of the
+ * ReLU that produced x -- the chain conv -> ReLU(inplace) -> conv of VGG19 (networks.py:477-492)
+ * -- with the mask applied in the GEMM epilogue instead of a separate pass over dx. */
+int jpdse_conv_dgrad_relu(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack,
+                          const void* x, void* dx, void* ws, size_t ws_bytes, void* stream);
 /* dw (fp32, KRSC master layout) = d(loss)/d(w); overwritten (beta = 0) */
 int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw_krsc,
                      void* ws, size_t ws_bytes, void* stream);
@@ -192,6 +198,11 @@ int jpdse_l1_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const v
 /* da = scale * (*gout) * sign(a-b) / count ; gout is a DEVICE scalar (no host sync) */
 int jpdse_l1_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b,
                  const float* gout, float scale, void* da, void* stream);
+/* as jpdse_l1_bwd when `a` is the output of a ReLU and the gradient is wanted w.r.t. its
+ * pre-activation: zero where a <= 0 (VGGLoss taps relu{1..5}_1, networks.py:124-139 -- fuses the
+ * ReLU backward of torchvision's in-place nn.ReLU into the loss gradient). */
+int jpdse_l1_bwd_relu(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b,
+                      const float* gout, float scale, void* da, void* stream);
 /* out[0] = mean (a-b)^2 (nn.MSELoss distortion: model.py:219-220) */
 int jpdse_mse_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out,
                   void* ws, size_t ws_bytes, void* stream);

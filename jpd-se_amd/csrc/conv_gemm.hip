@@ -791,7 +791,9 @@ static void phase_axis(int st, int q, int Rf, int lo, int hi, int& U, int& i0, i
 
 // Split-K factor of the fast 256x128 kernel for a GEMM of M rows, Ks output channels and k_tiles
 // 64-wide K-tiles: only when the tiles alone would leave most of the 256 CUs idle.
+static int g_splitk_enabled = 1, g_toep_enabled = 1;   // A/B switches (jpdse_debug_set_fast_path 6 / 5)
 static int splitk_for(int M, int Ks, int k_tiles) {
+  if (!g_splitk_enabled) return 1;
   if (Ks <= 64 || k_tiles < 32 || M <= 0) return 1;
   const long long tiles = (long long)((M + 255) / 256) * ((Ks + 127) / 128);
   if (tiles > 128) return 1;
@@ -1158,7 +1160,7 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
   if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
     return rc;
   const void* xin = ws;
-  if (p.toep && g_fast_enabled && p.OW % 4 == 0) {
+  if (p.toep && g_fast_enabled && g_toep_enabled && p.OW % 4 == 0) {
     // head: 4 output pixels x 8 channels per 32-wide GEMM row (see pack_fwd_toep_kernel); the [M/4][32]
     // result IS the NHWC output
     GemmFwdArgs a = {};
@@ -1218,9 +1220,24 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
   return launch_fwd<T>(a, s);
 }
 
+// dx *= (mask > 0), 16-byte vectors: the unfused form of the ReLU-masked data gradient
+template <typename T>
+__global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total_vec;
+       i += (long long)gridDim.x * blockDim.x) {
+    float v[VE], m[VE];
+    Vec16<T>::load(dx + i * VE, v);
+    Vec16<T>::load(mask + i * VE, m);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+    Vec16<T>::store(dx + i * VE, v);
+  }
+}
+
 template <typename T>
 static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx,
-                        void* ws, hipStream_t s) {
+                        void* ws, hipStream_t s, const void* mask = nullptr) {
   char* wsb = reinterpret_cast<char*>(ws);
   void* dyp = wsb;
   void* dxp = wsb + p.dypad_bytes;
@@ -1252,6 +1269,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.out_sw = p.Cs;
       h.out_base = 0;
       h.act = JPDSE_ACT_NONE;
+      h.mask = reinterpret_cast<const bf16_t*>(mask);
       return p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
     }
   }
@@ -1321,6 +1339,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         }
         g.act = JPDSE_ACT_NONE;
         g.slope = 0.f;
+        g.mask = refl ? nullptr : reinterpret_cast<const bf16_t*>(mask);
         g.splits = nlive_phases == 1 ? splitk_for(g.M, p.Cs, f.Uh * f.Uw * p.Ks / 64) : 1;
         g.partial = reinterpret_cast<float*>(wsb + p.splitk_off);
         batch.p[batch.n++] = g;
@@ -1374,6 +1393,13 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
                        reinterpret_cast<const T*>(dxp), reinterpret_cast<T*>(dx), d->N, d->H, d->W, p.Cs, d->pad,
                        total_vec);
     rc = check_launch("reflect_fold_kernel");
+  }
+  if (rc == JPDSE_OK && mask != nullptr && !(fast && !refl)) {
+    const int VE = 16 / (int)sizeof(T);
+    const long long total_vec = (long long)d->N * d->H * d->W * (p.Cs / VE);
+    hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, reinterpret_cast<T*>(dx),
+                       reinterpret_cast<const T*>(mask), total_vec);
+    rc = check_launch("relu_mask_kernel");
   }
   return rc;
 }
@@ -1709,7 +1735,9 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_fast_enabled = enable != 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
-  g_wgrad_row_enabled = enable != 4;  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
+  g_wgrad_row_enabled = enable != 4;
+  g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
+  g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
   g_wgrad_abl = enable >= 200 ? enable - 200 : 0;   // 200+bits: fast wgrad timing ablations   // 100+bits: halo kernel timing ablations (wrong results)
   return JPDSE_OK;
 }
@@ -1889,6 +1917,19 @@ int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad
   if (ws == nullptr || ws_bytes < need) return set_error(JPDSE_EWORKSPACE, "conv_dgrad: workspace %zu < %zu", ws_bytes, need);
   return d->dtype == JPDSE_BF16 ? conv_dgrad_t<bf16_t>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream))
                                 : conv_dgrad_t<float>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream));
+}
+
+int jpdse_conv_dgrad_relu(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, const void* x, void* dx,
+                          void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(dy && dgrad_pack && dx && x, "conv_dgrad_relu: null pointer");
+  ConvPlan p;
+  make_plan(d, &p);
+  const size_t need = jpdse_conv_workspace_size(d);
+  if (ws == nullptr || ws_bytes < need)
+    return set_error(JPDSE_EWORKSPACE, "conv_dgrad_relu: workspace %zu < %zu", ws_bytes, need);
+  return d->dtype == JPDSE_BF16 ? conv_dgrad_t<bf16_t>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x)
+                                : conv_dgrad_t<float>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x);
 }
 
 int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,

@@ -344,9 +344,11 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict
   if (threadIdx.x == 0) out[0] = t * inv_count;
 }
 
+// relu_a: `a` is a ReLU output and the gradient is wanted w.r.t. the PRE-activation (masked where a <= 0)
 template <typename T, int MODE>
 __global__ void loss_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, float target, int cs,
-                                const float* __restrict__ gout, float scale, T* __restrict__ da, long long total) {
+                                const float* __restrict__ gout, float scale, T* __restrict__ da, long long total,
+                                int relu_a) {
   constexpr int VE = Vec16<T>::N;
   const float g = gout[0] * scale;
   if (MODE == RED_MSE_CONST) {
@@ -365,8 +367,10 @@ __global__ void loss_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
         const float d = x[e] - y[e];
+        const bool dead = relu_a && !(x[e] > 0.f);
         if (MODE == RED_L1) x[e] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
         else x[e] = 2.f * d * g;
+        if (dead) x[e] = 0.f;
       }
       Vec16<T>::store(da + idx * VE, x);
     }
@@ -654,15 +658,15 @@ static int loss_fwd(const char* name, int dtype, long long total, long long coun
 
 template <int MODE>
 static int loss_bwd(const char* name, int dtype, long long total, long long count, const void* a, const void* b,
-                    float target, int cs, const float* gout, float scale, void* da, void* stream) {
+                    float target, int cs, const float* gout, float scale, void* da, void* stream, int relu_a = 0) {
   JPDSE_REQUIRE(!bad_dtype(dtype) && a && gout && da && total > 0 && count > 0, "%s: bad argument", name);
   const float sc = scale / (float)count;
   if (dtype == JPDSE_BF16)
     hipLaunchKernelGGL((loss_bwd_kernel<bf16_t, MODE>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
-                       cptr<bf16_t>(a), cptr<bf16_t>(b), target, cs, gout, sc, mptr<bf16_t>(da), total);
+                       cptr<bf16_t>(a), cptr<bf16_t>(b), target, cs, gout, sc, mptr<bf16_t>(da), total, relu_a);
   else
     hipLaunchKernelGGL((loss_bwd_kernel<float, MODE>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
-                       cptr<float>(a), cptr<float>(b), target, cs, gout, sc, mptr<float>(da), total);
+                       cptr<float>(a), cptr<float>(b), target, cs, gout, sc, mptr<float>(da), total, relu_a);
   return check_launch(name);
 }
 
@@ -689,6 +693,13 @@ int jpdse_l1_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const v
   if (int rc = vec_count("l1_bwd", dtype, n, &tv)) return rc;
   JPDSE_REQUIRE(b != nullptr, "l1_bwd: null b");
   return loss_bwd<RED_L1>("l1_bwd", dtype, tv, count, a, b, 0.f, 0, gout, scale, da, stream);
+}
+int jpdse_l1_bwd_relu(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, const float* gout,
+                      float scale, void* da, void* stream) {
+  long long tv;
+  if (int rc = vec_count("l1_bwd_relu", dtype, n, &tv)) return rc;
+  JPDSE_REQUIRE(b != nullptr, "l1_bwd_relu: null b");
+  return loss_bwd<RED_L1>("l1_bwd_relu", dtype, tv, count, a, b, 0.f, 0, gout, scale, da, stream, 1);
 }
 int jpdse_mse_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out, void* ws,
                   size_t ws_bytes, void* stream) {

@@ -39,6 +39,8 @@ struct FastArgs {
   // `partial` ([splits][M][Ks]); splitk_finish_kernel sums the slabs in a fixed order (deterministic).
   int splits;
   float* partial;
+  // optional fused ReLU backward: Y is zeroed where mask <= 0 (mask has Y's addressing: the conv's input)
+  const bf16_t* mask;
 };
 
 // Up to 4 independent problems in one launch (the stride-2 sub-pixel phases of a data gradient /
@@ -91,6 +93,18 @@ __device__ __forceinline__ void acc_tile_to_lds(char* tile, int pitch, int wrow0
       }
     }
   }
+}
+
+// 8 bf16 values of `v` zeroed where the matching value of `m` is <= 0 (or NaN)
+__device__ __forceinline__ u32x4 relu_mask8(u32x4 v, u32x4 m) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t lo = m[i] & 0xffffu, hi = m[i] >> 16;
+    const uint32_t klo = (lo - 1u) < 0x7f80u ? 0xffffu : 0u;          // 0 < bits <= +inf
+    const uint32_t khi = (hi - 1u) < 0x7f80u ? 0xffff0000u : 0u;
+    v[i] &= (klo | khi);
+  }
+  return v;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -315,7 +329,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     const int row = idx / VPR, v = idx - row * VPR;
     const long long off = row_off[row];
     if (off < 0 || n0 + v * 8 >= a.Ks) continue;
-    *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
+    u32x4 val = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
+    if (a.mask != nullptr) val = relu_mask8(val, *reinterpret_cast<const u32x4*>(a.mask + off + n0 + v * 8));
+    *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = val;
   }
 }
 
@@ -343,6 +359,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const FastArgs a, lo
     const bool live = col < a.Kout;
     const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
     o[e] = live ? apply_act(acc[e] + bv, a.act, a.slope) : 0.f;
+  }
+  if (a.mask != nullptr) {
+    float mk[8];
+    Vec16<bf16_t>::load(a.mask + off + c0, mk);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = mk[e] > 0.f ? o[e] : 0.f;
   }
   Vec16<bf16_t>::store(a.Y + off + c0, o);
 }

@@ -376,7 +376,7 @@ class Pix2PixHDModel(BaseModel):
       ops.channel_copy(d_in, self.label_nc, d_fake, 0, fake.C)
     if w_vgg != 0.0 and state['v_ctx'] is not None:
       wk = networks.VGGLoss.weights
-      dmaps = [ops.l1_bwd(state['vf'][k], state['vr'][k], one, w_vgg * wk[k]) for k in range(len(wk))]
+      dmaps = [ops.l1_bwd(state['vf'][k], state['vr'][k], one, w_vgg * wk[k], relu_a=True) for k in range(len(wk))]
       dv = self.criterionVGG.vgg.bwd(state['v_ctx'], dmaps)
       d_fake = dv if d_fake is None else ops.add_(d_fake, dv)
     if w_dist != 0.0:

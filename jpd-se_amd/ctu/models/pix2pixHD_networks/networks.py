@@ -389,7 +389,11 @@ class Vgg19(nn.Module):
     return maps, ctxs
 
   def bwd(self, ctxs, dmaps):
-    """Gradient w.r.t. the input image given gradients of the five taps (dgrad only)."""
+    """Gradient w.r.t. the input image given the gradients of the five taps (dgrad only).
+    Every ReLU backward is fused: `dmaps` must already be masked by their tap's ReLU
+    (ops.l1_bwd(..., relu_a=True)), and each conv's data gradient is masked by its own input
+    (a ReLU output or the max-pool of one) in the GEMM epilogue, so the gradient that reaches a
+    conv is always w.r.t. its pre-activation."""
     order, ci = [], 0
     for item in VGG_CFG:
       order.append(('M', None) if item == 'M' else ('C', ci))
@@ -408,7 +412,7 @@ class Vgg19(nn.Module):
         (x,) = ctxs[pos].items
         d = ops.maxpool2_bwd(x, d)
       else:
-        d = self.convs[ci].bwd(ctxs[pos], d, True, False)
+        d = self.convs[ci].bwd(ctxs[pos], d, True, False, dy_is_dz=True, relu_input=ci > 0)
     return d
 
   def forward(self, X):

@@ -57,6 +57,7 @@ SIGNATURES = {
     'jpdse_conv_workspace_size': (_SZ, [_CD]),
     'jpdse_conv_fwd': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_conv_dgrad_relu': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_wgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_convT_fwd': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_convT_dgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     'jpdse_loss_workspace_size': (_SZ, [_I64]),
     'jpdse_l1_fwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_l1_bwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),
+    'jpdse_l1_bwd_relu': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),
     'jpdse_mse_fwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_mse_bwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),
     'jpdse_mse_const_fwd': (_I32, [_I32, _I64, _I32, _F, _P, _P, _P, _SZ, _P]),

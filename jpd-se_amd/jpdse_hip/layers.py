@@ -135,7 +135,10 @@ class HipConv2d(nn.Module):
     y = ops.conv_fwd(d, x, fwd_pack, self.bias if self.apply_bias else None)
     return y, Ctx(x, y if self.act != ACT_NONE else None)
 
-  def bwd(self, ctx, dy, need_dx=True, need_dw=True):
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True, dy_is_dz=False, relu_input=False):
+    """dy_is_dz: dy is already the gradient w.r.t. the PRE-activation (the caller fused this layer's
+    activation backward upstream); relu_input: the layer's input is a ReLU output and the returned dx
+    is wanted w.r.t. that ReLU's pre-activation (mask fused into the data-gradient epilogue)."""
     fwd_pack, dgrad_pack = self.packs()
     need_dw = need_dw and self.weight.requires_grad
     if self.transposed:
@@ -148,7 +151,7 @@ class HipConv2d(nn.Module):
       return ops.conv_fwd(d, dy, fwd_pack, None) if need_dx else None
     x, y = ctx.items
     d = self._desc(x.N, x.H, x.W)
-    dz = dy if self.act == ACT_NONE else ops.act_bwd(y, dy, self.act, self.slope)
+    dz = dy if (self.act == ACT_NONE or dy_is_dz) else ops.act_bwd(y, dy, self.act, self.slope)
     if need_dw:
       ops.conv_wgrad(d, x, dz, self._wgrad_buffer())
       store = self._bgrad_buffer()
@@ -157,7 +160,7 @@ class HipConv2d(nn.Module):
         if self.bias.grad.data_ptr() != store.data_ptr():
           self.bias.grad.copy_(store[:self.cout])   # .grad re-homed into a DDP bucket view
       self._fire()
-    return ops.conv_dgrad(d, dz, dgrad_pack) if need_dx else None
+    return ops.conv_dgrad(d, dz, dgrad_pack, relu_input=x if relu_input else None) if need_dx else None
 
   def _fire(self):
     if self.grad_ready_hook is not None:

@@ -114,9 +114,15 @@ def conv_fwd(d, x, fwd_pack, bias, out=None):
   return y
 
 
-def conv_dgrad(d, dy, dgrad_pack):
+def conv_dgrad(d, dy, dgrad_pack, relu_input=None):
+  """relu_input: the conv's own input x when it is a ReLU output -- dx is then masked where x <= 0
+  (the ReLU backward fused into the GEMM epilogue)."""
   dx = Act.empty(d.N, d.H, d.W, d.C, d.dtype, dy.t.device)
   ws, n = _conv_ws(d, dy.t.device)
+  if relu_input is not None:
+    check(lib().jpdse_conv_dgrad_relu(ctypes.byref(d), _p(dy.t), _p(dgrad_pack), _p(relu_input.t), _p(dx.t), _p(ws),
+                                      ws.numel(), _stream()), 'conv_dgrad_relu')
+    return dx
   check(lib().jpdse_conv_dgrad(ctypes.byref(d), _p(dy.t), _p(dgrad_pack), _p(dx.t), _p(ws), ws.numel(), _stream()),
         'conv_dgrad')
   return dx
@@ -252,10 +258,12 @@ def l1_fwd(a, b, out):
   check(lib().jpdse_l1_fwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(out), _p(ws), ws.numel(), _stream()), 'l1_fwd')
 
 
-def l1_bwd(a, b, gout, scale):
+def l1_bwd(a, b, gout, scale, relu_a=False):
+  """relu_a: `a` is a ReLU output; return the gradient w.r.t. its pre-activation."""
   da = a.empty_like()
   count = a.N * a.H * a.W * a.C
-  check(lib().jpdse_l1_bwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(gout), scale, _p(da.t), _stream()), 'l1_bwd')
+  fn = lib().jpdse_l1_bwd_relu if relu_a else lib().jpdse_l1_bwd
+  check(fn(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(gout), scale, _p(da.t), _stream()), 'l1_bwd')
   return da
 
 

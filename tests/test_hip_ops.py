@@ -126,6 +126,52 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
   assert_close(layer.bias.grad.cpu(), br.grad, 2 * tol, name + ' bias grad')
 
 
+# conv -> ReLU(inplace) -> conv chains (VGG19): the second conv's data gradient with the ReLU backward fused
+# (jpdse_conv_dgrad_relu), on the halo, fast (merged stride phases), split-K and generic paths
+FUSED_RELU_CASES = [
+    ('halo_64to128',  1, 8,  64, 64,  128, 3, 1, 1, PAD_ZERO),
+    ('halo_128to64',  2, 4,  64, 128, 64,  3, 1, 1, PAD_ZERO),
+    ('fast_s2',       1, 24, 40, 64,  128, 3, 2, 1, PAD_ZERO),
+    ('splitk',        1, 10, 24, 256, 256, 3, 1, 1, PAD_ZERO),
+    ('generic_small', 2, 9,  11, 16,  24,  3, 1, 1, PAD_ZERO),
+    ('reflect',       1, 12, 20, 64,  64,  3, 1, 1, PAD_REFLECT),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', FUSED_RELU_CASES, ids=[c[0] for c in FUSED_RELU_CASES])
+def test_conv_dgrad_fused_relu(case, dtype):
+  name, N, H, W, C, K, k, st, pad, mode = case
+  g = G(hash(name) % 1000 + 7)
+  z = quantize_like(torch.randn(N, C, H, W, generator=g), dtype)      # pre-activation of the previous layer
+  w = torch.randn(K, C, k, k, generator=g) * (1.0 / (C * k * k) ** 0.5)
+  layer = HipConv2d(C, K, k, st, pad, mode, act=ACT_NONE, apply_bias=False, dtype=dtype, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(w)
+  zr = z.clone().requires_grad_(True)
+  wr = quantize_like(w, dtype)
+  y_ref = _torch_conv(F.relu(zr), wr, None, st, pad, mode, ACT_NONE)
+  gy = quantize_like(torch.randn(y_ref.shape, generator=g), dtype)
+  y_ref.backward(gy)
+  x = to_act(F.relu(z), dtype)
+  y, ctx = layer.fwd(x)
+  dz = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False, relu_input=True)
+  torch.cuda.synchronize()
+  assert_close(to_nchw(dz), zr.grad, 2 * RTOL[dtype], name + ' dgrad with fused ReLU mask')
+  assert (to_nchw(dz)[z <= 0] == 0).all()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_l1_bwd_relu_mask(dtype):
+  g = G(91)
+  a = quantize_like(F.relu(torch.randn(2, 24, 5, 7, generator=g)), dtype)
+  b = quantize_like(F.relu(torch.randn(2, 24, 5, 7, generator=g)), dtype)
+  one = torch.ones(1, dtype=torch.float32, device=DEV)
+  da = ops.l1_bwd(to_act(a, dtype), to_act(b, dtype), one, 3.0, relu_a=True)
+  ref = 3.0 * torch.sign(a - b) / a.numel() * (a > 0)
+  assert_close(to_nchw(da), ref, RTOL[dtype], 'l1 backward with ReLU mask')
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(2, 128, 64, 5, 7), (1, 1024, 512, 2, 4), (1, 24, 12, 3, 5)])
 def test_conv_transpose(shape, dtype):

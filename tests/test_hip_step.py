@@ -253,8 +253,13 @@ def test_bf16_full_width_fast_kernels_in_situ():
 
   bf16 has no reference counterpart.  Yardsticks, all on the same weights/batch:
     (1) losses within 2 % of the fp32 oracle;
-    (2) the fast kernels against the generic bf16 kernels (same rounding points, different
-        summation order): every weight gradient cosine > 0.995;
+    (2) the fast kernels WITHOUT split-K (debug mode 6: same rounding points and the same K order as the
+        generic kernels -- on single convs they are bit-identical) against the generic bf16 kernels:
+        every weight gradient cosine > 0.995.  With split-K (the default at this size) 0.04 % of a
+        conv's outputs move by one bf16 ulp (scripts/diag_splitk.py), and that alone decorrelates the
+        deep gradients to cosine ~0.95 between two equally valid bf16 runs (scripts/
+        diag_fast_vs_generic.py: both are at 0.897 from fp32): the default path is therefore held to
+        "as close to fp32 as the generic kernels, minus 0.02";
     (3) against the fp32 oracle the gradients are only as faithful as bf16 STORAGE of activations and
         activation gradients allows (ReLU-mask / L1-sign flips; measured cosine 0.90-0.92 in the deep
         layers at random init).  The oracle's bf16-storage emulation (oracle.ctu_cpu.nets.storage_bf16)
@@ -290,14 +295,16 @@ def test_bf16_full_width_fast_kernels_in_situ():
 
   cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
   g_fast, L = run(1)
+  g_nosplit, _ = run(6)
   g_gen, _ = run(0)
   for k in omodel.LOSS_NAMES:
     assert abs(L[k] - ora.last_losses[k]) <= 2e-2 * max(abs(ora.last_losses[k]), 1e-3), (k, L[k], ora.last_losses[k])
   for k, a in g_fast.items():
     ref, emu = gG[k].double().flatten(), eG[k].double().flatten()
-    c_kernels = cos(a, g_gen[k])
-    c_ref, c_emu = cos(a, ref), cos(emu, ref)
-    assert c_kernels > 0.995, '%s: fast vs generic bf16 kernels cosine %.5f' % (k, c_kernels)
+    c_kernels = cos(g_nosplit[k], g_gen[k])
+    c_ref, c_emu, c_gen = cos(a, ref), cos(emu, ref), cos(g_gen[k], ref)
+    assert c_kernels > 0.995, '%s: fast (no split-K) vs generic bf16 kernels cosine %.5f' % (k, c_kernels)
+    assert c_ref >= c_gen - 0.02, '%s: default path vs fp32 %.4f, generic kernels vs fp32 %.4f' % (k, c_ref, c_gen)
     assert c_ref >= c_emu - 0.03, '%s: HIP bf16 vs fp32 %.4f, bf16-storage emulation vs fp32 %.4f' % (k, c_ref, c_emu)
     assert abs(float(a.norm() / ref.norm()) - 1.0) < 5e-2, k
 
