@@ -225,6 +225,8 @@ typedef struct jpdse_adam_entry {
   float* v;       /* exp_avg_sq */
   int64_t n;      /* elements */
   int64_t block0; /* first 1024-element block of this tensor in the launch */
+  void* cast_bf16; /* optional: bf16 copy of the UPDATED parameter, same element order (the forward
+                    * GEMM panel of a conv whose panel is a plain cast of the KRSC master); NULL = none */
 } jpdse_adam_entry;
 int jpdse_adam_step(const jpdse_adam_entry* table, int32_t n_entries, int64_t total_blocks,
                     float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,

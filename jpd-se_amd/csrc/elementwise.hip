@@ -408,6 +408,13 @@ __global__ __launch_bounds__(256) void adam_kernel(const jpdse_adam_entry* __res
     *reinterpret_cast<f32x4*>(e.p + base) = p;
     *reinterpret_cast<f32x4*>(e.m + base) = m;
     *reinterpret_cast<f32x4*>(e.v + base) = v;
+    if (e.cast_bf16 != nullptr) {
+      uint32_t w0 = (uint32_t)f2bf(p[0]) | ((uint32_t)f2bf(p[1]) << 16);
+      uint32_t w1 = (uint32_t)f2bf(p[2]) | ((uint32_t)f2bf(p[3]) << 16);
+      uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(e.cast_bf16) + base);
+      out[0] = w0;
+      out[1] = w1;
+    }
   } else {
     for (long long i = base; i < base + 4 && i < e.n; ++i) {
       const float gi = e.g[i] * grad_scale;
@@ -415,7 +422,9 @@ __global__ __launch_bounds__(256) void adam_kernel(const jpdse_adam_entry* __res
       const float v = beta2 * e.v[i] + (1.f - beta2) * gi * gi;
       e.m[i] = m;
       e.v[i] = v;
-      e.p[i] -= lr_over_bc1 * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+      const float pn = e.p[i] - lr_over_bc1 * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+      e.p[i] = pn;
+      if (e.cast_bf16 != nullptr) reinterpret_cast<bf16_t*>(e.cast_bf16)[i] = f2bf(pn);
     }
   }
 }

@@ -34,7 +34,8 @@ class InormDesc(ctypes.Structure):
 
 class AdamEntry(ctypes.Structure):
   _fields_ = [('p', ctypes.c_void_p), ('g', ctypes.c_void_p), ('m', ctypes.c_void_p),
-              ('v', ctypes.c_void_p), ('n', ctypes.c_int64), ('block0', ctypes.c_int64)]
+              ('v', ctypes.c_void_p), ('n', ctypes.c_int64), ('block0', ctypes.c_int64),
+              ('cast_bf16', ctypes.c_void_p)]
 
 
 _P, _I32, _I64, _F, _SZ = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float,

@@ -26,6 +26,10 @@ def bump_weights_epoch():
   _weights_epoch[0] += 1
 
 
+def current_weights_epoch():
+  return _weights_epoch[0]
+
+
 class Ctx(object):
   """Saved tensors of one layer call; every entry is batch-first so a sub-batch can be
   back-propagated on its own (used for the fake half of the batched discriminator pass)."""
@@ -93,13 +97,24 @@ class HipConv2d(nn.Module):
         'master weights must be fp32 channels_last (KRSC)'
     return w
 
+  def _plain_fwd_panel(self):
+    """True when the forward panel is an element-for-element bf16 cast of the KRSC master (no channel or
+    chunk padding, no Toeplitz extra) -- then the fused Adam kernel can write it."""
+    C, K = (self.cout, self.cin) if self.transposed else (self.cin, self.cout)
+    return self.cdtype == BF16 and C % 8 == 0 and K % 8 == 0 and (self.k * C) % 32 == 0 and K > 8
+
   def packs(self):
     w = self._master()
-    key = (w._version, _weights_epoch[0], w.data_ptr(), self.cdtype)
+    wver = getattr(w, '_jpdse_wver', 0)        # bumped by FusedAdam for the tensors it updated
+    key = (w._version, _weights_epoch[0], w.data_ptr(), self.cdtype, wver)
     if self._pack_key != key:
       d = self._desc(1, 64, 64)   # pack layout does not depend on N,H,W
       if self._packs is None or self._pack_key[3] != self.cdtype:
         self._packs = ops.conv_pack(d, w, w.device)
+        w._jpdse_cast_out = self._packs[0] if self._plain_fwd_panel() else None
+      elif (getattr(w, '_jpdse_cast_out', None) is self._packs[0] and
+            getattr(w, '_jpdse_cast_wver', None) == wver and self._pack_key[:4] == key[:4]):
+        ops.conv_pack_into(d, w, None, self._packs[1])      # forward panel written by the Adam kernel
       else:
         ops.conv_pack_into(d, w, self._packs[0], self._packs[1])
       self._pack_key = key

@@ -50,8 +50,12 @@ class FusedAdam(torch.optim.Optimizer):
       if not (g.stride() == p.stride() and m.stride() == p.stride() and v.stride() == p.stride()):
         raise RuntimeError('FusedAdam: param/grad/state strides differ')
       n = p.numel()
-      entries.append(AdamEntry(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, block0))
-      sig.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()))
+      # conv layers whose forward GEMM panel is a plain bf16 cast of the master (layers.HipConv2d) let the
+      # Adam kernel write it: saves the separate cast pass over the weights
+      cast = getattr(p, '_jpdse_cast_out', None)
+      cast_ptr = cast.data_ptr() if cast is not None else None
+      entries.append(AdamEntry(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, block0, cast_ptr))
+      sig.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), cast_ptr))
       block0 += (n + 1023) // 1024
     return entries, tuple(sig), block0
 
@@ -80,5 +84,12 @@ class FusedAdam(torch.optim.Optimizer):
                                   float(b1), float(b2), float(group['eps']), int(step_t.item()),
                                   float(self.grad_scale),
                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'adam_step')
-    bump_weights_epoch()
+    # the kernel updates the masters outside torch's version counter: bump a per-parameter counter
+    # (layers.HipConv2d.packs keys its packed GEMM panels on it), only for the tensors that moved
+    for group in self.param_groups:
+      for p in group['params']:
+        if p.grad is not None:
+          p._jpdse_wver = getattr(p, '_jpdse_wver', 0) + 1
+          if getattr(p, '_jpdse_cast_out', None) is not None:
+            p._jpdse_cast_wver = p._jpdse_wver      # forward panel already holds the updated weights
     return None

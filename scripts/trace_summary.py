@@ -1,7 +1,7 @@
 """Summarise a rocprofv3 kernel trace: last full train step, grouped by kernel and grid."""
 import csv, collections, sys, glob
 path = sys.argv[1]
-rows = list(csv.DictReader(open(glob.glob(path + '/*/*_kernel_trace.csv')[0])))
+rows = list(csv.DictReader(open((glob.glob(path + '/*/*_kernel_trace.csv') + glob.glob(path + '/*_kernel_trace.csv'))[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 adam = [i for i, n in enumerate(names) if 'adam_kernel' in n]

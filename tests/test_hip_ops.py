@@ -361,6 +361,11 @@ def test_fused_adam_matches_torch():
     if q.dim() == 4:
       q = q.contiguous(memory_format=torch.channels_last)
     mine.append(torch.nn.Parameter(q))
+  # fused bf16 copy of the updated parameter (the forward GEMM panel of plain conv layers); ragged tail too
+  casts = {0: torch.zeros(mine[0].numel(), dtype=torch.bfloat16, device=DEV),
+           2: torch.zeros(mine[2].numel(), dtype=torch.bfloat16, device=DEV)}
+  for i, c in casts.items():
+    mine[i]._jpdse_cast_out = c
   o_ref = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
   o_hip = FusedAdam(mine, lr=2e-4, betas=(0.5, 0.999))
   for step in range(3):
@@ -374,5 +379,10 @@ def test_fused_adam_matches_torch():
     o_hip.step()
   for r, m in zip(ref, mine):
     assert_close(m.detach().cpu(), r.detach(), 1e-6, 'adam param')
+  for i, c in casts.items():
+    m = mine[i].detach()
+    flat = m.permute(0, 2, 3, 1).reshape(-1) if m.dim() == 4 else m.reshape(-1)     # memory (KRSC) order
+    assert torch.equal(c, flat.bfloat16()), 'fused bf16 cast of the updated parameter'
+    assert mine[i]._jpdse_cast_wver == mine[i]._jpdse_wver == 3
   sd = o_hip.state_dict()
   assert set(sd['state'][0].keys()) >= {'step', 'exp_avg', 'exp_avg_sq'} and float(sd['state'][0]['step']) == 3.0
