@@ -975,6 +975,8 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   bool timed = g_prof.on && (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   for (int i = 0; i < b.n; ++i) {
     const FastArgs& a = b.p[i];
+    if ((a.Y == nullptr && !a.no_finish) || ((a.splits > 1 || a.no_finish) && a.partial == nullptr))
+      return set_error(JPDSE_EINVAL, "gemm_fast: problem %d has no output buffer", i);
     b.first_tile[i] = total;
     total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN) * (a.splits > 1 ? a.splits : 1);
     const long long kdim = (long long)a.R * a.S * a.Cs;
@@ -984,7 +986,7 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   for (int i = b.n; i < 5; ++i) b.first_tile[i] = total;
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
   hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN, VAR, STAGES>), dim3(total), dim3(64 * WM * WN), lds, s, b);
-  if (b.n == 1 && b.p[0].splits > 1) {
+  if (b.n == 1 && b.p[0].splits > 1 && !b.p[0].no_finish) {
     const long long total_vec = (long long)b.p[0].M * (b.p[0].Ks / 8);
     hipLaunchKernelGGL(splitk_finish_kernel, dim3(ew_blocks(total_vec)), dim3(256), 0, s, b.p[0], total_vec);
   }
@@ -1011,7 +1013,7 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   const int Ks = b.p[0].Ks;
   if (b.n == 1 && b.p[0].splits > 1) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // split-K: 256 x 128 only
   for (int i = 0; i < b.n; ++i)
-    if (b.n > 1) b.p[i].splits = 1;
+    if (b.n > 1 && !b.p[i].no_finish) b.p[i].splits = 1;
   if (b.n == 1 && prefer_320(b.p[0].M, Ks)) return launch_fast_cfg<2, 4, 5, 1, 0, 2>(b, s);   // 320 x 128, 2 stages
   if (Ks > 64) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // 256 x 128
   if (Ks > 32) return launch_fast_cfg<4, 2, 2, 1, 0>(b, s);   // 256 x 64
@@ -1048,6 +1050,7 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
 }
 
 static int g_wgrad_abl = 0;
+static int g_ring_enabled = 1;
 static int g_halo_enabled = 1;
 static int g_halo_abl = 0;
 
@@ -1220,6 +1223,70 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
   return launch_fwd<T>(a, s);
 }
 
+// Reflect-padded 3x3 stride-1 data gradient = zero-padded data gradient (halo kernel, written to dx)
+// + the ring of the padded domain folded back: padded row -1 -> image row 1, row H -> H-2, column -1 -> 1,
+// column W -> W-2.  The four ring strips are small split-K GEMMs (fp32 slabs, FastArgs::no_finish); this
+// kernel sums their slabs and adds them into dx.  One thread = 8 channels of one target pixel; targets are
+// enumerated without duplicates: rows {1, H-2} completely, columns {1, W-2} without those two rows.
+struct RingFoldArgs {
+  bf16_t* dx;
+  const float* top; const float* bot; const float* left; const float* right;   // slabs [splits][M_q][Cs]
+  int splits_tb, splits_lr;
+  int N, H, W, Cs;
+};
+__device__ __forceinline__ void ring_acc(float (&acc)[8], const float* slab, int splits, long long slab_elems,
+                                         long long row, int Cs, int c0) {
+  for (int sp = 0; sp < splits; ++sp) {
+    const float4* src = reinterpret_cast<const float4*>(slab + sp * slab_elems + row * Cs + c0);
+    const float4 lo = src[0], hi = src[1];
+    acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w;
+    acc[4] += hi.x; acc[5] += hi.y; acc[6] += hi.z; acc[7] += hi.w;
+  }
+}
+__global__ __launch_bounds__(256) void ring_fold_kernel(const RingFoldArgs a, long long total_vec) {
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= total_vec) return;
+  const int cv = a.Cs >> 3;
+  const int c0 = (int)(v % cv) * 8;
+  long long t = v / cv;
+  const int per_n = 2 * a.W + 2 * (a.H - 2);
+  const int n = (int)(t / per_n);
+  int e = (int)(t - (long long)n * per_n);
+  const long long Mtb = (long long)a.N * (a.W + 2), Mlr = (long long)a.N * a.H;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  int i_row, j_col;
+  if (e < 2 * a.W) {                      // row targets
+    const bool is_top = e < a.W;
+    const int j = is_top ? e : e - a.W;
+    i_row = is_top ? 1 : a.H - 2;
+    j_col = j;
+    const float* slab = is_top ? a.top : a.bot;
+    const long long rb = (long long)n * (a.W + 2);
+    ring_acc(acc, slab, a.splits_tb, Mtb * a.Cs, rb + j + 1, a.Cs, c0);
+    if (j == 1) ring_acc(acc, slab, a.splits_tb, Mtb * a.Cs, rb, a.Cs, c0);                  // corner b = 0
+    if (j == a.W - 2) ring_acc(acc, slab, a.splits_tb, Mtb * a.Cs, rb + a.W + 1, a.Cs, c0);  // corner b = W+1
+    if (j == 1) ring_acc(acc, a.left, a.splits_lr, Mlr * a.Cs, (long long)n * a.H + i_row, a.Cs, c0);
+    if (j == a.W - 2) ring_acc(acc, a.right, a.splits_lr, Mlr * a.Cs, (long long)n * a.H + i_row, a.Cs, c0);
+  } else {                                // column targets, rows other than 1 and H-2
+    e -= 2 * a.W;
+    const bool is_left = e < a.H - 2;
+    int i = is_left ? e : e - (a.H - 2);  // index into the H-2 remaining rows
+    i = i == 0 ? 0 : i + 1;               // rows 0, 2, 3, ..., H-3, H-1
+    if (i >= a.H - 2) i += 1;
+    i_row = i;
+    j_col = is_left ? 1 : a.W - 2;
+    ring_acc(acc, is_left ? a.left : a.right, a.splits_lr, Mlr * a.Cs, (long long)n * a.H + i, a.Cs, c0);
+  }
+  bf16_t* dst = a.dx + (((long long)n * a.H + i_row) * a.W + j_col) * a.Cs + c0;
+  float cur[8];
+  Vec16<bf16_t>::load(dst, cur);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) cur[q] += acc[q];
+  Vec16<bf16_t>::store(dst, cur);
+}
+
 // dx *= (mask > 0), 16-byte vectors: the unfused form of the ReLU-masked data gradient
 template <typename T>
 __global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask, long long total_vec) {
@@ -1271,6 +1338,100 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.act = JPDSE_ACT_NONE;
       h.mask = reinterpret_cast<const bf16_t*>(mask);
       return p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (refl && g_ring_enabled && d->R == 3 && d->S == 3 && st == 1 && d->pad == 1 && d->H >= 8 &&
+        halo_ok(3, 3, 1, d->H, d->W, p.Ks, p.Cs) && p.ph[0].Lk == 3 * p.Ks) {
+      // (1) zero-padded data gradient straight into dx
+      HaloArgs h = {};
+      h.X = reinterpret_cast<const bf16_t*>(dy);
+      h.B = reinterpret_cast<const bf16_t*>(pack);
+      h.Y = reinterpret_cast<bf16_t*>(dx);
+      h.N = d->N;
+      h.OH = d->H;
+      h.OW = d->W;
+      h.IH = d->H;
+      h.IW = d->W;
+      h.Cs = p.Ks;
+      h.py = h.px = 1;
+      h.Kout = d->C;
+      h.Ks = p.Cs;
+      h.b_rows = p.Cs;
+      h.out_sn = (long long)d->H * d->W * p.Cs;
+      h.out_sh = (long long)d->W * p.Cs;
+      h.out_sw = p.Cs;
+      h.act = JPDSE_ACT_NONE;
+      if (int rc = p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s)) return rc;
+      // (2) the four ring strips of the reflect-padded domain as split-K GEMMs into fp32 slabs
+      const int H = d->H, W = d->W, Ks = p.Ks, Lk = p.ph[0].Lk;
+      const bf16_t* dyb = reinterpret_cast<const bf16_t*>(dy);
+      const bf16_t* pk = reinterpret_cast<const bf16_t*>(pack);
+      const int Mtb = d->N * (W + 2), Mlr = d->N * H;
+      const int nt = (p.Cs + 127) / 128;
+      const int tiles = 2 * ((Mtb + 255) / 256) * nt + 2 * ((Mlr + 255) / 256) * nt;
+      const int kt = 3 * Ks / 64;
+      int sp = 256 / tiles;
+      if (sp > kt / 8) sp = kt / 8;
+      if (sp > 8) sp = 8;
+      if (sp < 1) sp = 1;
+      float* slab = reinterpret_cast<float*>(wsb);
+      const size_t tb_elems = (size_t)sp * Mtb * p.Cs, lr_elems = (size_t)sp * Mlr * p.Cs;
+      FastBatch rb = {};
+      for (int q = 0; q < 4; ++q) {
+        FastArgs g = {};
+        const bool row_strip = q < 2;         // 0 top, 1 bottom, 2 left, 3 right
+        g.X = dyb + (q == 1 ? (long long)(H - 1) * W * Ks : (q == 3 ? (long long)(W - 1) * Ks : 0));
+        g.x_sn = (long long)H * W * Ks;
+        g.x_sh = (long long)W * Ks;
+        g.IH = row_strip ? 1 : H;
+        g.IW = row_strip ? W : 1;
+        g.Cs = Ks;
+        g.R = row_strip ? 1 : 3;
+        g.S = row_strip ? 3 : 1;
+        g.sy = g.sx = 1;
+        g.py = row_strip ? 0 : 1;
+        g.px = row_strip ? 2 : 0;
+        g.OH = row_strip ? 1 : H;
+        g.OW = row_strip ? W + 2 : 1;
+        g.M = row_strip ? Mtb : Mlr;
+        // panel [c][u'][w'][k] with u' = 2 - r, w' = 2 - s: top r=0 -> u'=2, bottom u'=0, left s=0 -> w'=2, right w'=0
+        g.B = pk + (q == 0 ? 2LL * Lk : (q == 2 ? 2LL * Ks : 0));
+        g.b_stride = 3LL * Lk;
+        g.b_tap_r = Lk;
+        g.b_tap_s = Ks;
+        g.Kout = d->C;
+        g.Ks = p.Cs;
+        g.b_rows = p.Cs;
+        g.act = JPDSE_ACT_NONE;
+        g.splits = sp;
+        g.no_finish = 1;
+        g.partial = slab + (q == 0 ? 0 : (q == 1 ? tb_elems : (q == 2 ? 2 * tb_elems : 2 * tb_elems + lr_elems)));
+        rb.p[rb.n++] = g;
+      }
+      if (int rc = launch_fast_batch(rb, s)) return rc;
+      // (3) fold the ring into rows 1 / H-2 and columns 1 / W-2 of dx
+      RingFoldArgs rf = {};
+      rf.dx = reinterpret_cast<bf16_t*>(dx);
+      rf.top = rb.p[0].partial;
+      rf.bot = rb.p[1].partial;
+      rf.left = rb.p[2].partial;
+      rf.right = rb.p[3].partial;
+      rf.splits_tb = rf.splits_lr = sp;
+      rf.N = d->N;
+      rf.H = H;
+      rf.W = W;
+      rf.Cs = p.Cs;
+      const long long tv = (long long)d->N * (2 * W + 2 * (H - 2)) * (p.Cs / 8);
+      hipLaunchKernelGGL(ring_fold_kernel, dim3(ew_blocks(tv)), dim3(256), 0, s, rf, tv);
+      int rc = check_launch("ring_fold_kernel");
+      if (rc == JPDSE_OK && mask != nullptr) {
+        const long long total_vec = (long long)d->N * H * W * (p.Cs / 8);
+        hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, reinterpret_cast<T*>(dx),
+                           reinterpret_cast<const T*>(mask), total_vec);
+        rc = check_launch("relu_mask_kernel");
+      }
+      return rc;
     }
   }
   bool fast = false;
@@ -1736,6 +1897,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_wgrad_row_enabled = enable != 4;
+  g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
   g_wgrad_abl = enable >= 200 ? enable - 200 : 0;   // 200+bits: fast wgrad timing ablations   // 100+bits: halo kernel timing ablations (wrong results)
@@ -1824,7 +1986,11 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   }
   const size_t fwd = p.xpad_bytes + dz;     // wgrad: padded x (+ tap-expanded dy for few-output-channel layers)
   const size_t dgrad = p.dypad_bytes + p.dxp_bytes;
-  const size_t sk = p.splitk_off + p.splitk_bytes;
+  size_t sk = p.splitk_off + p.splitk_bytes;
+  if (p.ES == 2 && d->pad_mode == JPDSE_PAD_REFLECT && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1) {
+    const size_t ring = (size_t)8 * d->N * (2 * (d->W + 2) + 2 * d->H) * p.Cs * 4;   // ring-strip slabs, <= 8 splits
+    sk = sk > ring ? sk : ring;
+  }
   const size_t m = fwd > dgrad ? fwd : dgrad;
   return m > sk ? m : sk;
 }

@@ -41,6 +41,12 @@ struct FastArgs {
   float* partial;
   // optional fused ReLU backward: Y is zeroed where mask <= 0 (mask has Y's addressing: the conv's input)
   const bf16_t* mask;
+  // optional generalisations (0 = the dense defaults): batch stride of X (a sub-image of a larger tensor),
+  // B row stride and B offsets per filter-row / filter-column step (a sub-panel of a larger filter panel)
+  long long x_sn, x_sh;   // batch / row strides of X in elements
+  long long b_stride;
+  int b_tap_r, b_tap_s;
+  int no_finish;       // split-K: leave the slabs to the caller (no splitk_finish_kernel)
 };
 
 // Up to 4 independent problems in one launch (the stride-2 sub-pixel phases of a data gradient /
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     int m = m0 + row;
     m = m < a.M ? m : a.M - 1;
     const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
-    a_nbase[i] = (long long)n * a.IH * a.IW * a.Cs;
+    a_nbase[i] = (long long)n * (a.x_sn ? a.x_sn : (long long)a.IH * a.IW * a.Cs);
     a_oh[i] = oh * a.sy - a.py;
     a_ow[i] = ow * a.sx - a.px;
     a_choff[i] = ((lslot ^ (row >> 1)) & 7) * 8;
@@ -163,7 +169,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   const bf16_t* b_ptr[BU];
   int b_lds[BU];
   bool b_on[BU];
-  const long long ktot = (long long)a.R * a.S * a.Cs;
+  const long long ktot = a.b_stride ? a.b_stride : (long long)a.R * a.S * a.Cs;
+  const long long x_sh = a.x_sh ? a.x_sh : (long long)a.IW * a.Cs;
+  const int b_tap_r = a.b_tap_r ? a.b_tap_r : a.S * a.Cs, b_tap_s = a.b_tap_s ? a.b_tap_s : a.Cs;
 #pragma unroll
   for (int j = 0; j < BU; ++j) {
     const int u = wid + j * NW;
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
       } else {
         ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
       }
-      a_src[i] = ok ? a.X + a_nbase[i] + ((long long)ih * a.IW + iw) * a.Cs + a_choff[i] : zero;
+      a_src[i] = ok ? a.X + a_nbase[i] + (long long)ih * x_sh + (long long)iw * a.Cs + a_choff[i] : zero;
       a_step[i] = ok ? 64 : 0;
     }
   };
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
       glds16(a_src[i], st + a_lds[i]);
       a_src[i] += a_step[i];
     }
-    const long long koff = (long long)it * 64;
+    const long long koff = (long long)ir * b_tap_r + is * b_tap_s + ic * 64;
 #pragma unroll
     for (int j = 0; j < BU; ++j)
       if (b_on[j]) glds16(b_ptr[j] + koff, st + b_lds[j]);
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   }
 
   // ---- epilogue --------------------------------------------------------------------------
-  if (a.splits > 1) {
+  if (a.splits > 1 || a.no_finish) {
     float* const slab = a.partial + (long long)split * a.M * a.Ks;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

@@ -79,6 +79,9 @@ CONV_CASES = [
     # per-filter-row weight gradient (wgrad_row.h): 3 taps share the staged dy / input row; stream-K segments
     ('wgrad_row_refl', 1, 6,  64,  128, 256, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
     ('wgrad_row_zero', 2, 5,  128, 256, 256, 3, 1, 1,  PAD_ZERO,    ACT_RELU),
+    # reflect data gradient = halo kernel on the interior + ring strips (split-K) folded back
+    ('ring_dgrad_64',  2, 8,  64,  64,  128, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    ('ring_dgrad_192', 1, 12, 128, 192, 64,  3, 1, 1,  PAD_REFLECT, ACT_NONE),
 ]
 
 
