@@ -1619,8 +1619,21 @@ static int launch_wgrad_fast(const FastWgArgs& a, hipStream_t s) {
   return launch_wgrad_fast_cfg<2, 2, 1, 1>(a, s);
 }
 
+template <int TM, int NW, int NT, int RR, int WM, int PITCH>
+static int launch_wgrad_thin_pitch(ThinWgArgs a, hipStream_t s);
+
 template <int TM, int NW, int NT, int RR = 1, int WM = 1>
-static int launch_wgrad_thin_cfg(ThinWgArgs a, hipStream_t s) {
+static int launch_wgrad_thin_cfg(const ThinWgArgs& a, hipStream_t s) {
+  switch (a.st * a.Cs) {      // the pitches of the hot path as compile-time constants
+    case 40: return launch_wgrad_thin_pitch<TM, NW, NT, RR, WM, 40>(a, s);   // 39-channel inputs, stride 1
+    case 80: return launch_wgrad_thin_pitch<TM, NW, NT, RR, WM, 80>(a, s);   // 39-channel inputs, stride 2
+    case 8: return launch_wgrad_thin_pitch<TM, NW, NT, RR, WM, 8>(a, s);     // heads (dy run operand)
+    default: return launch_wgrad_thin_pitch<TM, NW, NT, RR, WM, 0>(a, s);
+  }
+}
+
+template <int TM, int NW, int NT, int RR, int WM, int PITCH>
+static int launch_wgrad_thin_pitch(ThinWgArgs a, hipStream_t s) {
   const int pitch = a.st * a.Cs;
   a.x_units = (126 * pitch + 64 * NW * NT + 1023) / 1024;
   const int lds = 2 * (TM * WM * 64 * 64 + RR * a.x_units * 1024);
@@ -1635,7 +1648,11 @@ static int launch_wgrad_thin_cfg(ThinWgArgs a, hipStream_t s) {
   P = (a.strips_total + a.strips_per_block - 1) / a.strips_per_block;
   hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), s);
   if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR>), dim3(P, row_groups), dim3(64 * WM * NW), lds, s, a);
+  if constexpr (RR > 1) {      // heads: roles swapped, transposed output
+    hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR, PITCH, true>), dim3(P, row_groups), dim3(64 * WM * NW), lds, s, a);
+  } else {
+    hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR, PITCH, false>), dim3(P, row_groups), dim3(64 * WM * NW), lds, s, a);
+  }
   return check_launch("wgrad_thin_kernel");
 }
 

@@ -76,7 +76,11 @@ template <int N> __device__ __forceinline__ void tr_wait(s16x8 (&f)[N]) {
   else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
   else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]));
   else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
-  else static_assert(N <= 4, "tr_wait: up to 4 fragments");
+  else {      // longer lists: wait once, tie the rest to the same point
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+#pragma unroll
+    for (int i = 4; i < N; ++i) asm volatile("" : "+v"(f[i]));
+  }
 }
 
 // one 16-pixel k-step of a wave tile: TM + TN transposed fragments (asm reads), then TM*TN MFMAs

@@ -39,7 +39,9 @@ struct ThinWgArgs {
 };
 
 // TM m-tiles per wave, WM x WN waves (M = 32*TM*WM channels of the dy operand, WN*NT run tiles)
-template <int TM, int WM, int WN, int NT, int RR>
+// PITCH: st*Cs when known at compile time (the fragment offsets of the run operand become immediates: 24 fewer
+// live address registers, one more wave per SIMD), 0 = runtime
+template <int TM, int WM, int WN, int NT, int RR, int PITCH, bool TRANSPOSED>
 __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgArgs a) {
   constexpr int NW = WM * WN;
   constexpr int A_ROWB = TM * WM * 64;            // bytes per dy pixel row (Ks = 32*TM*WM channels)
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
   s_end = s_end < a.strips_total ? s_end : a.strips_total;
   if (s_begin >= s_end) return;
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-  const int pitch = a.st * a.Cs;                  // elements between consecutive output pixels' runs
+  const int pitch = PITCH ? PITCH : a.st * a.Cs;  // elements between consecutive output pixels' runs
   const int units = A_UNITS + RR * a.x_units;
 
   // transposed fragment offsets (lane roles as in wgrad_fast.h)
@@ -89,48 +91,68 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rr][i][j][e] = 0.f;
 
-  // one 16-pixel k-step: asm tr-reads (see tr_frag_asm: keeps the compiler from draining the DMA), MFMAs
-  auto thin_step = [&]<int KS>(uint32_t sbase) {
-    s16x8 af[TM];
+  // One 16-pixel k-step = TM + RR*NT transposed fragments (asm reads, see tr_frag_asm) and TM*RR*NT MFMAs.
+  // The fragments are double buffered: the reads of k-step KS+1 are issued right after the wait for
+  // k-step KS and fly while its MFMAs execute (a wait after every read group exposed the LDS latency 8
+  // times per strip: 0.60 -> 0.88 ms on the first conv).
+  auto rd_frags = [&]<int KS>(uint32_t sbase, s16x8 (&af)[TM], s16x8 (&bf)[RR * NT]) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[i] = tr_frag_asm<KS * 16 * A_ROWB, KS * 16 * A_ROWB + 4 * A_ROWB>(sbase + a_tr[i]);
-    tr_wait(af);
 #pragma unroll
-    for (int rr = 0; rr < RR; ++rr) {
-      s16x8 bf[NT];
+    for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const uint32_t lo = sbase + rr * xs_bytes + b_tr[j] + KS * pb16;
-        bf[j] = tr_frag_asm2(lo, lo + pb4);
+        if constexpr (PITCH != 0) {
+          bf[rr * NT + j] = tr_frag_asm<KS * 32 * PITCH, KS * 32 * PITCH + 8 * PITCH>(sbase + rr * xs_bytes + b_tr[j]);
+        } else {
+          const uint32_t lo = sbase + rr * xs_bytes + b_tr[j] + KS * pb16;
+          bf[rr * NT + j] = tr_frag_asm2(lo, lo + pb4);
+        }
       }
-      tr_wait(bf);
+  };
+  auto mma_frags = [&](const s16x8 (&af)[TM], const s16x8 (&bf)[RR * NT]) {
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[rr][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[rr][i][j], 0, 0, 0);
-    }
+          acc[rr][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[rr * NT + j], acc[rr][i][j], 0, 0, 0);
+  };
+  auto wait_frags = [&](s16x8 (&af)[TM], s16x8 (&bf)[RR * NT]) {
+    tr_wait(af);
+    tr_wait(bf);
   };
 
+  // lane constants of the loader (the per-unit part is wave-uniform and stays on the scalar unit)
+  const int a_pl = lane / (A_ROWB / 16);                      // pixel within a dy unit
+  const int a_lane_off = a_pl * a.Ks + (((lane % (A_ROWB / 16)) ^ trswz<A_ROWB>(a_pl)) << 3);
+  static_assert(A_PPU % 4 == 0 || A_ROWB >= 256, "swizzle must not depend on the unit index");
   auto issue = [&](int strip, int stage) {
     char* const st = smem + stage * stage_bytes;
     const int chunk = strip % a.chunks_per_row;
     const int row = strip / a.chunks_per_row;       // n*OH + oh
     const int oh = row % a.OH, n = row / a.OH;
     const int ow0 = chunk * 64;
-    const long long dy_base = ((long long)row * a.OW + ow0) * a.Ks;
+    const bf16_t* const dy_base = a.DY + ((long long)row * a.OW + ow0) * a.Ks;                       // uniform
     const long long x_base = (((long long)n * a.Hp + oh * a.st + r0) * a.Wp + (long long)ow0 * a.st) * a.Cs;
     const long long x_row = (long long)a.Wp * a.Cs;
+    const int px_left = a.OW - ow0;                  // valid output pixels from ow0 on
     for (int u = wid; u < units; u += NW) {
       const bf16_t* src;
       if (u < A_UNITS) {
-        const int pl = lane / (A_ROWB / 16), slot = lane % (A_ROWB / 16);
-        const int pix = u * A_PPU + pl;
-        src = ow0 + pix < a.OW ? a.DY + dy_base + (long long)pix * a.Ks + ((slot ^ trswz<A_ROWB>(pix)) << 3) : zero;
+        const int pix0 = u * A_PPU;                   // uniform
+        src = pix0 + a_pl < px_left ? dy_base + (pix0 * a.Ks + a_lane_off) : zero;
       } else {
-        const int ub = u - A_UNITS, rr = ub / a.x_units, uu = ub - rr * a.x_units;
-        const long long e = x_base + rr * x_row + ((long long)uu * 64 + lane) * 8;
-        src = (e + 8 <= a.x_limit && r0 + rr < a.R) ? a.XP + e : zero;
+        const int ub = u - A_UNITS;
+        int rr = 0, uu = ub;
+        if constexpr (RR > 1) {       // wave-uniform; RR == 1 keeps the division out of the loader
+          rr = ub / a.x_units;
+          uu = ub - rr * a.x_units;
+        }
+        const long long e0 = x_base + rr * x_row + (long long)uu * 512;   // uniform: first element of the unit
+        const bool row_ok = r0 + rr < a.R;
+        src = (row_ok && e0 + lane * 8 + 8 <= a.x_limit) ? a.XP + e0 + lane * 8 : zero;
       }
       glds16(src, st + u * 1024);
     }
@@ -144,10 +166,21 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
     if (sidx + 1 < s_end) issue(sidx + 1, stage ^ 1);
     const uint32_t sbase = lds0 + stage * stage_bytes;
     __builtin_amdgcn_s_setprio(1);
-    thin_step.template operator()<0>(sbase);
-    thin_step.template operator()<1>(sbase);
-    thin_step.template operator()<2>(sbase);
-    thin_step.template operator()<3>(sbase);
+    {
+      s16x8 afA[TM], bfA[RR * NT], afB[TM], bfB[RR * NT];
+      rd_frags.template operator()<0>(sbase, afA, bfA);
+      wait_frags(afA, bfA);
+      rd_frags.template operator()<1>(sbase, afB, bfB);
+      mma_frags(afA, bfA);
+      wait_frags(afB, bfB);
+      rd_frags.template operator()<2>(sbase, afA, bfA);
+      mma_frags(afB, bfB);
+      wait_frags(afA, bfA);
+      rd_frags.template operator()<3>(sbase, afB, bfB);
+      mma_frags(afA, bfA);
+      wait_frags(afB, bfB);
+      mma_frags(afB, bfB);
+    }
     __builtin_amdgcn_s_setprio(0);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -155,11 +188,11 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
   }
 
   const int run = a.S * a.Cs;
-  if (a.transposed) {
+  if constexpr (TRANSPOSED) {
     // The gradient row of one (output channel c, tap) is the M = a.K contiguous floats of the conv's input
     // channels: transpose each filter row's tile through LDS so that one atomic instruction covers a
     // contiguous row instead of 64 scattered cache lines.
-    constexpr int MROWS = 32 * TM * WM, COLS = 32 * WN * NT, PITCH = MROWS + 1;
+    constexpr int MROWS = 32 * TM * WM, COLS = 32 * WN * NT, TPITCH = MROWS + 1;
     float* const tbuf = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
@@ -173,7 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int k = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            tbuf[col * PITCH + k] = acc[rr][i][j][e];
+            tbuf[col * TPITCH + k] = acc[rr][i][j][e];
           }
       }
       __syncthreads();
@@ -183,7 +216,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
         const int s_out = sc / a.C, c = sc - s_out * a.C;
         if (k >= a.K) continue;
         atomicAdd(a.DW + (((long long)c * a.R + (a.R - 1 - r)) * a.S + (a.S - 1 - s_out)) * a.K + k,
-                  tbuf[(s_out * a.Cs + c) * PITCH + k]);
+                  tbuf[(s_out * a.Cs + c) * TPITCH + k]);
       }
     }
     return;
