@@ -1051,17 +1051,18 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
 
 static int g_wgrad_abl = 0;
 static int g_ring_enabled = 1;
+static int g_halo_single = 1;
 static int g_halo_enabled = 1;
 static int g_halo_abl = 0;
 
-template <int TN, int ABL = 0>
-static int launch_halo_cfg(const HaloArgs& a, hipStream_t s) {
+template <int TN, int ABL = 0, bool SINGLE = false>
+static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   constexpr int BN = 2 * TN * 32;
   constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
-  constexpr int lds = 2 * UH * 1024 + 3 * BN * 128;
+  constexpr int lds = (SINGLE ? 1 : 2) * UH * 1024 + 3 * BN * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -1072,13 +1073,19 @@ static int launch_halo_cfg(const HaloArgs& a, hipStream_t s) {
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL>), dim3(tiles), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE>), dim3(tiles), dim3(512), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
     ++g_prof.used;
   }
   return check_launch("gemm_halo_kernel");
+}
+
+template <int TN, int ABL = 0>
+static int launch_halo_cfg(const HaloArgs& a, hipStream_t s) {
+  if (a.Cs == 64 && ABL == 0 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true>(a, s);   // one slab: single patch buffer
+  return launch_halo_cfg_impl<TN, ABL, false>(a, s);
 }
 
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
@@ -1915,6 +1922,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_wgrad_row_enabled = enable != 4;
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
+  g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
   g_wgrad_abl = enable >= 200 ? enable - 200 : 0;   // 200+bits: fast wgrad timing ablations   // 100+bits: halo kernel timing ablations (wrong results)

@@ -35,7 +35,10 @@ struct HaloArgs {
 
 // ABL: timing-only ablation bits (results are wrong when non-zero): 1 = no DMA after the prologue,
 // 2 = no barrier, 4 = fragments read once per tap-group only (no per-k-step LDS reads), 8 = no vmcnt waits
-template <int TH, int TN, int ABL = 0>
+// SINGLE: one patch buffer instead of two -- for 64-channel inputs (one slab per tile, nothing to prefetch).
+// With the 64-wide N tile the block then needs 74 KiB of LDS and TWO blocks share a CU, overlapping one
+// block's patch load / epilogue with the other's MFMAs (these K = 576 layers are prologue-bound).
+template <int TH, int TN, int ABL = 0, bool SINGLE = false>
 __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   constexpr int R = 3, S = 3, TAPS = 9;
   constexpr int NW = 8, WN = 2;                       // waves: TH (=4) x 2
@@ -50,7 +53,8 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   static_assert(HU <= TAPS - 2, "patch units of the next slab are spread over taps 0..HU-1");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo0 = smem;
-  char* const bring = smem + 2 * HALO;
+  constexpr int NBUF = SINGLE ? 1 : 2;
+  char* const bring = smem + NBUF * HALO;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   const int T_total = CC * TAPS;
 
   auto issue_patch_unit = [&](int i, int slab) {      // i: compile-time after unrolling at the call sites
-    char* const dst = halo0 + (slab & 1) * HALO + h_lds[i];
+    char* const dst = halo0 + (slab & (NBUF - 1)) * HALO + h_lds[i];
     const bf16_t* src = h_off[i] >= 0 ? a.X + h_off[i] + slab * 64 : zero;
     glds16(src, dst);
   };
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
       if (t + 2 < T_total) issue_b(t + 2);
     }
 
-    const char* const hb = halo0 + (slab & 1) * HALO;
+    const char* const hb = halo0 + (slab & (NBUF - 1)) * HALO;
     const char* const st = bring + (t % 3) * B_STAGE;
     const int r = tap / S, s = tap - r * S;
     const int tapoff = r * PW + s;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   // global stores are 16-byte channel vectors (see acc_tile_to_lds)
   __syncthreads();
   constexpr int PITCH = BN * 2 + 64;
-  static_assert(TH * 64 * PITCH <= 2 * HALO + 3 * B_STAGE, "epilogue tile fits the pipeline LDS");
+  static_assert(TH * 64 * PITCH <= NBUF * HALO + 3 * B_STAGE, "epilogue tile fits the pipeline LDS");
   acc_tile_to_lds<2, TN>(smem, PITCH, wm * 64, wn * TN * 32, n0, lane, acc, a.bias, a.Kout, a.act, a.slope);
   __syncthreads();
   const long long blk_base = a.out_base + n * a.out_sn + (long long)oh0 * a.out_sh + (long long)ow0 * a.out_sw;

@@ -27,9 +27,21 @@ def rel_err(a, b):
   return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
 
 
+def _where_bad(a, b, tol):
+  """Index ranges of the offending elements (diagnostic for intermittent failures)."""
+  a = torch.as_tensor(a, dtype=torch.float64)
+  b = torch.as_tensor(b, dtype=torch.float64)
+  bad = torch.nonzero((a - b).abs() > tol * b.abs().max().clamp_min(1e-20))
+  if bad.numel() == 0:
+    return ''
+  return ' [%d of %d elements off; index ranges %s; first %s]' % (
+      bad.shape[0], a.numel(), [(int(bad[:, j].min()), int(bad[:, j].max())) for j in range(bad.shape[1])],
+      bad[0].tolist())
+
+
 def assert_close(a, b, tol, what=''):
   e = rel_err(a, b)
-  assert e <= tol, '%s: max|a-b|/max|b| = %.3e > %.1e' % (what, e, tol)
+  assert e <= tol, '%s: max|a-b|/max|b| = %.3e > %.1e%s' % (what, e, tol, _where_bad(a, b, tol))
 
 
 def bf16_round(t):

@@ -2,6 +2,8 @@
 seeded inputs (fp32: <= 1e-3 relative, the north_star bound; bf16: documented looser bound).
 Shapes cover each distinct conv class of SURVEY.md §2.1 at sizes the CPU finishes in seconds,
 ragged tails (M, K not multiples of the tile), and the borders of pad / pool / convT."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -101,7 +103,10 @@ def _torch_conv(x, w, b, st, pad, mode, act):
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(case, dtype):
   name, N, H, W, C, K, k, st, pad, mode, act = case
-  g = G(hash(name) % 1000)
+  # crc32, not hash(): str hashes are salted per process, and a run-dependent seed turns the rare case of a
+  # pre-activation within rounding distance of 0 (ReLU mask flips between two correct fp32 results:
+  # ~25 % of random draws at these sizes) into an intermittent failure
+  g = G(zlib.crc32(name.encode()) % 1000)
   x = quantize_like(torch.randn(N, C, H, W, generator=g), dtype)
   w = torch.randn(K, C, k, k, generator=g) * (1.0 / (C * k * k) ** 0.5)
   b = torch.randn(K, generator=g) * 0.1
@@ -145,7 +150,7 @@ FUSED_RELU_CASES = [
 @pytest.mark.parametrize('case', FUSED_RELU_CASES, ids=[c[0] for c in FUSED_RELU_CASES])
 def test_conv_dgrad_fused_relu(case, dtype):
   name, N, H, W, C, K, k, st, pad, mode = case
-  g = G(hash(name) % 1000 + 7)
+  g = G(zlib.crc32(name.encode()) % 1000 + 7)
   z = quantize_like(torch.randn(N, C, H, W, generator=g), dtype)      # pre-activation of the previous layer
   w = torch.randn(K, C, k, k, generator=g) * (1.0 / (C * k * k) ** 0.5)
   layer = HipConv2d(C, K, k, st, pad, mode, act=ACT_NONE, apply_bias=False, dtype=dtype, device=DEV)
