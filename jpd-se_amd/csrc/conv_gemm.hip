@@ -1051,6 +1051,7 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
 
 static int g_wgrad_abl = 0;
 static int g_ring_enabled = 1;
+static int g_merge_min_kt = 16;
 static int g_halo_single = 1;
 static int g_halo_enabled = 1;
 static int g_halo_abl = 0;
@@ -1460,7 +1461,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     }
     nlive_phases = nlive;
     if (nlive == 1) fast = fast && fast_pays(m_single, p.Cs, kt_max);
-    else fast = fast && g_fast_enabled && p.Cs > 32 && kt_max >= 16 && tiles >= 384;   // short K loops: generic wins
+    else fast = fast && g_fast_enabled && p.Cs > 32 && kt_max >= g_merge_min_kt && tiles >= 384;   // short K loops: generic wins
   }
   FastBatch batch = {};
   int rc = JPDSE_OK;
@@ -1922,6 +1923,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_wgrad_row_enabled = enable != 4;
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
+  g_merge_min_kt = enable == 9 ? 4 : 16;   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
