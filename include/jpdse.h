@@ -114,6 +114,13 @@ int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad
  * -- with the mask applied in the GEMM epilogue instead of a separate pass over dx. */
 int jpdse_conv_dgrad_relu(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack,
                           const void* x, void* dx, void* ws, size_t ws_bytes, void* stream);
+/* dx = (conv_dgrad(dy) + addend) * (x > 0); `x` (ReLU mask, see above) and `addend` (same shape as dx)
+ * may each be NULL.  The addend is the other branch of a gradient fan-in: the skip connection of a
+ * ResnetBlock (`out = x + self.conv_block(x)`, networks.py:303-305) or the loss gradient arriving at
+ * a VGG19 tap -- summed in the GEMM epilogue instead of a separate add pass. */
+int jpdse_conv_dgrad_fused(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack,
+                           const void* x, const void* addend, void* dx, void* ws, size_t ws_bytes,
+                           void* stream);
 /* dw (fp32, KRSC master layout) = d(loss)/d(w); overwritten (beta = 0) */
 int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw_krsc,
                      void* ws, size_t ws_bytes, void* stream);

@@ -1295,24 +1295,33 @@ __global__ __launch_bounds__(256) void ring_fold_kernel(const RingFoldArgs a, lo
   Vec16<bf16_t>::store(dst, cur);
 }
 
-// dx *= (mask > 0), 16-byte vectors: the unfused form of the ReLU-masked data gradient
+// dx = (dx + addend) * (mask > 0), 16-byte vectors: the unfused form of the data-gradient epilogue extras
+// (either pointer may be null)
 template <typename T>
-__global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask, long long total_vec) {
+__global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask, long long total_vec,
+                                 const T* __restrict__ addend = nullptr) {
   constexpr int VE = Vec16<T>::N;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total_vec;
        i += (long long)gridDim.x * blockDim.x) {
     float v[VE], m[VE];
     Vec16<T>::load(dx + i * VE, v);
-    Vec16<T>::load(mask + i * VE, m);
+    if (addend != nullptr) {
+      Vec16<T>::load(addend + i * VE, m);
 #pragma unroll
-    for (int e = 0; e < VE; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < VE; ++e) v[e] += m[e];
+    }
+    if (mask != nullptr) {
+      Vec16<T>::load(mask + i * VE, m);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+    }
     Vec16<T>::store(dx + i * VE, v);
   }
 }
 
 template <typename T>
 static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx,
-                        void* ws, hipStream_t s, const void* mask = nullptr) {
+                        void* ws, hipStream_t s, const void* mask = nullptr, const void* addend = nullptr) {
   char* wsb = reinterpret_cast<char*>(ws);
   void* dyp = wsb;
   void* dxp = wsb + p.dypad_bytes;
@@ -1345,6 +1354,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.out_base = 0;
       h.act = JPDSE_ACT_NONE;
       h.mask = reinterpret_cast<const bf16_t*>(mask);
+      h.addend = reinterpret_cast<const bf16_t*>(addend);
       return p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
     }
   }
@@ -1370,6 +1380,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.out_sh = (long long)d->W * p.Cs;
       h.out_sw = p.Cs;
       h.act = JPDSE_ACT_NONE;
+      h.addend = reinterpret_cast<const bf16_t*>(addend);
       if (int rc = p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s)) return rc;
       // (2) the four ring strips of the reflect-padded domain as split-K GEMMs into fp32 slabs
       const int H = d->H, W = d->W, Ks = p.Ks, Lk = p.ph[0].Lk;
@@ -1509,6 +1520,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         g.act = JPDSE_ACT_NONE;
         g.slope = 0.f;
         g.mask = refl ? nullptr : reinterpret_cast<const bf16_t*>(mask);
+        g.addend = refl ? nullptr : reinterpret_cast<const bf16_t*>(addend);
         g.splits = nlive_phases == 1 ? splitk_for(g.M, p.Cs, f.Uh * f.Uw * p.Ks / 64) : 1;
         g.partial = reinterpret_cast<float*>(wsb + p.splitk_off);
         batch.p[batch.n++] = g;
@@ -1563,11 +1575,11 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
                        total_vec);
     rc = check_launch("reflect_fold_kernel");
   }
-  if (rc == JPDSE_OK && mask != nullptr && !(fast && !refl)) {
+  if (rc == JPDSE_OK && (mask != nullptr || addend != nullptr) && !(fast && !refl)) {
     const int VE = 16 / (int)sizeof(T);
     const long long total_vec = (long long)d->N * d->H * d->W * (p.Cs / VE);
     hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, reinterpret_cast<T*>(dx),
-                       reinterpret_cast<const T*>(mask), total_vec);
+                       reinterpret_cast<const T*>(mask), total_vec, reinterpret_cast<const T*>(addend));
     rc = check_launch("relu_mask_kernel");
   }
   return rc;
@@ -2114,15 +2126,21 @@ int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad
 
 int jpdse_conv_dgrad_relu(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, const void* x, void* dx,
                           void* ws, size_t ws_bytes, void* stream) {
+  JPDSE_REQUIRE(x != nullptr, "conv_dgrad_relu: null mask tensor");
+  return jpdse_conv_dgrad_fused(d, dy, dgrad_pack, x, nullptr, dx, ws, ws_bytes, stream);
+}
+
+int jpdse_conv_dgrad_fused(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, const void* x,
+                           const void* addend, void* dx, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = validate(d)) return rc;
-  JPDSE_REQUIRE(dy && dgrad_pack && dx && x, "conv_dgrad_relu: null pointer");
+  JPDSE_REQUIRE(dy && dgrad_pack && dx, "conv_dgrad_fused: null pointer");
   ConvPlan p;
   make_plan(d, &p);
   const size_t need = jpdse_conv_workspace_size(d);
   if (ws == nullptr || ws_bytes < need)
-    return set_error(JPDSE_EWORKSPACE, "conv_dgrad_relu: workspace %zu < %zu", ws_bytes, need);
-  return d->dtype == JPDSE_BF16 ? conv_dgrad_t<bf16_t>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x)
-                                : conv_dgrad_t<float>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x);
+    return set_error(JPDSE_EWORKSPACE, "conv_dgrad_fused: workspace %zu < %zu", ws_bytes, need);
+  return d->dtype == JPDSE_BF16 ? conv_dgrad_t<bf16_t>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x, addend)
+                                : conv_dgrad_t<float>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x, addend);
 }
 
 int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,

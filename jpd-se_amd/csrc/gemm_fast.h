@@ -41,6 +41,7 @@ struct FastArgs {
   float* partial;
   // optional fused ReLU backward: Y is zeroed where mask <= 0 (mask has Y's addressing: the conv's input)
   const bf16_t* mask;
+  const bf16_t* addend;   // optional: Y = result + addend (same addressing as Y), before the mask
   // optional generalisations (0 = the dense defaults): batch stride of X (a sub-image of a larger tensor),
   // B row stride and B offsets per filter-row / filter-column step (a sub-panel of a larger filter panel)
   long long x_sn, x_sh;   // batch / row strides of X in elements
@@ -99,6 +100,17 @@ __device__ __forceinline__ void acc_tile_to_lds(char* tile, int pitch, int wrow0
       }
     }
   }
+}
+
+// 8 bf16 values: v + w in fp32, rounded once
+__device__ __forceinline__ u32x4 add_bf16x8(u32x4 v, u32x4 w) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(v[i] << 16) + __uint_as_float(w[i] << 16);
+    const float hi = __uint_as_float(v[i] & 0xffff0000u) + __uint_as_float(w[i] & 0xffff0000u);
+    v[i] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  }
+  return v;
 }
 
 // 8 bf16 values of `v` zeroed where the matching value of `m` is <= 0 (or NaN)
@@ -338,6 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     const long long off = row_off[row];
     if (off < 0 || n0 + v * 8 >= a.Ks) continue;
     u32x4 val = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
+    if (a.addend != nullptr) val = add_bf16x8(val, *reinterpret_cast<const u32x4*>(a.addend + off + n0 + v * 8));
     if (a.mask != nullptr) val = relu_mask8(val, *reinterpret_cast<const u32x4*>(a.mask + off + n0 + v * 8));
     *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = val;
   }
@@ -367,6 +380,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const FastArgs a, lo
     const bool live = col < a.Kout;
     const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
     o[e] = live ? apply_act(acc[e] + bv, a.act, a.slope) : 0.f;
+  }
+  if (a.addend != nullptr) {
+    float ad[8];
+    Vec16<bf16_t>::load(a.addend + off + c0, ad);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += ad[e];
   }
   if (a.mask != nullptr) {
     float mk[8];

@@ -31,6 +31,7 @@ struct HaloArgs {
   int act;
   float slope;
   const bf16_t* mask;   // optional fused ReLU backward (see FastArgs::mask)
+  const bf16_t* addend; // optional: Y = result + addend
 };
 
 // ABL: timing-only ablation bits (results are wrong when non-zero): 1 = no DMA after the prologue,
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     if (n0 + v * 8 >= a.Ks) continue;
     const long long off = blk_base + (long long)(row >> 6) * a.out_sh + (long long)(row & 63) * a.out_sw;
     u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);
+    if (a.addend != nullptr) val = add_bf16x8(val, *reinterpret_cast<const u32x4*>(a.addend + off + n0 + v * 8));
     if (a.mask != nullptr) val = relu_mask8(val, *reinterpret_cast<const u32x4*>(a.mask + off + n0 + v * 8));
     *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = val;
   }

@@ -402,17 +402,17 @@ class Vgg19(nn.Module):
     d = None
     for pos in range(len(order) - 1, -1, -1):
       kind, ci = order[pos]
-      if kind == 'C' and ci in VGG_TAPS:
-        g = dmaps[VGG_TAPS.index(ci)]
-        if g is not None:
-          d = g if d is None else ops.add_(d, g)
+      if kind == 'C' and ci in VGG_TAPS and d is None:
+        d = dmaps[VGG_TAPS.index(ci)]            # deepest tap: nothing to add to
       if d is None:
         continue
       if kind == 'M':
         (x,) = ctxs[pos].items
         d = ops.maxpool2_bwd(x, d)
       else:
-        d = self.convs[ci].bwd(ctxs[pos], d, True, False, dy_is_dz=True, relu_input=ci > 0)
+        # the loss gradient of the tap that is this conv's INPUT (relu{k}_1 feeds conv{k}_2) is summed in the epilogue
+        tap = dmaps[VGG_TAPS.index(ci - 1)] if (ci - 1) in VGG_TAPS and order[pos - 1][0] == 'C' else None
+        d = self.convs[ci].bwd(ctxs[pos], d, True, False, dy_is_dz=True, relu_input=ci > 0, addend=tap)
     return d
 
   def forward(self, X):

@@ -59,6 +59,7 @@ SIGNATURES = {
     'jpdse_conv_fwd': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad_relu': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_conv_dgrad_fused': (_I32, [_CD, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_wgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_convT_fwd': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_convT_dgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),

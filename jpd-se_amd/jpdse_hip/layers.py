@@ -150,10 +150,11 @@ class HipConv2d(nn.Module):
     y = ops.conv_fwd(d, x, fwd_pack, self.bias if self.apply_bias else None)
     return y, Ctx(x, y if self.act != ACT_NONE else None)
 
-  def bwd(self, ctx, dy, need_dx=True, need_dw=True, dy_is_dz=False, relu_input=False):
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True, dy_is_dz=False, relu_input=False, addend=None):
     """dy_is_dz: dy is already the gradient w.r.t. the PRE-activation (the caller fused this layer's
     activation backward upstream); relu_input: the layer's input is a ReLU output and the returned dx
-    is wanted w.r.t. that ReLU's pre-activation (mask fused into the data-gradient epilogue)."""
+    is wanted w.r.t. that ReLU's pre-activation (mask fused into the data-gradient epilogue); addend: another
+    gradient w.r.t. the layer's input, summed into dx in the same epilogue."""
     fwd_pack, dgrad_pack = self.packs()
     need_dw = need_dw and self.weight.requires_grad
     if self.transposed:
@@ -175,7 +176,7 @@ class HipConv2d(nn.Module):
         if self.bias.grad.data_ptr() != store.data_ptr():
           self.bias.grad.copy_(store[:self.cout])   # .grad re-homed into a DDP bucket view
       self._fire()
-    return ops.conv_dgrad(d, dz, dgrad_pack, relu_input=x if relu_input else None) if need_dx else None
+    return ops.conv_dgrad(d, dz, dgrad_pack, relu_input=x if relu_input else None, addend=addend) if need_dx else None
 
   def _fire(self):
     if self.grad_ready_hook is not None:
@@ -244,10 +245,8 @@ class HipResnetBlock(nn.Module):
     d = self.norm2.bwd(n2, dy)
     d = self.conv_block[5].bwd(c2, d, True, need_dw)
     d = self.norm1.bwd(n1, d)
-    d = self.conv_block[1].bwd(c1, d, need_dx, need_dw)
-    if not need_dx:
-      return None
-    return ops.add_(d, dy)
+    # the skip connection's gradient is summed in the data-gradient epilogue of the first conv
+    return self.conv_block[1].bwd(c1, d, need_dx, need_dw, addend=dy if need_dx else None)
 
 
 def run_chain_fwd(stages, x):

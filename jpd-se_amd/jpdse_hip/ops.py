@@ -114,14 +114,17 @@ def conv_fwd(d, x, fwd_pack, bias, out=None):
   return y
 
 
-def conv_dgrad(d, dy, dgrad_pack, relu_input=None):
+def conv_dgrad(d, dy, dgrad_pack, relu_input=None, addend=None):
   """relu_input: the conv's own input x when it is a ReLU output -- dx is then masked where x <= 0
-  (the ReLU backward fused into the GEMM epilogue)."""
+  (the ReLU backward fused into the GEMM epilogue).  addend: another gradient w.r.t. the same tensor
+  (skip connection, loss tap), summed in the epilogue: dx = (dgrad + addend) * mask."""
   dx = Act.empty(d.N, d.H, d.W, d.C, d.dtype, dy.t.device)
   ws, n = _conv_ws(d, dy.t.device)
-  if relu_input is not None:
-    check(lib().jpdse_conv_dgrad_relu(ctypes.byref(d), _p(dy.t), _p(dgrad_pack), _p(relu_input.t), _p(dx.t), _p(ws),
-                                      ws.numel(), _stream()), 'conv_dgrad_relu')
+  if relu_input is not None or addend is not None:
+    check(lib().jpdse_conv_dgrad_fused(ctypes.byref(d), _p(dy.t), _p(dgrad_pack),
+                                       _p(relu_input.t if relu_input is not None else None),
+                                       _p(addend.t if addend is not None else None), _p(dx.t), _p(ws),
+                                       ws.numel(), _stream()), 'conv_dgrad_fused')
     return dx
   check(lib().jpdse_conv_dgrad(ctypes.byref(d), _p(dy.t), _p(dgrad_pack), _p(dx.t), _p(ws), ws.numel(), _stream()),
         'conv_dgrad')

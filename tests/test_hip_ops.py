@@ -167,6 +167,14 @@ def test_conv_dgrad_fused_relu(case, dtype):
   torch.cuda.synchronize()
   assert_close(to_nchw(dz), zr.grad, 2 * RTOL[dtype], name + ' dgrad with fused ReLU mask')
   assert (to_nchw(dz)[z <= 0] == 0).all()
+  # gradient fan-in summed in the same epilogue: dz = (dgrad + other) * mask, and without the mask
+  other = quantize_like(torch.randn(z.shape, generator=g), dtype)
+  dz2 = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False, relu_input=True, addend=to_act(other, dtype))
+  assert_close(to_nchw(dz2), zr.grad + other * (z > 0), 2 * RTOL[dtype], name + ' dgrad + addend, masked')
+  dx3 = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False, addend=to_act(other, dtype))
+  y2 = _torch_conv(x_leaf := F.relu(z).clone().requires_grad_(True), wr, None, st, pad, mode, ACT_NONE)
+  y2.backward(gy)
+  assert_close(to_nchw(dx3), x_leaf.grad + other, 2 * RTOL[dtype], name + ' dgrad + addend')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
