@@ -1008,12 +1008,24 @@ static bool prefer_320(int M, int Ks) {
   return c320 < c256;
 }
 
+static int g_fast_small = 20;      // K-tile count up to which the 128-row / 2-stage fast configs are used
 static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   if (b.n <= 0) return JPDSE_OK;
   const int Ks = b.p[0].Ks;
   if (b.n == 1 && b.p[0].splits > 1) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // split-K: 256 x 128 only
   for (int i = 0; i < b.n; ++i)
     if (b.n > 1 && !b.p[i].no_finish) b.p[i].splits = 1;
+  int kt = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const int k = b.p[i].R * b.p[i].S * (b.p[i].Cs / 64);
+    kt = k > kt ? k : kt;
+  }
+  if (g_fast_small && kt <= g_fast_small && b.p[0].splits <= 1) {
+    // short reductions are prologue / epilogue bound: 128-row tiles, 4 waves, 2 stages = 64 (48) KiB of LDS, so two
+    // (three) blocks share a CU and overlap each other's fill and store phases
+    if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);   // 128 x 128
+    if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);   // 128 x 64
+  }
   if (b.n == 1 && prefer_320(b.p[0].M, Ks)) return launch_fast_cfg<2, 4, 5, 1, 0, 2>(b, s);   // 320 x 128, 2 stages
   if (Ks > 64) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // 256 x 128
   if (Ks > 32) return launch_fast_cfg<4, 2, 2, 1, 0>(b, s);   // 256 x 64
@@ -1051,7 +1063,7 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
 
 static int g_wgrad_abl = 0;
 static int g_ring_enabled = 1;
-static int g_merge_min_kt = 16;
+static int g_merge_min_kt = 4;
 static int g_halo_single = 1;
 static int g_halo_enabled = 1;
 static int g_halo_abl = 0;
@@ -1935,7 +1947,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_wgrad_row_enabled = enable != 4;
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
-  g_merge_min_kt = enable == 9 ? 4 : 16;   // 9: merged stride-phase data gradient also for short K loops (A/B)
+  g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
+  g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
