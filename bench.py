@@ -51,6 +51,8 @@ def parse():
                   help='BASELINE config 2: GlobalGenerator + 2-scale PatchGAN step without the VGG loss '
                        '(no_vgg_loss + skip_unused_losses: VGG is not run at all)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--debug-mode', type=int, default=None,
+                  help='developer A/B switch: value for jpdse_debug_set_fast_path (kernel selection), default untouched')
   return ap.parse_args()
 
 
@@ -103,6 +105,8 @@ def main():
   from ctu.trainers import get_trainer
   from oracle.ctu_cpu.model import synthetic_batch
   jpdse_hip.require_gpu(dev_index)
+  if args.debug_mode is not None:
+    check(lib().jpdse_debug_set_fast_path(args.debug_mode), 'debug_set_fast_path')
 
   torch.manual_seed(1234)            # identical replicas; enable_data_parallel also broadcasts rank 0
   opt = make_opt(args, dev_index)

@@ -73,6 +73,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "wgrad_fast.h"
 #include "wgrad_thin.h"
 #include "wgrad_row.h"
+#include "wgrad_taps.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1747,6 +1748,103 @@ static int launch_wgrad_row(const RowWgArgs& a, hipStream_t s) {
   return launch_wgrad_row_cfg<0>(a, s);
 }
 
+// ---- all-taps weight gradient of the narrow high-resolution layers (wgrad_taps.h) -----------------
+// config id: 0 none; 1: 3x3 s2 K%128 C%64; 2: 3x3 s1 K%64 C%64; 3: 4x4 s2 K%128 C%64; 4: 3x3 s2 K%256 C%128
+static int g_wgrad_taps_enabled = 1;
+static int wgrad_taps_cfg(const jpdse_conv_desc* d, const ConvPlan& p) {
+  if (!g_fast_enabled || !g_wgrad_taps_enabled || p.ES != 2 || d->R != d->S) return 0;
+  if (p.Ks > 256 || p.Cs > 128 || (long long)d->N * p.OH * ((p.OW + 63) / 64) < 32) return 0;
+  if ((long long)d->N * p.OH * p.OW * p.Ks >= (1LL << 31) || (long long)d->N * d->H * d->W * p.Cs >= (1LL << 31)) return 0;
+  if (d->R == 3 && d->stride == 2 && p.Ks % 256 == 0 && p.Cs % 64 == 0) return 4;
+  if (d->R == 3 && d->stride == 2 && p.Ks % 128 == 0 && p.Cs % 64 == 0) return 1;
+  if (d->R == 3 && d->stride == 1 && p.Ks % 64 == 0 && p.Ks <= 128 && p.Cs % 64 == 0) return 2;
+  if (d->R == 4 && d->stride == 2 && p.Ks % 128 == 0 && p.Cs % 64 == 0) return 3;
+  return 0;
+}
+
+struct TapsGeom { int BM, BN, T, NROW, lds, blocks_per_cu; };
+static TapsGeom taps_geom(int cfg) {
+  switch (cfg) {
+    case 1: return {128, 64, 9, 3, 2 * (64 * 256 + 49 * 1024), 1};
+    case 2: return {64, 64, 9, 3, 2 * (64 * 128 + 25 * 1024), 2};
+    case 3: return {128, 64, 8, 2, 2 * (64 * 256 + 33 * 1024), 1};
+    default: return {256, 64, 3, 1, 2 * (64 * 512 + 17 * 1024), 1};
+  }
+}
+
+static void taps_partition(const jpdse_conv_desc* d, const ConvPlan& p, int cfg, TapsWgArgs* a) {
+  const TapsGeom g = taps_geom(cfg);
+  a->chunks_per_row = (p.OW + 63) / 64;
+  a->chunks_total = d->N * p.OH * a->chunks_per_row;
+  a->k_tiles = p.Ks / g.BM;
+  a->r_groups = (d->R + g.NROW - 1) / g.NROW;
+  a->c_tiles = p.Cs / g.BN;
+  const int tiles = a->k_tiles * a->r_groups * a->c_tiles;
+  int bpt = 256 * g.blocks_per_cu / tiles;
+  if (bpt < 1) bpt = 1;
+  if (bpt > a->chunks_total) bpt = a->chunks_total;
+  a->chunks_per_block = (a->chunks_total + bpt - 1) / bpt;
+  a->blocks_per_tile = (a->chunks_total + a->chunks_per_block - 1) / a->chunks_per_block;
+}
+
+static size_t wgrad_taps_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
+  const int cfg = wgrad_taps_cfg(d, p);
+  if (!cfg) return 0;
+  TapsWgArgs a = {};
+  taps_partition(d, p, cfg, &a);
+  const TapsGeom g = taps_geom(cfg);
+  return (size_t)a.k_tiles * a.r_groups * a.c_tiles * a.blocks_per_tile * g.T * g.BM * g.BN * sizeof(float);
+}
+
+template <int TMW, int WM, int WN, int S, int NROW, int ST>
+static int launch_wgrad_taps_cfg(const TapsWgArgs& a, int lds, hipStream_t s) {
+  constexpr int BM = WM * TMW * 32, BN = WN * 32;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<TMW, WM, WN, S, NROW, ST>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_taps: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  const int blocks = a.k_tiles * a.r_groups * a.c_tiles * a.blocks_per_tile;
+  hipLaunchKernelGGL((wgrad_taps_kernel<TMW, WM, WN, S, NROW, ST>), dim3(blocks), dim3(64 * WM * WN), lds, s, a);
+  if (int rc = check_launch("wgrad_taps_kernel")) return rc;
+  const long long total = (long long)a.K * a.R * a.S * a.C;
+  hipLaunchKernelGGL((wgrad_taps_reduce_kernel<BM, BN, S, NROW>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s,
+                     a, total);
+  return check_launch("wgrad_taps_reduce_kernel");
+}
+
+static int launch_wgrad_taps(const jpdse_conv_desc* d, const ConvPlan& p, int cfg, const void* x, const void* dy,
+                             float* dw, void* ws, hipStream_t s) {
+  TapsWgArgs a = {};
+  a.X = reinterpret_cast<const bf16_t*>(x);
+  a.DY = reinterpret_cast<const bf16_t*>(dy);
+  a.partial = reinterpret_cast<float*>(ws);
+  a.DW = dw;
+  a.N = d->N;
+  a.IH = d->H;
+  a.IW = d->W;
+  a.OH = p.OH;
+  a.OW = p.OW;
+  a.Cs = p.Cs;
+  a.C = d->C;
+  a.Ks = p.Ks;
+  a.K = d->K;
+  a.R = d->R;
+  a.S = d->S;
+  a.pad = d->pad;
+  a.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+  taps_partition(d, p, cfg, &a);
+  const int lds = taps_geom(cfg).lds;
+  switch (cfg) {
+    case 1: return launch_wgrad_taps_cfg<1, 4, 2, 3, 3, 2>(a, lds, s);
+    case 2: return launch_wgrad_taps_cfg<1, 2, 2, 3, 3, 1>(a, lds, s);
+    case 3: return launch_wgrad_taps_cfg<1, 4, 2, 4, 2, 2>(a, lds, s);
+    default: return launch_wgrad_taps_cfg<2, 4, 2, 3, 1, 2>(a, lds, s);
+  }
+}
+
 // heads with <= 8 output channels on a 32- / 64-channel input, stride 1 (64->3, 32->3 7x7)
 static bool wgrad_head_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
   return g_fast_enabled && p.Ks == 8 && d->stride == 1 && (p.Cs == 32 || p.Cs == 64) && d->S * 8 <= 64 && d->R <= 7;
@@ -1791,6 +1889,7 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       f.reflect = 0;
       return launch_wgrad_fast(f, s);
     }
+    if (const int tcfg = wgrad_taps_cfg(d, p)) return launch_wgrad_taps(d, p, tcfg, x, dy, dw, ws, s);
     if (wgrad_row_ok(d, p)) {
       RowWgArgs w = {};
       w.X = reinterpret_cast<const bf16_t*>(x);
@@ -1946,6 +2045,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_wgrad_row_enabled = enable != 4;
+  g_wgrad_taps_enabled = enable != 12;   // 12: fast kernels without the all-taps weight gradient (A/B)
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
   g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
@@ -2043,7 +2143,9 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
     const size_t ring = (size_t)8 * d->N * (2 * (d->W + 2) + 2 * d->H) * p.Cs * 4;   // ring-strip slabs, <= 8 splits
     sk = sk > ring ? sk : ring;
   }
-  const size_t m = fwd > dgrad ? fwd : dgrad;
+  size_t m = fwd > dgrad ? fwd : dgrad;
+  const size_t taps = wgrad_taps_ws_bytes(d, p);
+  m = m > taps ? m : taps;
   return m > sk ? m : sk;
 }
 

@@ -84,6 +84,11 @@ CONV_CASES = [
     # reflect data gradient = halo kernel on the interior + ring strips (split-K) folded back
     ('ring_dgrad_64',  2, 8,  64,  64,  128, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
     ('ring_dgrad_192', 1, 12, 128, 192, 64,  3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    # all-taps weight gradient (wgrad_taps.h), one case per configuration; ragged 64-pixel chunks, several blocks per tile
+    ('taps_3x3s2',     2, 40, 150, 64,  128, 3, 2, 1,  PAD_ZERO,    ACT_NONE),
+    ('taps_3x3s1_refl', 2, 36, 100, 64, 64,  3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    ('taps_4x4s2',     2, 38, 140, 64,  128, 4, 2, 2,  PAD_ZERO,    ACT_LRELU),
+    ('taps_3x3s2_256', 1, 80, 136, 128, 256, 3, 2, 1,  PAD_ZERO,    ACT_NONE),
 ]
 
 
