@@ -793,10 +793,13 @@ static void phase_axis(int st, int q, int Rf, int lo, int hi, int& U, int& i0, i
 // Split-K factor of the fast 256x128 kernel for a GEMM of M rows, Ks output channels and k_tiles
 // 64-wide K-tiles: only when the tiles alone would leave most of the 256 CUs idle.
 static int g_splitk_enabled = 1, g_toep_enabled = 1;   // A/B switches (jpdse_debug_set_fast_path 6 / 5)
+static int g_thin_out_fast = 1;
 static int splitk_for(int M, int Ks, int k_tiles) {
   if (!g_splitk_enabled) return 1;
-  if (Ks <= 64 || k_tiles < 32 || M <= 0) return 1;
-  const long long tiles = (long long)((M + 255) / 256) * ((Ks + 127) / 128);
+  // narrow outputs (Ks <= 32: the 512 -> 1 PatchGAN map) only with long reductions
+  if ((Ks <= 64 && !(Ks <= 32 && k_tiles >= 64 && g_thin_out_fast)) || k_tiles < 32 || M <= 0) return 1;
+  const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32);
+  const long long tiles = (long long)((M + 255) / 256) * ((Ks + bn - 1) / bn);
   if (tiles > 128) return 1;
   int sp = (int)(256 / tiles);
   if (sp > k_tiles / 16) sp = k_tiles / 16;
@@ -1013,7 +1016,11 @@ static int g_fast_small = 20;      // K-tile count up to which the 128-row / 2-s
 static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   if (b.n <= 0) return JPDSE_OK;
   const int Ks = b.p[0].Ks;
-  if (b.n == 1 && b.p[0].splits > 1) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // split-K: 256 x 128 only
+  if (b.n == 1 && b.p[0].splits > 1) {   // split-K
+    if (Ks > 64) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);
+    if (Ks > 32) return launch_fast_cfg<4, 2, 2, 1, 0>(b, s);
+    return launch_fast_cfg<8, 1, 1, 1, 0>(b, s);
+  }
   for (int i = 0; i < b.n; ++i)
     if (b.n > 1 && !b.p[i].no_finish) b.p[i].splits = 1;
   int kt = 0;
@@ -1051,7 +1058,12 @@ static bool prefer_320(int M, int Ks);
 static bool fast_pays(int M, int Ks, int k_tiles) {
   if (!g_fast_enabled) return false;
   if (k_tiles < 8) return false;   // short reductions (stride-2 sub-pixel phases of 2x2 taps x 64 ch) do not fill the 3-stage ring
-  if (Ks <= 32) return false;   // measured: the generic 256x32 kernel beats the 8-wave 256x32 fast config
+  if (Ks <= 32) {
+    // measured: the generic 256x32 kernel beats the 8-wave 256x32 fast config on short reductions; with a long
+    // one (512 -> 1 PatchGAN map, K = 8192) the fast kernel needs no padded copy and streams the input by DMA
+    if (!(g_thin_out_fast && k_tiles >= 64)) return false;
+    return splitk_for(M, Ks, k_tiles) > 1 || (M + 255) / 256 >= 128;
+  }
   if (splitk_for(M, Ks, k_tiles) > 1) return true;
   const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32);
   const long long tiles = (long long)((M + 255) / 256) * ((Ks + bn - 1) / bn);
@@ -1109,10 +1121,77 @@ static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_
          Cs_in % 64 == 0 && Ks_out > 32;
 }
 
+// Convs with K*R*S <= 32 outputs-times-taps (the 512 -> 1 PatchGAN map): y[p][k] = sum_taps Z[p + tap][k, tap] with
+// Z[q][(k, tap)] = sum_c x[q][c] * w[k][tap][c] -- a 1x1 GEMM over the INPUT pixels (K*R*S <= 32 columns: one MFMA
+// tile, every input pixel read once, no padded copy) followed by this gather-sum over the taps.  The direct
+// form wastes 31 of 32 MFMA columns and re-reads the input once per tap.
+__global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ Z, const float* __restrict__ bias,
+                                                    bf16_t* __restrict__ y, int N, int H, int W, int OH, int OW,
+                                                    int K, int Ks_out, int R, int S, int pad, int reflect, int zs,
+                                                    int act, float slope, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over output pixels x Ks_out
+  if (idx >= total) return;
+  const int k = (int)(idx % Ks_out);
+  long long t = idx / Ks_out;
+  const int ow = (int)(t % OW);
+  t /= OW;
+  const int oh = (int)(t % OH), n = (int)(t / OH);
+  float v = 0.f;
+  if (k < K) {
+    v = bias != nullptr ? bias[k] : 0.f;
+    for (int r = 0; r < R; ++r) {
+      int ih = oh + r - pad;
+      if (reflect) ih = ih < 0 ? -ih : (ih >= H ? 2 * (H - 1) - ih : ih);
+      else if ((unsigned)ih >= (unsigned)H) continue;
+      for (int s2 = 0; s2 < S; ++s2) {
+        int iw = ow + s2 - pad;
+        if (reflect) iw = iw < 0 ? -iw : (iw >= W ? 2 * (W - 1) - iw : iw);
+        else if ((unsigned)iw >= (unsigned)W) continue;
+        v += Z[(((long long)n * H + ih) * W + iw) * zs + (k * R + r) * S + s2];
+      }
+    }
+    v = apply_act(v, act, slope);
+  }
+  y[idx] = f2bf(v);
+}
+
+static int g_tapsum_enabled = 1;
+static bool tapsum_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
+  return g_fast_enabled && g_tapsum_enabled && p.ES == 2 && d->stride == 1 && d->K * d->R * d->S <= 32 &&
+         p.Cs % 64 == 0 && p.Cs >= 256 && p.Lk_fwd == d->S * p.Cs;
+}
+
 template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
                       const float* bias, void* y, void* ws, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    if (tapsum_ok(d, p)) {
+      const int cols = d->K * d->R * d->S, zs = (cols + 7) / 8 * 8;
+      FastArgs f = {};
+      f.X = reinterpret_cast<const bf16_t*>(x);
+      f.B = reinterpret_cast<const bf16_t*>(pack);     // row k of the plain panel = [R*S][Cs]: K*R*S rows of Cs
+      f.M = d->N * d->H * d->W;
+      f.OH = d->H;
+      f.OW = d->W;
+      f.IH = d->H;
+      f.IW = d->W;
+      f.Cs = p.Cs;
+      f.R = f.S = 1;
+      f.sy = f.sx = 1;
+      f.Kout = cols;
+      f.Ks = zs;
+      f.b_rows = cols;
+      f.act = JPDSE_ACT_NONE;
+      f.splits = 1;
+      f.no_finish = 1;
+      f.partial = reinterpret_cast<float*>(ws);
+      if (int rc = launch_fast(f, s)) return rc;
+      const long long total = (long long)d->N * p.OH * p.OW * p.Ks;
+      hipLaunchKernelGGL(tapsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, f.partial, bias,
+                         reinterpret_cast<bf16_t*>(y), d->N, d->H, d->W, p.OH, p.OW, d->K, p.Ks, d->R, d->S, d->pad,
+                         d->pad_mode == JPDSE_PAD_REFLECT ? 1 : 0, zs, d->act, d->slope, total);
+      return check_launch("tapsum_kernel");
+    }
     if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks)) {
       HaloArgs h = {};
       h.X = reinterpret_cast<const bf16_t*>(x);
@@ -2050,6 +2129,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
+  g_tapsum_enabled = enable != 13;    // 13: narrow-output layers without the tap-sum forward (A/B)
+  g_thin_out_fast = enable != 13;     // 13: narrow-output long-K layers on the generic kernel (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
   g_wgrad_abl = enable >= 200 ? enable - 200 : 0;   // 200+bits: fast wgrad timing ablations   // 100+bits: halo kernel timing ablations (wrong results)
@@ -2144,6 +2225,10 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
     sk = sk > ring ? sk : ring;
   }
   size_t m = fwd > dgrad ? fwd : dgrad;
+  if (p.ES == 2 && d->stride == 1 && d->K * d->R * d->S <= 32) {      // Z of the tap-sum forward (tapsum_kernel)
+    const size_t zb = (size_t)d->N * d->H * d->W * 32 * sizeof(float);
+    m = m > zb ? m : zb;
+  }
   const size_t taps = wgrad_taps_ws_bytes(d, p);
   m = m > taps ? m : taps;
   return m > sk ? m : sk;

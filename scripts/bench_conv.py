@@ -33,6 +33,7 @@ LAYERS = [
   ('VGG conv3_x 256->256',         128, 256, 256, 256, 3, 1, 1, PAD_ZERO, False),
   ('VGG conv4_x 512->512',         64, 128, 512, 512, 3, 1, 1, PAD_ZERO, False),
   ('L ResBlock 64 3x3 @256x512',    256, 512, 64, 64, 3, 1, 1, PAD_REFLECT, False),
+  ('D layer4 512->1 4x4 s1 @66x130 N8', 66, 130, 512, 1, 4, 1, 2, PAD_ZERO, False),
   ('D layer0 39->64 4x4 s2',       512, 1024, 39, 64, 4, 2, 2, PAD_ZERO, False),
   ('D layer1 64->128 4x4 s2',      257, 513, 64, 128, 4, 2, 2, PAD_ZERO, False),
   ('D layer3 256->512 4x4 s1',     65, 129, 256, 512, 4, 1, 2, PAD_ZERO, False),
