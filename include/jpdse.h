@@ -179,6 +179,12 @@ int jpdse_channel_sum(int32_t dtype, int64_t npix, int32_t C, const void* dy, fl
  * (model.py:455,595,733) and its backward (slice). */
 int jpdse_channel_copy(int32_t dtype, int64_t npix, const void* src, int32_t src_cs, int32_t src_c0,
                        void* dst, int32_t dst_cs, int32_t dst_c0, int32_t nch, void* stream);
+/* out = base with channels [c0, c0+nch) taken from img: `torch.cat((input_label, image), dim=1)`
+ * (pix2pixHD_model.py:456,595) when the label/edge channels of `base` are already in place --
+ * one pass instead of a copy of base plus a channel copy.  cs / img_cs: channel storage of
+ * base,out / img. */
+int jpdse_concat_channels(int32_t dtype, int64_t npix, const void* base, int32_t cs, const void* img,
+                          int32_t img_cs, int32_t c0, int32_t nch, void* out, void* stream);
 /* fill n elements with zero */
 int jpdse_zero(int32_t dtype, int64_t n, void* p, void* stream);
 

@@ -240,6 +240,32 @@ __global__ void channel_copy_kernel(const T* __restrict__ src, int src_cs, int s
   }
 }
 
+// out[p][:] = base[p][:] except channels [c0, c0+nch) = img[p][0..nch): torch.cat((labels, image), dim=1) when the
+// label part of `base` is already in place (one pass instead of a copy of base + a channel copy)
+template <typename T>
+__global__ void concat_channels_kernel(const T* __restrict__ base, const T* __restrict__ img, T* __restrict__ out,
+                                       int cs, int img_cs, int c0, int nch, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = cs / VE;
+  GRID_STRIDE(idx, total_vec) {
+    const int v = (int)(idx % cv);
+    const long long p = idx / cv;
+    const int cb = v * VE;
+    u32x4 val = *reinterpret_cast<const u32x4*>(base + p * cs + cb);
+    if (cb + VE > c0 && cb < c0 + nch) {
+      T tmp[VE];
+      *reinterpret_cast<u32x4*>(tmp) = val;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const int c = cb + e;
+        if (c >= c0 && c < c0 + nch) tmp[e] = img[p * img_cs + (c - c0)];
+      }
+      val = *reinterpret_cast<const u32x4*>(tmp);
+    }
+    *reinterpret_cast<u32x4*>(out + p * cs + cb) = val;
+  }
+}
+
 // ---- layout conversion ---------------------------------------------------------------------
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int Cs, long long HW,
@@ -595,6 +621,20 @@ int jpdse_channel_copy(int32_t dtype, int64_t npix, const void* src, int32_t src
     hipLaunchKernelGGL((channel_copy_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
                        cptr<float>(src), src_cs, src_c0, mptr<float>(dst), dst_cs, dst_c0, nch, total);
   return check_launch("channel_copy");
+}
+
+int jpdse_concat_channels(int32_t dtype, int64_t npix, const void* base, int32_t cs, const void* img, int32_t img_cs,
+                          int32_t c0, int32_t nch, void* out, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && base && img && out && npix > 0 && nch > 0, "concat_channels: bad argument");
+  JPDSE_REQUIRE(cs % 8 == 0 && c0 >= 0 && c0 + nch <= cs && nch <= img_cs, "concat_channels: channel range out of bounds");
+  const long long tv = (long long)npix * (cs / (16 / (int)esize(dtype)));
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((concat_channels_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(base), cptr<bf16_t>(img), mptr<bf16_t>(out), cs, img_cs, c0, nch, tv);
+  else
+    hipLaunchKernelGGL((concat_channels_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
+                       cptr<float>(base), cptr<float>(img), mptr<float>(out), cs, img_cs, c0, nch, tv);
+  return check_launch("concat_channels");
 }
 
 int jpdse_nchw_to_nhwc(int32_t dtype, int32_t N, int32_t C, int32_t H, int32_t W, const float* src, void* dst,

@@ -254,9 +254,7 @@ class Pix2PixHDModel(BaseModel):
   def _with_image(self, base, img, out=None):
     """torch.cat((input_label, img), dim=1) in NHWC: copy of `base` with the image channels filled."""
     dst = out if out is not None else base.empty_like()
-    dst.t.copy_(base.t)
-    ops.channel_copy(img, 0, dst, self.label_nc, img.C)
-    return dst
+    return ops.concat_channels(base, img, self.label_nc, dst)
 
   # ---- inference ------------------------------------------------------------------------------
   def get_img(self, x_dict):

@@ -222,6 +222,14 @@ def channel_copy(src, src_c0, dst, dst_c0, nch):
         'channel_copy')
 
 
+def concat_channels(base, img, c0, out):
+  """out = base with channels [c0, c0 + img.C) replaced by img (both NHWC Acts of the same N,H,W)."""
+  npix = base.N * base.H * base.W
+  check(lib().jpdse_concat_channels(base.dtype, npix, _p(base.t), base.t.shape[-1], _p(img.t), img.t.shape[-1], c0,
+                                    img.C, _p(out.t), _stream()), 'concat_channels')
+  return out
+
+
 def nchw_to_nhwc(src, dtype_code):
   """fp32 NCHW device tensor -> Act."""
   assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 4

@@ -183,6 +183,18 @@ def test_conv_dgrad_fused_relu(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_concat_channels(dtype):
+  """torch.cat((labels, image), 1) into a base whose label channels are in place (36 + 3 -> 39 of 40 lanes)."""
+  g = G(17)
+  base = quantize_like(torch.randn(2, 39, 5, 7, generator=g), dtype)
+  img = quantize_like(torch.randn(2, 3, 5, 7, generator=g), dtype)
+  out = ops.concat_channels(to_act(base, dtype), to_act(img, dtype), 36, to_act(torch.zeros(2, 39, 5, 7), dtype))
+  ref = torch.cat((base[:, :36], img), dim=1)
+  assert torch.equal(to_nchw(out), ref)
+  assert (out.t[..., 39:] == 0).all()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_l1_bwd_relu_mask(dtype):
   g = G(91)
   a = quantize_like(F.relu(torch.randn(2, 24, 5, 7, generator=g)), dtype)
