@@ -99,6 +99,23 @@ size_t jpdse_conv_dgrad_pack_size(const jpdse_conv_desc* d);
 /* master fp32 KRSC -> compute-dtype panels (either output pointer may be NULL to skip) */
 int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w_krsc, void* fwd_pack,
                             void* dgrad_pack, void* stream);
+/* Batched re-packing of the data-gradient panels of many layers in ONE launch (per optimizer step every
+ * conv of the stepped network needs a fresh panel).  jpdse_conv_pack_entries (host only, no GPU work)
+ * appends one entry per stride phase of layer `d` to `out` and returns their number, or -1 when the
+ * layer cannot be batched (fp32, or a phase whose panel rows are padded): use jpdse_conv_pack_weights
+ * for those.  The caller fills `block0` with the running sum of `blocks` over its whole table, uploads
+ * the table once and calls jpdse_conv_pack_run(table_dev, n, total_blocks) after each optimizer step. */
+typedef struct jpdse_pack_entry {
+  const float* w;   /* fp32 KRSC master */
+  void* out;        /* this phase's panel inside the layer's dgrad pack */
+  int32_t K, Ks, C, Cs, R, S, st, qh, qw, Uh, Uw, Lk, gx, gy;
+  int64_t blocks;   /* thread blocks this entry needs */
+  int64_t block0;   /* first block of this entry in the launch */
+} jpdse_pack_entry;
+int jpdse_conv_pack_entries(const jpdse_conv_desc* d, const float* w_krsc, void* dgrad_pack,
+                            jpdse_pack_entry* out, int32_t max_entries);
+int jpdse_conv_pack_run(const jpdse_pack_entry* table_dev, int32_t n_entries, int64_t total_blocks,
+                        void* stream);
 /* workspace needed by fwd / dgrad / wgrad (max over the three) */
 size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d);
 /* y = act(conv(pad(x)) + bias); bias may be NULL (convs feeding an affine-less

@@ -733,6 +733,36 @@ __global__ __launch_bounds__(256) void pack_dgrad_tile_kernel(const float* __res
   }
 }
 
+// The same transpose for MANY layers / stride phases in one launch (per-layer launches of 8-18 us each added up
+// to 1 ms per optimizer step): block -> table entry by binary search on block0, as in adam_kernel.
+__global__ __launch_bounds__(256) void pack_dgrad_tile_many_kernel(const jpdse_pack_entry* __restrict__ table, int n) {
+  __shared__ float tile[64][65];
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block0 <= blk) lo = mid;
+    else hi = mid - 1;
+  }
+  const jpdse_pack_entry e = table[lo];
+  const int id = (int)(blk - e.block0);
+  const int bx = id % e.gx, by = (id / e.gx) % e.gy, bz = id / (e.gx * e.gy);
+  const int c0 = bx * 64, k0 = by * 64;
+  const int up = bz / e.Uw, wp = bz % e.Uw;
+  const int r = e.qh + e.st * (e.Uh - 1 - up), s = e.qw + e.st * (e.Uw - 1 - wp);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int kk = ty; kk < 64; kk += 4) {
+    const int k = k0 + kk, c = c0 + tx;
+    tile[kk][tx] = (k < e.K && c < e.C) ? e.w[(((long long)k * e.R + r) * e.S + s) * e.C + c] : 0.f;
+  }
+  __syncthreads();
+  bf16_t* const out = reinterpret_cast<bf16_t*>(e.out);
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, k = k0 + tx;
+    if (c < e.Cs && k < e.Ks) out[((long long)c * e.Uh + up) * e.Lk + wp * e.Ks + k] = f2bf(tile[tx][cc]);
+  }
+}
+
 // =========================================================================================
 // host side: planning and launch
 // =========================================================================================
@@ -2232,6 +2262,39 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   const size_t taps = wgrad_taps_ws_bytes(d, p);
   m = m > taps ? m : taps;
   return m > sk ? m : sk;
+}
+
+int jpdse_conv_pack_entries(const jpdse_conv_desc* d, const float* w, void* dgrad_pack, jpdse_pack_entry* out,
+                            int32_t max_entries) {
+  if (validate(d)) return -1;
+  if (d->dtype != JPDSE_BF16 || w == nullptr || dgrad_pack == nullptr || out == nullptr) return -1;
+  ConvPlan p;
+  make_plan(d, &p);
+  int n = 0;
+  for (int i = 0; i < p.nph; ++i) {
+    const Phase& f = p.ph[i];
+    if ((long long)p.Cs * f.Uh * f.Lk == 0) continue;
+    if (!(f.Lk == f.Uw * p.Ks && p.Cs * p.Ks >= 64 * 64)) return -1;   // a phase that needs the padded-K kernel
+    if (n >= max_entries) return -1;
+    jpdse_pack_entry e = {};
+    e.w = w;
+    e.out = reinterpret_cast<char*>(dgrad_pack) + f.pack_off;
+    e.K = d->K; e.Ks = p.Ks; e.C = d->C; e.Cs = p.Cs; e.R = d->R; e.S = d->S; e.st = d->stride;
+    e.qh = f.qh; e.qw = f.qw; e.Uh = f.Uh; e.Uw = f.Uw; e.Lk = f.Lk;
+    e.gx = (p.Cs + 63) / 64; e.gy = (p.Ks + 63) / 64;
+    e.blocks = e.gx * e.gy * f.Uh * f.Uw;
+    e.block0 = 0;            // filled by the caller (prefix sum over its whole table)
+    out[n++] = e;
+  }
+  return n;
+}
+
+int jpdse_conv_pack_run(const jpdse_pack_entry* table_dev, int32_t n_entries, int64_t total_blocks, void* stream) {
+  JPDSE_REQUIRE(table_dev != nullptr && n_entries > 0 && total_blocks > 0 && total_blocks < (1LL << 31),
+                "conv_pack_run: bad table");
+  hipLaunchKernelGGL(pack_dgrad_tile_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), table_dev,
+                     n_entries);
+  return check_launch("pack_dgrad_tile_many_kernel");
 }
 
 int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w, void* fwd_pack, void* dgrad_pack,

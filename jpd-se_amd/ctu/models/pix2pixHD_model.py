@@ -26,6 +26,7 @@ from jpdse_hip import F32, BF16, JpdseError, require_gpu
 from jpdse_hip import ops
 from jpdse_hip.ops import Act
 from jpdse_hip.optim import FusedAdam
+from jpdse_hip.layers import PackBatcher
 from ctu.utils.image_pool import ImagePool
 from ctu.utils.misc import tensor2im
 from ctu.models.pix2pixHD_networks.base_model import BaseModel
@@ -386,6 +387,15 @@ class Pix2PixHDModel(BaseModel):
     self.netG.bwd(state['g_ctx'], d_fake, need_dx=False, need_dw=True)
     return True
 
+  def _repack(self, which):
+    """One-launch re-pack of the stepped network's data-gradient panels (jpdse_hip.layers.PackBatcher)."""
+    if not hasattr(self, '_pack_batchers'):
+      self._pack_batchers = {}
+    b = self._pack_batchers.get(which)
+    if b is None:
+      b = self._pack_batchers[which] = PackBatcher(self.netG if which == 'G' else self.netD)
+    b.run()
+
   def backward_D(self, state, w_d):
     """d(loss_D)/d(netD params), loss_D = w_d * (D_fake + D_real)  (w_d = 0.5 in the trainer)."""
     if w_d == 0.0 or state['pred'] is None:
@@ -416,11 +426,13 @@ class Pix2PixHDModel(BaseModel):
       if bg is not None:
         bg.finish()
       optimizer_G.step()
+      self._repack('G')
     bd = self.grad_buckets.get('D')
     if self.backward_D(state, 0.0 if opt.no_d_gan_loss else 0.5):
       if bd is not None:
         bd.finish()
       optimizer_D.step()
+      self._repack('D')
     return self._reduce_losses(slots.cpu().tolist(), layout)
 
   # ------------------------------------------------------------------------------------------

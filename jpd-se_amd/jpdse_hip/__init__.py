@@ -32,6 +32,12 @@ class InormDesc(ctypes.Structure):
               ('slope', ctypes.c_float), ('eps', ctypes.c_float), ('has_residual', ctypes.c_int32)]
 
 
+class PackEntry(ctypes.Structure):
+  _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + \
+             [(n, ctypes.c_int32) for n in ('K', 'Ks', 'C', 'Cs', 'R', 'S', 'st', 'qh', 'qw', 'Uh', 'Uw', 'Lk', 'gx', 'gy')] + \
+             [('blocks', ctypes.c_int64), ('block0', ctypes.c_int64)]
+
+
 class AdamEntry(ctypes.Structure):
   _fields_ = [('p', ctypes.c_void_p), ('g', ctypes.c_void_p), ('m', ctypes.c_void_p),
               ('v', ctypes.c_void_p), ('n', ctypes.c_int64), ('block0', ctypes.c_int64),
@@ -54,6 +60,8 @@ SIGNATURES = {
     'jpdse_conv_plan_query': (_I32, [_CD, ctypes.POINTER(_I32), _I32]),
     'jpdse_conv_fwd_pack_size': (_SZ, [_CD]),
     'jpdse_conv_dgrad_pack_size': (_SZ, [_CD]),
+    'jpdse_conv_pack_entries': (_I32, [_CD, _P, _P, ctypes.POINTER(PackEntry), _I32]),
+    'jpdse_conv_pack_run': (_I32, [_P, _I32, _I64, _P]),
     'jpdse_conv_pack_weights': (_I32, [_CD, _P, _P, _P, _P]),
     'jpdse_conv_workspace_size': (_SZ, [_CD]),
     'jpdse_conv_fwd': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -8,6 +8,7 @@ layout while their memory is channels_last (= KRSC, the ABI's m
 layout), so `state_dict()` round-trips with reference `net_G.pth` / `net_D.pth` files.
 Weight gradients are written by the kernels straight into persistent `.grad` buffers.
 """
+import ctypes
 import math
 
 import torch
@@ -120,6 +121,31 @@ class HipConv2d(nn.Module):
       self._pack_key = key
     return self._packs
 
+  def _pack_key_now(self):
+    w = self._master()
+    return (w._version, _weights_epoch[0], w.data_ptr(), self.cdtype, getattr(w, '_jpdse_wver', 0))
+
+  def batched_pack_entries(self):
+    """Table entries for PackBatcher, or None when this layer needs its own pack call right now (first use,
+    fp32, forward panel not written by Adam, weights replaced, padded panel rows)."""
+    w = self._master()
+    if self._packs is None or self._pack_key is None or self.cdtype != BF16:
+      return None
+    key = self._pack_key_now()
+    if key == self._pack_key:
+      return []                                     # nothing to do
+    if not (getattr(w, '_jpdse_cast_out', None) is self._packs[0] and
+            getattr(w, '_jpdse_cast_wver', None) == key[4] and self._pack_key[:4] == key[:4]):
+      return None
+    if getattr(self, '_pack_entries_cache', None) is None or self._pack_entries_cache[0] != (w.data_ptr(), self._packs[1].data_ptr()):
+      from . import lib, PackEntry
+      buf = (PackEntry * 4)()
+      d = self._desc(1, 64, 64)
+      n = lib().jpdse_conv_pack_entries(ctypes.byref(d), ctypes.c_void_p(w.data_ptr()),
+                                        ctypes.c_void_p(self._packs[1].data_ptr()), buf, 4)
+      self._pack_entries_cache = ((w.data_ptr(), self._packs[1].data_ptr()), [buf[i] for i in range(n)] if n >= 0 else None)
+    return self._pack_entries_cache[1]
+
   def _wgrad_buffer(self):
     w = self.weight
     if w.grad is None or w.grad.data_ptr() == 0 or not w.grad.permute(0, 2, 3, 1).is_contiguous():
@@ -181,6 +207,45 @@ class HipConv2d(nn.Module):
   def _fire(self):
     if self.grad_ready_hook is not None:
       self.grad_ready_hook(self)
+
+
+class PackBatcher(object):
+  """Re-packs the data-gradient panels of all conv layers of one network in ONE launch right after its
+  optimizer step (jpdse_conv_pack_run); layers it cannot cover keep their lazy per-layer pack."""
+
+  def __init__(self, net):
+    self.net = net
+    self._sig = None
+    self._table = None
+
+  def run(self):
+    from . import lib, check, PackEntry
+    layers, entries = [], []
+    for m in self.net.modules():
+      if isinstance(m, HipConv2d):
+        e = m.batched_pack_entries()
+        if e:
+          layers.append(m)
+          entries.extend(e)
+    if not entries:
+      return 0
+    sig = tuple((e.w, e.out) for e in entries)
+    if sig != self._sig:
+      arr = (PackEntry * len(entries))()
+      block0 = 0
+      for i, e in enumerate(entries):
+        arr[i] = e
+        arr[i].block0 = block0
+        block0 += e.blocks
+      host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+      self._table = (host.to(layers[0].weight.device), len(entries), block0)
+      self._sig = sig
+    dev, n, total = self._table
+    check(lib().jpdse_conv_pack_run(ctypes.c_void_p(dev.data_ptr()), n, total,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'conv_pack_run')
+    for m in layers:
+      m._pack_key = m._pack_key_now()
+    return len(layers)
 
 
 class InstNormAct(object):
