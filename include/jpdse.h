@@ -233,6 +233,12 @@ int jpdse_l1_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const v
  * ReLU backward of torchvision's in-place nn.ReLU into the loss gradient). */
 int jpdse_l1_bwd_relu(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b,
                       const float* gout, float scale, void* da, void* stream);
+/* L1Loss forward and backward in ONE pass over a, b: out[0] = mean|a-b| and
+ * da = scale/count * sign(a-b) (* [a > 0] when relu_a).  Valid because the upstream gradient of every
+ * L1 term of loss_G is a constant known at forward time (the loss weights of
+ * pix2pixHD_trainer.py:48-56): saves re-reading both operands in the backward pass. */
+int jpdse_l1_fwd_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out,
+                     float scale, int32_t relu_a, void* da, void* ws, size_t ws_bytes, void* stream);
 /* out[0] = mean (a-b)^2 (nn.MSELoss distortion: model.py:219-220) */
 int jpdse_mse_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out,
                   void* ws, size_t ws_bytes, void* stream);

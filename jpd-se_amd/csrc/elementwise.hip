@@ -222,12 +222,32 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
   }
 }
 
-__global__ void channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int Cs, int nblk) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cs) return;
+// 256 threads = 64 channels x 4 groups of partial blocks, 8 independent loads in flight per thread (a serial loop
+// over up to 2048 partials per channel was latency-bound: 60 us); fixed summation order
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                               int Cs, int nblk) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float a = 0.f;
-  for (int b = 0; b < nblk; ++b) a += partial[(long long)b * Cs + c];
-  out[c] = a;
+  if (c < Cs) {
+    const int per = (nblk + 3) / 4;
+    const int b0 = grp * per;
+    int b1 = b0 + per;
+    b1 = b1 < nblk ? b1 : nblk;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(b + u) * Cs + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; b < b1; ++b) a += partial[(long long)b * Cs + c];
+  }
+  red[grp][cl] = a;
+  __syncthreads();
+  if (grp == 0 && c < Cs) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 template <typename T>
@@ -333,10 +353,12 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return t;
 }
 
+// da (optional, L1 only): the gradient sign(a-b) * gscale (* [a > 0] when relu_a), written in the same pass
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                           float target, int cs, float* __restrict__ partial,
-                                                          long long total) {
+                                                          long long total, T* __restrict__ da = nullptr,
+                                                          float gscale = 0.f, int relu_a = 0) {
   constexpr int VE = Vec16<T>::N;
   __shared__ float red[4];
   float acc = 0.f;
@@ -354,7 +376,12 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__
       for (int e = 0; e < VE; ++e) {
         const float d = x[e] - y[e];
         acc += (MODE == RED_L1) ? fabsf(d) : d * d;
+        if (MODE == RED_L1) {
+          const bool dead = relu_a && !(x[e] > 0.f);
+          x[e] = dead ? 0.f : (d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f));
+        }
       }
+      if (MODE == RED_L1 && da != nullptr) Vec16<T>::store(da + idx * VE, x);
     }
   }
   const float t = block_sum_256(acc, red);
@@ -603,7 +630,7 @@ int jpdse_channel_sum(int32_t dtype, int64_t npix, int32_t C, const void* dy, fl
     hipLaunchKernelGGL((channel_sum_kernel<float>), dim3(nblk * col_blocks), dim3(256), 0, as_stream(stream),
                        cptr<float>(dy), partial, (long long)npix, Cs, TX, TY, ppb);
   if (int rc = check_launch("channel_sum")) return rc;
-  hipLaunchKernelGGL(channel_sum_final_kernel, dim3((Cs + 255) / 256), dim3(256), 0, as_stream(stream), partial, out,
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3((Cs + 63) / 64), dim3(256), 0, as_stream(stream), partial, out,
                      Cs, nblk);
   return check_launch("channel_sum_final");
 }
@@ -742,6 +769,27 @@ int jpdse_l1_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const v
   if (int rc = vec_count("l1_bwd", dtype, n, &tv)) return rc;
   JPDSE_REQUIRE(b != nullptr, "l1_bwd: null b");
   return loss_bwd<RED_L1>("l1_bwd", dtype, tv, count, a, b, 0.f, 0, gout, scale, da, stream);
+}
+int jpdse_l1_fwd_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out, float scale,
+                     int32_t relu_a, void* da, void* ws, size_t ws_bytes, void* stream) {
+  long long tv;
+  if (int rc = vec_count("l1_fwd_bwd", dtype, n, &tv)) return rc;
+  JPDSE_REQUIRE(a && b && out && da && count > 0, "l1_fwd_bwd: bad argument");
+  if (ws == nullptr || ws_bytes < kRedBlocks * sizeof(float))
+    return set_error(JPDSE_EWORKSPACE, "l1_fwd_bwd: workspace too small");
+  int grid = ew_blocks(tv);
+  if (grid > kRedBlocks) grid = kRedBlocks;
+  float* partial = reinterpret_cast<float*>(ws);
+  const float gs = scale / (float)count;
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((loss_partial_kernel<bf16_t, RED_L1>), dim3(grid), dim3(256), 0, as_stream(stream),
+                       cptr<bf16_t>(a), cptr<bf16_t>(b), 0.f, 0, partial, tv, mptr<bf16_t>(da), gs, relu_a);
+  else
+    hipLaunchKernelGGL((loss_partial_kernel<float, RED_L1>), dim3(grid), dim3(256), 0, as_stream(stream),
+                       cptr<float>(a), cptr<float>(b), 0.f, 0, partial, tv, mptr<float>(da), gs, relu_a);
+  if (int rc = check_launch("l1_fwd_bwd")) return rc;
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, grid, 1.f / (float)count, out);
+  return check_launch("l1_fwd_bwd");
 }
 int jpdse_l1_bwd_relu(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, const float* gout,
                       float scale, void* da, void* stream) {

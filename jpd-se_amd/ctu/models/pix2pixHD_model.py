@@ -277,8 +277,11 @@ class Pix2PixHDModel(BaseModel):
     return slot[0]
 
   # ---- training -------------------------------------------------------------------------------
-  def _forward_losses(self, x_dict):
-    """Forward pass of the whole loss graph.  Returns (state for backward, slots tensor, layout)."""
+  def _forward_losses(self, x_dict, grad_w=None):
+    """Forward pass of the whole loss graph.  Returns (state for backward, slots tensor, layout).
+    grad_w = dict(feat=, vgg=, dist=) (train_step): the gradients of the L1 terms -- whose upstream
+    gradient is just that constant weight -- are produced in the same pass as the loss values
+    (jpdse_l1_fwd_bwd) and handed to backward_G through `state`."""
     opt = self.opt
     dev = self._device()
     pre = self.preprocess(x_dict)
@@ -315,6 +318,8 @@ class Pix2PixHDModel(BaseModel):
     layout['dist'] = o
     slots = torch.zeros(o + 1, dtype=torch.float32, device=dev)
     s = lambda i: slots[i:i + 1]
+    gw = grad_w or {}
+    d_feat, d_vgg, d_dist = None, None, None
     for i in range(nD if run_d else 0):
       p = pred[i][-1]
       ops.mse_const_fwd(p.batch_slice(0, B), 0.0, s(layout['D_fake'][i]))
@@ -322,11 +327,25 @@ class Pix2PixHDModel(BaseModel):
       ops.mse_const_fwd(p.batch_slice(0, B), 1.0, s(layout['G_GAN'][i]))
       for j in range(nF):
         f = pred[i][j]
-        ops.l1_fwd(f.batch_slice(0, B), f.batch_slice(B, 2 * B), s(layout['feat'][i][j]))
+        ff, fr = f.batch_slice(0, B), f.batch_slice(B, 2 * B)
+        if gw.get('feat') and j < nF - 1:
+          d_feat = d_feat if d_feat is not None else [[None] * nF for _ in range(nD)]
+          d_feat[i][j] = ops.l1_fwd_bwd(ff, fr, s(layout['feat'][i][j]), gw['feat'] / nD)
+        else:
+          ops.l1_fwd(ff, fr, s(layout['feat'][i][j]))
+    wk = networks.VGGLoss.weights
     for k in range(len(vf)):
-      ops.l1_fwd(vf[k], vr[k], s(layout['vgg'][k]))
-    (ops.l1_fwd if opt.distortion_loss_fn == 'l1' else ops.mse_fwd)(fake, real, s(layout['dist']))
-    state = dict(B=B, fake=fake, real=real, g_ctx=g_ctx, pred=pred, d_ctx=d_ctx, vf=vf, vr=vr, v_ctx=v_ctx)
+      if gw.get('vgg') and v_ctx is not None:
+        d_vgg = d_vgg if d_vgg is not None else [None] * len(vf)
+        d_vgg[k] = ops.l1_fwd_bwd(vf[k], vr[k], s(layout['vgg'][k]), gw['vgg'] * wk[k], relu_a=True)
+      else:
+        ops.l1_fwd(vf[k], vr[k], s(layout['vgg'][k]))
+    if opt.distortion_loss_fn == 'l1' and gw.get('dist'):
+      d_dist = ops.l1_fwd_bwd(fake, real, s(layout['dist']), gw['dist'])
+    else:
+      (ops.l1_fwd if opt.distortion_loss_fn == 'l1' else ops.mse_fwd)(fake, real, s(layout['dist']))
+    state = dict(B=B, fake=fake, real=real, g_ctx=g_ctx, pred=pred, d_ctx=d_ctx, vf=vf, vr=vr, v_ctx=v_ctx,
+                 d_feat=d_feat, d_vgg=d_vgg, d_dist=d_dist)
     return state, slots, layout
 
   def _reduce_losses(self, vals, layout):
@@ -367,20 +386,25 @@ class Pix2PixHDModel(BaseModel):
           ff, fr = f.batch_slice(0, B), f.batch_slice(B, 2 * B)
           if j == len(state['pred'][i]) - 1:
             row.append(ops.mse_const_bwd(ff, 1.0, one, w_gan) if w_gan != 0.0 else None)
+          elif w_feat == 0.0:
+            row.append(None)
+          elif state.get('d_feat') is not None and state['d_feat'][i][j] is not None:
+            row.append(state['d_feat'][i][j])           # produced with the loss value (l1_fwd_bwd)
           else:
-            row.append(ops.l1_bwd(ff, fr, one, w_feat / opt.num_D) if w_feat != 0.0 else None)
+            row.append(ops.l1_bwd(ff, fr, one, w_feat / opt.num_D))
         dres.append(row)
       d_in = self.netD.bwd(state['d_ctx'], dres, need_dx=True, need_dw=False, batch=(0, B))
       d_fake = Act(torch.zeros_like(fake.t), fake.C)
       ops.channel_copy(d_in, self.label_nc, d_fake, 0, fake.C)
     if w_vgg != 0.0 and state['v_ctx'] is not None:
       wk = networks.VGGLoss.weights
-      dmaps = [ops.l1_bwd(state['vf'][k], state['vr'][k], one, w_vgg * wk[k], relu_a=True) for k in range(len(wk))]
+      dmaps = state.get('d_vgg') or [ops.l1_bwd(state['vf'][k], state['vr'][k], one, w_vgg * wk[k], relu_a=True)
+                                     for k in range(len(wk))]
       dv = self.criterionVGG.vgg.bwd(state['v_ctx'], dmaps)
       d_fake = dv if d_fake is None else ops.add_(d_fake, dv)
     if w_dist != 0.0:
       fn = ops.l1_bwd if opt.distortion_loss_fn == 'l1' else ops.mse_bwd
-      dd = fn(fake, real, one, w_dist)
+      dd = state['d_dist'] if state.get('d_dist') is not None else fn(fake, real, one, w_dist)
       d_fake = dd if d_fake is None else ops.add_(d_fake, dd)
     if d_fake is None:
       return False
@@ -416,11 +440,11 @@ class Pix2PixHDModel(BaseModel):
     """One optimisation step with the reference's order (pix2pixHD_trainer.py:44-78): forward,
     loss_G backward + Adam(G), loss_D backward + Adam(D).  One host sync (the loss readback)."""
     opt = self.opt
-    state, slots, layout = self._forward_losses(x_dict)
     w_gan = 0.0 if opt.no_g_gan_loss else 1.0
     w_feat = 0.0 if opt.no_gan_feat_loss else opt.lambda_feat
     w_vgg = 0.0 if opt.no_vgg_loss else opt.lambda_feat
     w_dist = 0.0 if opt.no_distortion_loss else opt.lambda_distortion * lambda_distortion_weight
+    state, slots, layout = self._forward_losses(x_dict, grad_w=dict(feat=w_feat, vgg=w_vgg, dist=w_dist))
     bg = self.grad_buckets.get('G')
     if self.backward_G(state, w_gan, w_feat, w_vgg, w_dist):
       if bg is not None:

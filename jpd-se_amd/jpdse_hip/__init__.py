@@ -93,6 +93,7 @@ SIGNATURES = {
     'jpdse_l1_fwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_l1_bwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),
     'jpdse_l1_bwd_relu': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),
+    'jpdse_l1_fwd_bwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _I32, _P, _P, _SZ, _P]),
     'jpdse_mse_fwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_mse_bwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),
     'jpdse_mse_const_fwd': (_I32, [_I32, _I64, _I32, _F, _P, _P, _P, _SZ, _P]),

@@ -269,6 +269,16 @@ def l1_fwd(a, b, out):
   check(lib().jpdse_l1_fwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(out), _p(ws), ws.numel(), _stream()), 'l1_fwd')
 
 
+def l1_fwd_bwd(a, b, out, scale, relu_a=False):
+  """Loss value into `out` and its gradient w.r.t. a (times `scale`) in one pass; returns the gradient."""
+  ws = _loss_ws(a.t.device)
+  da = a.empty_like()
+  count = a.N * a.H * a.W * a.C
+  check(lib().jpdse_l1_fwd_bwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(out), float(scale), int(relu_a),
+                               _p(da.t), _p(ws), ws.numel(), _stream()), 'l1_fwd_bwd')
+  return da
+
+
 def l1_bwd(a, b, gout, scale, relu_a=False):
   """relu_a: `a` is a ReLU output; return the gradient w.r.t. its pre-activation."""
   da = a.empty_like()

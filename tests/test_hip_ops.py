@@ -183,6 +183,19 @@ def test_conv_dgrad_fused_relu(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('relu_a', [False, True])
+def test_l1_fwd_bwd_one_pass(dtype, relu_a):
+  g = G(93)
+  a = quantize_like(F.relu(torch.randn(2, 24, 9, 7, generator=g)), dtype)
+  b = quantize_like(F.relu(torch.randn(2, 24, 9, 7, generator=g)), dtype)
+  slot = torch.zeros(1, dtype=torch.float32, device=DEV)
+  da = ops.l1_fwd_bwd(to_act(a, dtype), to_act(b, dtype), slot, 2.5, relu_a=relu_a)
+  ref = 2.5 * torch.sign(a - b) / a.numel() * ((a > 0) if relu_a else 1.0)
+  assert_close(to_nchw(da), ref, RTOL[dtype], 'fused l1 gradient')
+  assert abs(slot.item() - (a - b).abs().mean().item()) <= 1e-5 * max(1.0, (a - b).abs().mean().item())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_concat_channels(dtype):
   """torch.cat((labels, image), 1) into a base whose label channels are in place (36 + 3 -> 39 of 40 lanes)."""
   g = G(17)
