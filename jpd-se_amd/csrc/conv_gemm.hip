@@ -74,6 +74,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "wgrad_thin.h"
 #include "wgrad_row.h"
 #include "wgrad_taps.h"
+#include "head_fwd.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1185,6 +1186,28 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ Z
   y[idx] = f2bf(v);
 }
 
+static int g_head_fwd_enabled = 1;
+static bool head_fwd_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
+  const int ncols = d->K * d->R * d->S;
+  return g_fast_enabled && g_head_fwd_enabled && p.ES == 2 && d->stride == 1 && d->K <= 3 && p.Ks == 8 &&
+         (p.Cs == 64 || p.Cs == 32) && d->R == 7 && d->S == 7 && ncols <= 160 && p.Lk_fwd == d->S * p.Cs;
+}
+
+template <int CIN>
+static int launch_head_fwd(const HeadFwdArgs& a, hipStream_t s) {
+  constexpr int NT = 5;
+  constexpr int lds = NT * 32 * CIN * 2 + 3 * kHeadMR * CIN * 2 + NT * 32 * kHeadZP * 4 + kHeadTH * 64 * 4 * 4;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fwd_kernel<CIN, NT, 7, 7>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "head_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((head_fwd_kernel<CIN, NT, 7, 7>), dim3(a.N * a.tiles_h * a.tiles_w), dim3(64 * NT), lds, s, a);
+  return check_launch("head_fwd_kernel");
+}
+
 static int g_tapsum_enabled = 1;
 static bool tapsum_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
   return g_fast_enabled && g_tapsum_enabled && p.ES == 2 && d->stride == 1 && d->K * d->R * d->S <= 32 &&
@@ -1195,6 +1218,29 @@ template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
                       const float* bias, void* y, void* ws, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    if (head_fwd_ok(d, p)) {
+      HeadFwdArgs h = {};
+      h.X = reinterpret_cast<const bf16_t*>(x);
+      h.Wp = reinterpret_cast<const bf16_t*>(pack);
+      h.bias = bias;
+      h.Y = reinterpret_cast<bf16_t*>(y);
+      h.N = d->N;
+      h.H = d->H;
+      h.W = d->W;
+      h.OH = p.OH;
+      h.OW = p.OW;
+      h.K = d->K;
+      h.Ks_out = p.Ks;
+      h.R = d->R;
+      h.S = d->S;
+      h.pad = d->pad;
+      h.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+      h.act = d->act;
+      h.slope = d->slope;
+      h.tiles_w = (p.OW + 63) / 64;
+      h.tiles_h = (p.OH + kHeadTH - 1) / kHeadTH;
+      return p.Cs == 64 ? launch_head_fwd<64>(h, s) : launch_head_fwd<32>(h, s);
+    }
     if (tapsum_ok(d, p)) {
       const int cols = d->K * d->R * d->S, zs = (cols + 7) / 8 * 8;
       FastArgs f = {};
@@ -2159,6 +2205,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
+  g_head_fwd_enabled = enable != 14 && enable != 6;   // 14: heads on the Toeplitz GEMM (A/B); 6 keeps the generic order
   g_tapsum_enabled = enable != 13;    // 13: narrow-output layers without the tap-sum forward (A/B)
   g_thin_out_fast = enable != 13;     // 13: narrow-output long-K layers on the generic kernel (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
