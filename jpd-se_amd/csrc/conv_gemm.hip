@@ -1193,18 +1193,17 @@ static bool head_fwd_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
          (p.Cs == 64 || p.Cs == 32) && d->R == 7 && d->S == 7 && ncols <= 160 && p.Lk_fwd == d->S * p.Cs;
 }
 
-template <int CIN>
+template <int CIN, int NT = 5, int FR = 7, int FS = 7>
 static int launch_head_fwd(const HeadFwdArgs& a, hipStream_t s) {
-  constexpr int NT = 5;
   constexpr int lds = NT * 32 * CIN * 2 + 3 * kHeadMR * CIN * 2 + NT * 32 * kHeadZP * 4 + kHeadTH * 64 * 4 * 4;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fwd_kernel<CIN, NT, 7, 7>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fwd_kernel<CIN, NT, FR, FS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "head_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((head_fwd_kernel<CIN, NT, 7, 7>), dim3(a.N * a.tiles_h * a.tiles_w), dim3(64 * NT), lds, s, a);
+  hipLaunchKernelGGL((head_fwd_kernel<CIN, NT, FR, FS>), dim3(a.N * a.tiles_h * a.tiles_w), dim3(64 * NT), lds, s, a);
   return check_launch("head_fwd_kernel");
 }
 
@@ -1619,6 +1618,31 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         rc = check_launch("relu_mask_kernel");
       }
       return rc;
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // few INPUT channels (VGG conv1_1: 3 <- 64): the data gradient is itself a conv with <= 3 output channels; the
+    // single-phase dgrad panel [c][u'][w'][k] is exactly the "plain forward panel" head_fwd_kernel expects
+    if (g_fast_enabled && g_head_fwd_enabled && !refl && st == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && d->C <= 3 &&
+        p.Cs == 8 && p.Ks == 64 && p.nph == 1 && p.ph[0].Lk == 3 * p.Ks && mask == nullptr && addend == nullptr) {
+      HeadFwdArgs h = {};
+      h.X = reinterpret_cast<const bf16_t*>(dy);
+      h.Wp = reinterpret_cast<const bf16_t*>(pack);
+      h.Y = reinterpret_cast<bf16_t*>(dx);
+      h.N = d->N;
+      h.H = p.OH;
+      h.W = p.OW;
+      h.OH = d->H;
+      h.OW = d->W;
+      h.K = d->C;
+      h.Ks_out = p.Cs;
+      h.R = 3;
+      h.S = 3;
+      h.pad = 1;
+      h.act = JPDSE_ACT_NONE;
+      h.tiles_w = (d->W + 63) / 64;
+      h.tiles_h = (d->H + kHeadTH - 1) / kHeadTH;
+      return launch_head_fwd<64, 3, 3, 3>(h, s);
     }
   }
   bool fast = false;
