@@ -2026,7 +2026,8 @@ static int launch_wgrad_taps(const jpdse_conv_desc* d, const ConvPlan& p, int cf
 
 // heads with <= 8 output channels on a 32- / 64-channel input, stride 1 (64->3, 32->3 7x7)
 static bool wgrad_head_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
-  return g_fast_enabled && p.Ks == 8 && d->stride == 1 && (p.Cs == 32 || p.Cs == 64) && d->S * 8 <= 64 && d->R <= 7;
+  return g_fast_enabled && p.Ks == 8 && d->stride == 1 && (p.Cs == 32 || p.Cs == 64) && d->S * 8 <= 64 && d->R <= 7 &&
+         d->R == d->S;
 }
 
 static int launch_wgrad_head(const ThinWgArgs& a, hipStream_t s) {
@@ -2085,15 +2086,11 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       return launch_wgrad_row(w, s);
     }
     if (wgrad_head_ok(d, p)) {
-      // roles swapped (see wgrad_thin.h): A = padded input, run operand = dy zero-padded by (R-1, S-1)
-      if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-        return rc;
-      bf16_t* dyp = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ws) + p.xpad_bytes);
-      if (int rc = launch_pad<T>(dy, dyp, d->N, p.OH, p.OW, 8, d->R - 1, d->R - 1, d->S - 1, d->S - 1, JPDSE_PAD_ZERO, s))
-        return rc;
+      // roles swapped (see wgrad_thin.h): A = padded input, run operand = dy zero-padded by (R-1, S-1); both
+      // paddings are resolved by the loader
       ThinWgArgs t = {};
-      t.XP = dyp;
-      t.DY = reinterpret_cast<const bf16_t*>(ws);
+      t.XP = reinterpret_cast<const bf16_t*>(dy);
+      t.DY = reinterpret_cast<const bf16_t*>(x);
       t.DW = dw;
       t.N = d->N;
       t.OH = p.Hp;
@@ -2107,16 +2104,22 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       t.R = d->R;
       t.S = d->S;
       t.st = 1;
-      t.x_limit = (long long)d->N * t.Hp * t.Wp * 8 + (long long)(kSlackBytes / 2);
+      t.unpadded = 1;
+      t.RH = p.OH;
+      t.RW = p.OW;
+      t.r_pad = d->R - 1;            // square filters on this path (R == S checked by wgrad_head_ok)
+      t.r_reflect = 0;
+      t.AH = d->H;
+      t.AW = d->W;
+      t.a_pad = d->pad;
+      t.a_reflect = d->pad_mode == JPDSE_PAD_REFLECT;
       t.transposed = 1;
       return launch_wgrad_head(t, s);
     }
     if (wgrad_thin_ok(d, p)) {
-      // thin inputs (40-channel network inputs): input strips staged once, see wgrad_thin.h
-      if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-        return rc;
+      // thin inputs (40-channel network inputs): input strips staged once (wgrad_thin.h)
       ThinWgArgs t = {};
-      t.XP = reinterpret_cast<const bf16_t*>(ws);
+      t.XP = reinterpret_cast<const bf16_t*>(x);
       t.DY = reinterpret_cast<const bf16_t*>(dy);
       t.DW = dw;
       t.N = d->N;
@@ -2131,7 +2134,23 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       t.R = d->R;
       t.S = d->S;
       t.st = d->stride;
-      t.x_limit = (long long)d->N * p.Hp * p.Wp * p.Cs + (long long)(kSlackBytes / 2);
+      if (d->stride == 2) {
+        // padding resolved by the loader (no padded copy): pays for the stride-2 layers (PatchGAN layer 0)
+        t.unpadded = 1;
+        t.RH = d->H;
+        t.RW = d->W;
+        t.r_pad = d->pad;
+        t.r_reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+        t.AH = p.OH;
+        t.AW = p.OW;
+      } else {
+        // 7x7 stride-1 first convs: 7 filter rows re-read every strip, the per-lane padding arithmetic costs more
+        // than one pass of pad_kernel (measured 0.65 vs 0.84 ms)
+        if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+          return rc;
+        t.XP = reinterpret_cast<const bf16_t*>(ws);
+        t.x_limit = (long long)d->N * p.Hp * p.Wp * p.Cs + (long long)(kSlackBytes / 2);
+      }
       return launch_wgrad_thin(t, s);
     }
     // the fast kernel's loader uses 32-bit element offsets

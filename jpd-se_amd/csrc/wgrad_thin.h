@@ -36,6 +36,11 @@ struct ThinWgArgs {
   int x_units;         // 1 KiB DMA units per input strip
   long long x_limit;   // elements of XP that may be read (tensor + zeroed slack)
   int transposed;
+  // In-loader padding (no materialised padded copies): XP / DY are the UNPADDED tensors, the padded geometry
+  // (Hp, Wp for the run operand; OH, OW for the dy-side operand) is virtual and every lane resolves its pixel.
+  int unpadded;        // 1: the fields below are valid
+  int RH, RW, r_pad, r_reflect;   // run operand: real dims, padding that produced Hp x Wp
+  int AH, AW, a_pad, a_reflect;   // dy-side operand: real dims, padding that produced OH x OW (0 for a true dy)
 };
 
 // TM m-tiles per wave, WM x WN waves (M = 32*TM*WM channels of the dy operand, WN*NT run tiles)
@@ -126,7 +131,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
 
   // lane constants of the loader (the per-unit part is wave-uniform and stays on the scalar unit)
   const int a_pl = lane / (A_ROWB / 16);                      // pixel within a dy unit
-  const int a_lane_off = a_pl * a.Ks + (((lane % (A_ROWB / 16)) ^ trswz<A_ROWB>(a_pl)) << 3);
+  const int a_slot_off = ((lane % (A_ROWB / 16)) ^ trswz<A_ROWB>(a_pl)) << 3;
+  const int a_lane_off = a_pl * a.Ks + a_slot_off;
+  constexpr int CS = PITCH == 80 ? 40 : PITCH;        // channel storage when the pitch is a compile-time constant
   static_assert(A_PPU % 4 == 0 || A_ROWB >= 256, "swizzle must not depend on the unit index");
   auto issue = [&](int strip, int stage) {
     char* const st = smem + stage * stage_bytes;
@@ -142,7 +149,20 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
       const bf16_t* src;
       if (u < A_UNITS) {
         const int pix0 = u * A_PPU;                   // uniform
-        src = pix0 + a_pl < px_left ? dy_base + (pix0 * a.Ks + a_lane_off) : zero;
+        if (!a.unpadded) {
+          src = pix0 + a_pl < px_left ? dy_base + (pix0 * a.Ks + a_lane_off) : zero;
+        } else {
+          // virtual (oh, ow0 + pix) of the padded grid -> pixel of the real tensor
+          int ay = oh - a.a_pad, ax = ow0 + pix0 + a_pl - a.a_pad;
+          if (a.a_reflect) {
+            ay = ay < 0 ? -ay : (ay >= a.AH ? 2 * (a.AH - 1) - ay : ay);
+            ax = ax < 0 ? -ax : (ax >= a.AW ? 2 * (a.AW - 1) - ax : ax);
+          }
+          const bool arow_ok = (unsigned)ay < (unsigned)a.AH;                                      // uniform
+          const bf16_t* const arow = a.DY + ((long long)n * a.AH + (arow_ok ? ay : 0)) * a.AW * a.Ks;
+          const bool ok = arow_ok && pix0 + a_pl < px_left && (unsigned)ax < (unsigned)a.AW;
+          src = ok ? arow + (__mul24(ax, a.Ks) + a_slot_off) : zero;
+        }
       } else {
         const int ub = u - A_UNITS;
         int rr = 0, uu = ub;
@@ -150,9 +170,25 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
           rr = ub / a.x_units;
           uu = ub - rr * a.x_units;
         }
-        const long long e0 = x_base + rr * x_row + (long long)uu * 512;   // uniform: first element of the unit
         const bool row_ok = r0 + rr < a.R;
-        src = (row_ok && e0 + lane * 8 + 8 <= a.x_limit) ? a.XP + e0 + lane * 8 : zero;
+        if (!a.unpadded) {
+          const long long e0 = x_base + rr * x_row + (long long)uu * 512;   // uniform: first element of the unit
+          src = (row_ok && e0 + lane * 8 + 8 <= a.x_limit) ? a.XP + e0 + lane * 8 : zero;
+        } else {
+          // element offset inside the virtual padded row -> (pixel, channel slot) -> real pixel
+          const int el = uu * 512 + lane * 8;
+          const int pxo = PITCH ? el / CS : el / a.Cs;
+          const int ch = el - pxo * (PITCH ? CS : a.Cs);
+          int ry = oh * a.st + r0 + rr - a.r_pad, rx = ow0 * a.st + pxo - a.r_pad;
+          if (a.r_reflect) {
+            ry = ry < 0 ? -ry : (ry >= a.RH ? 2 * (a.RH - 1) - ry : ry);
+            rx = rx < 0 ? -rx : (rx >= a.RW ? 2 * (a.RW - 1) - rx : rx);
+          }
+          const bool rrow_ok = row_ok && oh * a.st + r0 + rr < a.Hp && (unsigned)ry < (unsigned)a.RH;   // uniform
+          const bf16_t* const rrow = a.XP + ((long long)n * a.RH + (rrow_ok ? ry : 0)) * a.RW * (PITCH ? CS : a.Cs);
+          const bool ok = rrow_ok && ow0 * a.st + pxo < a.Wp && (unsigned)rx < (unsigned)a.RW;
+          src = ok ? rrow + (__mul24(rx, PITCH ? CS : a.Cs) + ch) : zero;
+        }
       }
       glds16(src, st + u * 1024);
     }
