@@ -148,7 +148,7 @@ def main():
     roof = None
     if n.value > 0 and ms.value > 0:
       achieved = fl.value / (ms.value * 1e-3) / 1e12
-      roof = dict(bound='mfma', kernel='gemm_fwd_kernel (ResnetBlock 3x3 conv fwd+dgrad, N=1024 K=9216)',
+      roof = dict(bound='mfma', kernel='gemm_halo_kernel (ResnetBlock 3x3 conv fwd + data gradient, N=1024 K=9216)',
                   achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4),
                   traffic=None, launches_per_step=n.value / args.steps,
                   avg_launch_ms=round(ms.value / n.value, 4),
