@@ -992,8 +992,6 @@ static int launch_wgrad(const GemmWgradArgs& a, hipStream_t s) {
   return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, s);
 }
 
-static int g_fast_variant = 0;   // A/B (scripts/bench_conv.py): the simple schedule is as fast or faster
-
 template <int WM, int WN, int TM, int TN, int VAR, int STAGES = 3>
 static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -1139,8 +1137,11 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   return check_launch("gemm_halo_kernel");
 }
 
+static int g_halo_xcd = 0;
 template <int TN, int ABL = 0>
-static int launch_halo_cfg(const HaloArgs& a, hipStream_t s) {
+static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
+  HaloArgs a = a0;
+  a.xcd_mode = g_halo_xcd;
   if (a.Cs == 64 && ABL == 0 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true>(a, s);   // one slab: single patch buffer
   return launch_halo_cfg_impl<TN, ABL, false>(a, s);
 }
@@ -2247,6 +2248,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
   g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
+  g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_head_fwd_enabled = enable != 14 && enable != 6;   // 14: heads on the Toeplitz GEMM (A/B); 6 keeps the generic order
   g_tapsum_enabled = enable != 13;    // 13: narrow-output layers without the tap-sum forward (A/B)

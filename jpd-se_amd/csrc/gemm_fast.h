@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
 
   // K-tile cursor of the NEXT tile to issue.  The padded source address of a tap is resolved only
   // when the tap (r,s) changes; within a tap consecutive K-tiles advance the pointer by 64 channels.
-  int it = t_begin, istage = 0;
+  int istage = 0;
   int ic = t_begin % CC, is = (t_begin / CC) % a.S, ir = (t_begin / CC) / a.S;
   const bf16_t* a_src[AU];
   int a_step[AU];
@@ -265,7 +265,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
 #pragma unroll
     for (int j = 0; j < BU; ++j)
       if (b_on[j]) glds16(b_ptr[j] + koff, st + b_lds[j]);
-    ++it;
     if (++ic == CC) {
       ic = 0;
       if (++is == a.S) { is = 0; ++ir; }

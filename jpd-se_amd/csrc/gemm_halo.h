@@ -32,6 +32,7 @@ struct HaloArgs {
   float slope;
   const bf16_t* mask;   // optional fused ReLU backward (see FastArgs::mask)
   const bf16_t* addend; // optional: Y = result + addend
+  int xcd_mode;         // 0: block b -> tile b; 1: blocks of one XCD (b % 8) take consecutive tiles; 2: 2 N-tiles x half the patches per XCD
 };
 
 // ABL: timing-only ablation bits (results are wrong when non-zero): 1 = no DMA after the prologue,
@@ -62,7 +63,22 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   const int wm = wid / WN, wn = wid % WN;
   const int tiles_w = a.OW / 64, tiles_h = a.OH / TH;
   const int tiles_m = a.N * tiles_h * tiles_w;
-  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+  // XCD-aware tile order (blocks are dealt round-robin to the 8 XCDs, each with its own L2)
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if (a.xcd_mode != 0 && (nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
+  if (a.xcd_mode == 2 && (tiles_m & 1) == 0) {
+    // pairs of N-tiles share half of the patches: (tile_n pair, half) <- old tile_n; inside: patch fastest
+    const int tiles_n = nblk / tiles_m;
+    if ((tiles_n & 1) == 0) {
+      const int hm = tiles_m >> 1;
+      const int grp = bid / tiles_m, within = bid - grp * tiles_m;      // grp = old tile_n
+      const int pair = grp >> 1, half = grp & 1;
+      tile_n = 2 * pair + (within / hm);
+      tile_m = half * hm + (within % hm);
+    }
+  }
   const int tw_i = tile_m % tiles_w, t1 = tile_m / tiles_w;
   const int th_i = t1 % tiles_h, n = t1 / tiles_h;
   const int oh0 = th_i * TH, ow0 = tw_i * 64, n0 = tile_n * BN;
