@@ -75,6 +75,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "wgrad_row.h"
 #include "wgrad_taps.h"
 #include "head_fwd.h"
+#include "thin_fwd.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -809,6 +810,8 @@ struct ConvPlan {
   size_t xpad_bytes, dypad_bytes, dxp_bytes;
   size_t splitk_off, splitk_bytes;   // fp32 partial slabs of the split-K fast path (behind the other regions)
   int toep, Lk_toep;                 // bf16 head (<= 8 output channels, stride 1): extra Toeplitz forward panel
+  int thinf, KP_thin;                // bf16 stride-1 conv on a thin input: extra [R][K][KP] panel (thin_fwd.h)
+  size_t thin_pack_off;
   size_t fwd_pack_plain_bytes, fwd_pack_bytes;
 };
 
@@ -887,6 +890,10 @@ static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
   p->toep = (p->ES == 2 && p->Ks == 8 && st == 1) ? 1 : 0;
   p->Lk_toep = p->toep ? round_up((d->S + 3) * p->Cs, p->BKE) : 0;
   p->fwd_pack_bytes = p->fwd_pack_plain_bytes + (p->toep ? align_up((size_t)32 * d->R * p->Lk_toep * p->ES, 256) : 0);
+  p->thinf = (p->ES == 2 && st == 1 && p->Cs % 64 != 0 && p->Cs <= 40 && (p->Ks == 32 || p->Ks == 64) && d->K == p->Ks) ? 1 : 0;
+  p->KP_thin = p->thinf ? round_up(d->S * p->Cs, 16) + 8 : 0;
+  p->thin_pack_off = p->fwd_pack_bytes;
+  if (p->thinf) p->fwd_pack_bytes += align_up((size_t)d->R * p->Ks * p->KP_thin * 2, 256);
   if (p->toep) {
     // the Toeplitz rows of the last pixel group read (S+3)*Cs rounded up to a chunk: keep that inside the slack
     p->xpad_bytes = align_up(p->xpad_bytes + (size_t)p->BKE * p->ES, 256);
@@ -1187,6 +1194,33 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ Z
   y[idx] = f2bf(v);
 }
 
+static int g_thin_fwd_enabled = 1;
+static int thin_fwd_lds(const jpdse_conv_desc* d, const ConvPlan& p, int* strip_units, int* w_units) {
+  *strip_units = ((64 + d->S - 1) * p.Cs * 2 + 16 + 1023) / 1024;
+  *w_units = (p.Ks * p.KP_thin * 2 + 1023) / 1024;
+  int lds = ((kThinTH + d->R - 1) * *strip_units + 2 * *w_units) * 1024;
+  const int epi = kThinTH * 64 * (p.Ks * 2 + 64);
+  return lds > epi ? lds : epi;
+}
+static bool thin_fwd_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
+  if (!(g_fast_enabled && g_thin_fwd_enabled && p.thinf)) return false;
+  int su, wu;
+  return thin_fwd_lds(d, p, &su, &wu) <= 160 * 1024;
+}
+
+template <int TN>
+static int launch_thin_fwd(const ThinFwdArgs& a, int lds, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((thin_fwd_kernel<TN>), dim3(a.N * a.tiles_h * a.tiles_w), dim3(512), lds, s, a);
+  return check_launch("thin_fwd_kernel");
+}
+
 static int g_head_fwd_enabled = 1;
 static bool head_fwd_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
   const int ncols = d->K * d->R * d->S;
@@ -1218,6 +1252,33 @@ template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
                       const float* bias, void* y, void* ws, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    if (thin_fwd_ok(d, p)) {
+      ThinFwdArgs t = {};
+      t.X = reinterpret_cast<const bf16_t*>(x);
+      t.Wt = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + p.thin_pack_off);
+      t.bias = bias;
+      t.Y = reinterpret_cast<bf16_t*>(y);
+      t.N = d->N;
+      t.H = d->H;
+      t.W = d->W;
+      t.OH = p.OH;
+      t.OW = p.OW;
+      t.Cs = p.Cs;
+      t.K = d->K;
+      t.Ks = p.Ks;
+      t.R = d->R;
+      t.S = d->S;
+      t.pad = d->pad;
+      t.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+      t.act = d->act;
+      t.slope = d->slope;
+      t.KP = p.KP_thin;
+      t.ksteps = (p.KP_thin - 8) / 16;
+      const int lds = thin_fwd_lds(d, p, &t.strip_units, &t.w_units);
+      t.tiles_w = (p.OW + 63) / 64;
+      t.tiles_h = (p.OH + kThinTH - 1) / kThinTH;
+      return p.Ks == 64 ? launch_thin_fwd<2>(t, lds, s) : launch_thin_fwd<1>(t, lds, s);
+    }
     if (head_fwd_ok(d, p)) {
       HeadFwdArgs h = {};
       h.X = reinterpret_cast<const bf16_t*>(x);
@@ -2251,6 +2312,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_head_fwd_enabled = enable != 14 && enable != 6;   // 14: heads on the Toeplitz GEMM (A/B); 6 keeps the generic order
+  g_thin_fwd_enabled = enable != 18;  // 18: thin-input forward on the generic kernel (A/B)
   g_tapsum_enabled = enable != 13;    // 13: narrow-output layers without the tap-sum forward (A/B)
   g_thin_out_fast = enable != 13;     // 13: narrow-output long-K layers on the generic kernel (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
@@ -2415,6 +2477,13 @@ int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w, void* fwd_
       hipLaunchKernelGGL((pack_fwd_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
                          reinterpret_cast<float*>(fwd_pack), d->K, p.Ks, d->C, p.Cs, d->R, d->S, p.Lk_fwd, total);
     if (int rc = check_launch("pack_fwd_kernel")) return rc;
+  }
+  if (fwd_pack && p.thinf) {
+    const long long total = (long long)d->R * p.Ks * p.KP_thin;
+    hipLaunchKernelGGL(pack_thin_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, w,
+                       reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(fwd_pack) + p.thin_pack_off), d->K, p.Ks, d->C,
+                       p.Cs, d->R, d->S, p.KP_thin, total);
+    if (int rc = check_launch("pack_thin_fwd_kernel")) return rc;
   }
   if (fwd_pack && p.toep) {
     const long long total = (long long)32 * d->R * p.Lk_toep;
