@@ -890,7 +890,7 @@ static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
   p->toep = (p->ES == 2 && p->Ks == 8 && st == 1) ? 1 : 0;
   p->Lk_toep = p->toep ? round_up((d->S + 3) * p->Cs, p->BKE) : 0;
   p->fwd_pack_bytes = p->fwd_pack_plain_bytes + (p->toep ? align_up((size_t)32 * d->R * p->Lk_toep * p->ES, 256) : 0);
-  p->thinf = (p->ES == 2 && st == 1 && p->Cs % 64 != 0 && p->Cs <= 40 && (p->Ks == 32 || p->Ks == 64) && d->K == p->Ks) ? 1 : 0;
+  p->thinf = (p->ES == 2 && p->Cs % 64 != 0 && p->Cs <= 48 && st <= 2 && (p->Ks == 32 || p->Ks == 64) && d->K == p->Ks) ? 1 : 0;
   p->KP_thin = p->thinf ? round_up(d->S * p->Cs, 16) + 8 : 0;
   p->thin_pack_off = p->fwd_pack_bytes;
   if (p->thinf) p->fwd_pack_bytes += align_up((size_t)d->R * p->Ks * p->KP_thin * 2, 256);
@@ -1195,29 +1195,37 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ Z
 }
 
 static int g_thin_fwd_enabled = 1;
-static int thin_fwd_lds(const jpdse_conv_desc* d, const ConvPlan& p, int* strip_units, int* w_units) {
-  *strip_units = ((64 + d->S - 1) * p.Cs * 2 + 16 + 1023) / 1024;
-  *w_units = (p.Ks * p.KP_thin * 2 + 1023) / 1024;
-  int lds = ((kThinTH + d->R - 1) * *strip_units + 2 * *w_units) * 1024;
-  const int epi = kThinTH * 64 * (p.Ks * 2 + 64);
-  return lds > epi ? lds : epi;
-}
-static bool thin_fwd_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
+// geometry of the thin forward kernel for a layer: TH output rows per block (8, or 4 for stride 2 / when LDS is short)
+struct ThinFwdGeom { int TH, TW, strip_units, w_units, lds; };
+static bool thin_fwd_geom(const jpdse_conv_desc* d, const ConvPlan& p, ThinFwdGeom* g) {
   if (!(g_fast_enabled && g_thin_fwd_enabled && p.thinf)) return false;
-  int su, wu;
-  return thin_fwd_lds(d, p, &su, &wu) <= 160 * 1024;
+  const int st = d->stride;
+  g->w_units = (p.Ks * p.KP_thin * 2 + 1023) / 1024;
+  static const int cand[3][2] = {{8, 64}, {4, 64}, {4, 32}};
+  for (int c = 0; c < 3; ++c) {
+    const int TH = cand[c][0], TW = cand[c][1];
+    if (TH == 4 && p.Ks != 64) break;                 // 4 rows x 2 column groups needs K = 64 (32 per group)
+    g->strip_units = (((TW - 1) * st + d->S) * p.Cs * 2 + 16 + 1023) / 1024;
+    const int lds = (((TH - 1) * st + d->R) * g->strip_units + 2 * g->w_units) * 1024;
+    const int epi = TH * TW * (p.Ks * 2 + 64);
+    g->TH = TH;
+    g->TW = TW;
+    g->lds = lds > epi ? lds : epi;
+    if (g->lds <= 160 * 1024) return true;
+  }
+  return false;
 }
 
-template <int TN>
+template <int TN, int TH, int ST, int TW>
 static int launch_thin_fwd(const ThinFwdArgs& a, int lds, hipStream_t s) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<TN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<TN, TH, ST, TW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL((thin_fwd_kernel<TN>), dim3(a.N * a.tiles_h * a.tiles_w), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((thin_fwd_kernel<TN, TH, ST, TW>), dim3(a.N * a.tiles_h * a.tiles_w), dim3(512), lds, s, a);
   return check_launch("thin_fwd_kernel");
 }
 
@@ -1252,7 +1260,8 @@ template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
                       const float* bias, void* y, void* ws, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    if (thin_fwd_ok(d, p)) {
+    ThinFwdGeom tg;
+    if (thin_fwd_geom(d, p, &tg)) {
       ThinFwdArgs t = {};
       t.X = reinterpret_cast<const bf16_t*>(x);
       t.Wt = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + p.thin_pack_off);
@@ -1274,10 +1283,16 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       t.slope = d->slope;
       t.KP = p.KP_thin;
       t.ksteps = (p.KP_thin - 8) / 16;
-      const int lds = thin_fwd_lds(d, p, &t.strip_units, &t.w_units);
-      t.tiles_w = (p.OW + 63) / 64;
-      t.tiles_h = (p.OH + kThinTH - 1) / kThinTH;
-      return p.Ks == 64 ? launch_thin_fwd<2>(t, lds, s) : launch_thin_fwd<1>(t, lds, s);
+      t.strip_units = tg.strip_units;
+      t.w_units = tg.w_units;
+      t.tiles_w = (p.OW + tg.TW - 1) / tg.TW;
+      t.tiles_h = (p.OH + tg.TH - 1) / tg.TH;
+      if (d->stride == 1) {
+        if (tg.TH == 8) return p.Ks == 64 ? launch_thin_fwd<2, 8, 1, 64>(t, tg.lds, s) : launch_thin_fwd<1, 8, 1, 64>(t, tg.lds, s);
+        return tg.TW == 64 ? launch_thin_fwd<1, 4, 1, 64>(t, tg.lds, s) : launch_thin_fwd<1, 4, 1, 32>(t, tg.lds, s);
+      }
+      if (tg.TH == 8) return p.Ks == 64 ? launch_thin_fwd<2, 8, 2, 64>(t, tg.lds, s) : launch_thin_fwd<1, 8, 2, 64>(t, tg.lds, s);
+      return tg.TW == 64 ? launch_thin_fwd<1, 4, 2, 64>(t, tg.lds, s) : launch_thin_fwd<1, 4, 2, 32>(t, tg.lds, s);
     }
     if (head_fwd_ok(d, p)) {
       HeadFwdArgs h = {};

@@ -5,7 +5,7 @@
 // block owns 8 output rows x 64 output pixels x all K (32 / 64) output channels: the 8 + R - 1 input-row strips
 // ((64 + S - 1) pixels x Cs channels, dense, reflect / zero padding resolved per pixel by the DMA loader) are
 // staged ONCE and stay in LDS; the filter rows w_r ([K][S*Cs] padded to a 16-multiple + 8) stream through a
-// 2-stage ring.  Wave w computes output row w: the A fragment of k-step ks is a plain 16-byte LDS read of the
+// 2-stage ring.  Wave w computes one output row (x a column group of K): the A fragment of k-step ks is a plain 16-byte LDS read of the
 // strip at (pix*Cs + 16*ks) -- rows overlap, pitch 80 B is conflict-free -- the B fragment a read of w_r.
 #pragma once
 #include "common.h"
@@ -26,29 +26,32 @@ struct ThinFwdArgs {
   int tiles_w, tiles_h;
 };
 
-constexpr int kThinTH = 8;
-
-template <int TN>      // TN = 32-column tiles of K per wave (K = 32 * TN)
+// TH output rows per block, 8 waves = TH rows x (8 / TH) column groups of TN 32-wide tiles (K = 32 * TN * 8 / TH);
+// ST = stride (the run of output pixel ow starts at input pixel ow * ST); TW = output pixels per block row (64 / 32):
+// strips hold (TW - 1) * ST + S pixels
+template <int TN, int TH, int ST, int TW>
 __global__ __launch_bounds__(512) void thin_fwd_kernel(const ThinFwdArgs a) {
+  constexpr int WN = 8 / TH, MI = TW / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
   const int tw = blockIdx.x % a.tiles_w, t1 = blockIdx.x / a.tiles_w;
   const int th = t1 % a.tiles_h, n = t1 / a.tiles_h;
-  const int oh0 = th * kThinTH, ow0 = tw * 64;
-  const int n_strips = kThinTH + a.R - 1;
+  const int oh0 = th * TH, ow0 = tw * TW;
+  const int wrow = wid % TH, wcol = wid / TH;          // this wave's output row / column group
+  const int n_strips = (TH - 1) * ST + a.R;
   const int strip_bytes = a.strip_units * 1024, w_bytes = a.w_units * 1024;
   char* const strips = smem;
   char* const wring = smem + n_strips * strip_bytes;
-  const int run_px = 64 + a.S - 1;
+  const int run_px = (TW - 1) * ST + a.S;
 
   // ---- stage all strips: unit u of strip j; lane -> 16 bytes at byte offset b of the dense strip ----------------
   for (int u = wid; u < n_strips * a.strip_units; u += 8) {
     const int j = u / a.strip_units, uu = u - j * a.strip_units;
     const int el = uu * 512 + lane * 8;                 // element offset inside the strip
     const int px = el / a.Cs, ch = el - px * a.Cs;
-    int ih = oh0 + j - a.pad, iw = ow0 + px - a.pad;
+    int ih = oh0 * ST + j - a.pad, iw = ow0 * ST + px - a.pad;
     bool ok = px < run_px;
     if (a.reflect) {
       ih = ih < 0 ? -ih : (ih >= a.H ? 2 * (a.H - 1) - ih : ih);
@@ -68,18 +71,18 @@ __global__ __launch_bounds__(512) void thin_fwd_kernel(const ThinFwdArgs a) {
   };
   issue_w(0, 0);
 
-  f32x16 acc[2][TN];
+  f32x16 acc[MI][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // fragment addressing: A row = output pixel (lane & 31) + 32*i of this wave's output row; k-half = lane >> 5
-  const int a_lane = ((lane & 31) * a.Cs + (lane >> 5) * 8) * 2;
-  const int a_i1 = 32 * a.Cs * 2;
-  const int b_lane = ((lane & 31) * a.KP + (lane >> 5) * 8) * 2;
+  const int a_lane = ((lane & 31) * ST * a.Cs + (lane >> 5) * 8) * 2;
+  const int a_i1 = 32 * ST * a.Cs * 2;
+  const int b_lane = ((wcol * TN * 32 + (lane & 31)) * a.KP + (lane >> 5) * 8) * 2;
   const int b_j1 = 32 * a.KP * 2;
 
   for (int r = 0; r < a.R; ++r) {
@@ -87,17 +90,17 @@ __global__ __launch_bounds__(512) void thin_fwd_kernel(const ThinFwdArgs a) {
     __builtin_amdgcn_s_barrier();                      // w_r (and, for r = 0, the strips) staged; ring slot (r+1)&1 free
     asm volatile("" ::: "memory");
     if (r + 1 < a.R) issue_w(r + 1, (r + 1) & 1);
-    const char* const sa = strips + (wid + r) * strip_bytes + a_lane;
+    const char* const sa = strips + (wrow * ST + r) * strip_bytes + a_lane;
     const char* const sb = wring + (r & 1) * w_bytes + b_lane;
     __builtin_amdgcn_s_setprio(1);
     for (int ks = 0; ks < a.ksteps; ++ks) {
-      s16x8 af[2], bf[TN];
+      s16x8 af[MI], bf[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const s16x8*>(sa + i * a_i1 + ks * 32);
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const s16x8*>(sa + i * a_i1 + ks * 32);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(sb + j * b_j1 + ks * 32);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
@@ -107,13 +110,13 @@ __global__ __launch_bounds__(512) void thin_fwd_kernel(const ThinFwdArgs a) {
 
   // ---- epilogue: wave w = output row oh0 + w; bias + activation, 16-byte stores through LDS -----------------------
   __syncthreads();
-  constexpr int BN = TN * 32, PITCH = BN * 2 + 64;
-  acc_tile_to_lds<2, TN>(smem, PITCH, wid * 64, 0, 0, lane, acc, a.bias, a.K, a.act, a.slope);
+  constexpr int BN = WN * TN * 32, PITCH = BN * 2 + 64;
+  acc_tile_to_lds<MI, TN>(smem, PITCH, wrow * TW, wcol * TN * 32, 0, lane, acc, a.bias, a.K, a.act, a.slope);
   __syncthreads();
   constexpr int VPR = BN / 8;
-  for (int idx = tid; idx < kThinTH * 64 * VPR; idx += 512) {
+  for (int idx = tid; idx < TH * TW * VPR; idx += 512) {
     const int row = idx / VPR, v = idx - row * VPR;
-    const int oh = oh0 + (row >> 6), ow = ow0 + (row & 63);
+    const int oh = oh0 + row / TW, ow = ow0 + row % TW;
     if (oh >= a.OH || ow >= a.OW || v * 8 >= a.Ks) continue;
     *reinterpret_cast<u32x4*>(a.Y + (((long long)n * a.OH + oh) * a.OW + ow) * a.Ks + v * 8) =
         *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);

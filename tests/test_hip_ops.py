@@ -72,6 +72,10 @@ CONV_CASES = [
     # thin-input weight gradient (wgrad_thin.h): several 64-pixel strips per row with a ragged last one
     ('thin_ragged',    2, 10, 150, 39, 64,  7, 1, 3,  PAD_REFLECT, ACT_NONE),
     ('thin_s2_k32',    1, 8,  260, 39, 32,  4, 2, 2,  PAD_ZERO,    ACT_LRELU),
+    # thin-input forward (thin_fwd.h): stride 2 with 4 rows x 64 px blocks; 48-channel storage -> 4 x 32 px blocks
+    ('thinf_s2_40',    2, 20, 150, 39, 64,  4, 2, 2,  PAD_ZERO,    ACT_LRELU),
+    ('thinf_s2_48',    1, 18, 100, 42, 64,  4, 2, 2,  PAD_ZERO,    ACT_LRELU),
+    ('thinf_s1_48',    1, 13, 100, 42, 64,  7, 1, 3,  PAD_REFLECT, ACT_NONE),
     # head weight gradient (wgrad_thin.h, transposed roles): 32-channel input (LocalEnhancer), ragged strips
     ('head_local32',   2, 9,  70,  32, 3,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
     ('head_3x3_zero',  1, 6,  130, 64, 5,   3, 1, 1,  PAD_ZERO,    ACT_NONE),
