@@ -161,6 +161,17 @@ def main():
                   traffic=None, launches_per_step=n.value / args.steps,
                   avg_launch_ms=round(ms.value / n.value, 4),
                   flops_per_launch=fl.value / n.value)
+      # HBM-side bytes per launch of the same kernel: rocprofv3 PMC counters cannot be read from inside this
+      # process, so the figure is the committed one of scripts/run_pmc_hbm.sh (separate --pmc passes over this
+      # very command, FETCH_SIZE doubled per the gfx950 correction) -- only quoted for the workload it was taken on
+      tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+      if (os.path.exists(tpath) and (args.netG, args.width, args.height, args.batch, args.dtype) ==
+          ('global', 1024, 512, 4, 'bf16')):
+        with open(tpath) as fh:
+          tj = json.load(fh)
+        roof['traffic'] = tj['fetch_bytes_per_launch'] + tj['write_bytes_per_launch']
+        roof['traffic_unit'] = 'bytes per launch (memory-side of L2, Infinity-Cache hits included)'
+        roof['traffic_source'] = tj['source']
     f_alg = F_ALG_GFLOP.get((args.netG, args.width, args.height))
     if args.no_vgg and f_alg:      # minus VGG's 3 passes (2 fwd + 1 dgrad), SURVEY.md 8d config 2
       f_alg = round(f_alg - 6 * 189.4 * (args.width * args.height) / (1024.0 * 512.0), 1)

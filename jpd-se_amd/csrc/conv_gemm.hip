@@ -890,7 +890,7 @@ static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
   p->toep = (p->ES == 2 && p->Ks == 8 && st == 1) ? 1 : 0;
   p->Lk_toep = p->toep ? round_up((d->S + 3) * p->Cs, p->BKE) : 0;
   p->fwd_pack_bytes = p->fwd_pack_plain_bytes + (p->toep ? align_up((size_t)32 * d->R * p->Lk_toep * p->ES, 256) : 0);
-  p->thinf = (p->ES == 2 && p->Cs % 64 != 0 && p->Cs <= 48 && st <= 2 && (p->Ks == 32 || p->Ks == 64) && d->K == p->Ks) ? 1 : 0;
+  p->thinf = (p->ES == 2 && p->Cs % 64 != 0 && p->Cs > 8 && p->Cs <= 48 && st <= 2 && (p->Ks == 32 || p->Ks == 64) && d->K == p->Ks) ? 1 : 0;
   p->KP_thin = p->thinf ? round_up(d->S * p->Cs, 16) + 8 : 0;
   p->thin_pack_off = p->fwd_pack_bytes;
   if (p->thinf) p->fwd_pack_bytes += align_up((size_t)d->R * p->Ks * p->KP_thin * 2, 256);
@@ -1117,14 +1117,14 @@ static int g_halo_single = 1;
 static int g_halo_enabled = 1;
 static int g_halo_abl = 0;
 
-template <int TN, int ABL = 0, bool SINGLE = false>
+template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false>
 static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   constexpr int BN = 2 * TN * 32;
   constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
   constexpr int lds = (SINGLE ? 1 : 2) * UH * 1024 + 3 * BN * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -1135,7 +1135,7 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE>), dim3(tiles), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16>), dim3(tiles), dim3(512), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
@@ -1145,10 +1145,15 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
 }
 
 static int g_halo_xcd = 0;
+static int g_halo_mf16 = 0;     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
 template <int TN, int ABL = 0>
 static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
   HaloArgs a = a0;
   a.xcd_mode = g_halo_xcd;
+  if (ABL == 0 && g_halo_mf16) {
+    if (a.Cs == 64 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, true>(a, s);
+    return launch_halo_cfg_impl<TN, 0, false, true>(a, s);
+  }
   if (a.Cs == 64 && ABL == 0 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true>(a, s);   // one slab: single patch buffer
   return launch_halo_cfg_impl<TN, ABL, false>(a, s);
 }
@@ -2325,6 +2330,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
+  g_halo_mf16 = enable == 19;         // 19: halo kernel on 16x16x32 MFMAs (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_head_fwd_enabled = enable != 14 && enable != 6;   // 14: heads on the Toeplitz GEMM (A/B); 6 keeps the generic order
   g_thin_fwd_enabled = enable != 18;  // 18: thin-input forward on the generic kernel (A/B)

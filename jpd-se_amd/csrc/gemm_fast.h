@@ -102,6 +102,35 @@ __device__ __forceinline__ void acc_tile_to_lds(char* tile, int pitch, int wrow0
   }
 }
 
+// Same for 16x16 accumulator blocks (v_mfma_f32_16x16x32_bf16: lane -> column lane & 15, rows 4 * (lane >> 4) + e)
+template <int TM, int TN>
+__device__ __forceinline__ void acc16_tile_to_lds(char* tile, int pitch, int wrow0, int wcol0, int n0, int lane,
+                                                  const f32x4 (&acc)[TM][TN], const float* bias, int Kout, int act,
+                                                  float slope) {
+  const int odd = lane & 1;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int lcol = wcol0 + j * 16 + (lane & 15);
+    const int col = n0 + lcol;
+    const bool live = col < Kout;
+    const float bv = (bias != nullptr && live) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int ep = 0; ep < 2; ++ep) {
+        const int e = 2 * ep;
+        const float v0 = live ? apply_act(acc[i][j][e] + bv, act, slope) : 0.f;
+        const float v1 = live ? apply_act(acc[i][j][e + 1] + bv, act, slope) : 0.f;
+        const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);
+        const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
+        const uint32_t word = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+        const int row = wrow0 + i * 16 + 4 * (lane >> 4) + e + odd;
+        *reinterpret_cast<uint32_t*>(tile + row * pitch + (lcol - odd) * 2) = word;
+      }
+    }
+  }
+}
+
 // 8 bf16 values: v + w in fp32, rounded once
 __device__ __forceinline__ u32x4 add_bf16x8(u32x4 v, u32x4 w) {
 #pragma unroll

@@ -28,6 +28,7 @@ LAYERS = [
   ('G up convT 1024->512',         32, 64, 1024, 512, 3, 2, 1, PAD_ZERO, True),
   ('G up convT 128->64',           256, 512, 128, 64, 3, 2, 1, PAD_ZERO, True),
   ('G last 7x7 64->3',             512, 1024, 64, 3, 7, 1, 3, PAD_REFLECT, False),
+  ('VGG conv1_1 3->64',            512, 1024, 3, 64, 3, 1, 1, PAD_ZERO, False),
   ('VGG conv1_2 64->64',           512, 1024, 64, 64, 3, 1, 1, PAD_ZERO, False),
   ('VGG conv2_2 128->128',         256, 512, 128, 128, 3, 1, 1, PAD_ZERO, False),
   ('VGG conv3_x 256->256',         128, 256, 256, 256, 3, 1, 1, PAD_ZERO, False),

@@ -143,6 +143,18 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
   assert_close(layer.bias.grad.cpu(), br.grad, 2 * tol, name + ' bias grad')
 
 
+@pytest.mark.parametrize('name', ['halo_vgg_64', 'halo_vgg_256', 'ring_dgrad_192'])
+def test_halo_kernel_mfma_16x16x32_variant(name):
+  # debug mode 19: the halo kernel built on v_mfma_f32_16x16x32_bf16 (other swizzle, fragment and epilogue layout)
+  from jpdse_hip import lib
+  case = [c for c in CONV_CASES if c[0] == name][0]
+  lib().jpdse_debug_set_fast_path(19)
+  try:
+    test_conv_fwd_dgrad_wgrad(case, BF16)
+  finally:
+    lib().jpdse_debug_set_fast_path(1)
+
+
 # conv -> ReLU(inplace) -> conv chains (VGG19): the second conv's data gradient with the ReLU backward fused
 # (jpdse_conv_dgrad_relu), on the halo, fast (merged stride phases), split-K and generic paths
 FUSED_RELU_CASES = [
