@@ -66,7 +66,8 @@ int jpdse_arch_check(int device);
  * summation order as the generic kernels: bit-comparable); 7 = reflect data gradient on the padded
  * domain; 8 = halo kernel always double buffered; 9 / 10 = long-K-only phase merging / no 128-row
  * tiles; 12 = no all-taps weight gradient; 13 = no tap-sum forward; 14 = no head kernel;
- * 15 / 16 = XCD-aware halo tile orders.  Each call resets the others to their defaults. */
+ * 15 / 16 = XCD-aware halo tile orders; 18 = no thin-input forward kernel; 19 = halo kernel on
+ * 16x16x32 MFMA fragments.  Each call resets the others to their defaults. */
 int jpdse_debug_set_fast_path(int32_t enable);
 int jpdse_prof_select(int32_t enable, int32_t Ks, int64_t kdim, int32_t max_launches);
 int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
