@@ -57,7 +57,7 @@ def parse():
 
 
 def make_opt(args, device_index):
-  from oracle.ctu_cpu.model import default_opt     # only the opt namespace (field list), no compute
+  from ctu.utils.synthetic import default_opt
   kw = dict(gpu_ids=[device_index], print_losses=False, compute_dtype=args.dtype, use_compressed=True,
             netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch)
   if args.no_vgg:
@@ -103,7 +103,7 @@ def main():
   import jpdse_hip
   from jpdse_hip import lib, check
   from ctu.trainers import get_trainer
-  from oracle.ctu_cpu.model import synthetic_batch
+  from ctu.utils.synthetic import synthetic_batch
   jpdse_hip.require_gpu(dev_index)
   if args.debug_mode is not None:
     check(lib().jpdse_debug_set_fast_path(args.debug_mode), 'debug_set_fast_path')

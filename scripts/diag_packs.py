@@ -4,7 +4,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'jpd-se_amd'))
 import torch, collections
 from jpdse_hip import ops
 from ctu.trainers import get_trainer
-from oracle.ctu_cpu import model as omodel
+from ctu.utils import synthetic as omodel
 opt = omodel.default_opt(gpu_ids=[0], print_losses=False, compute_dtype='bf16', ngf=16)
 tr = get_trainer(opt)(opt, 'train')
 xd = omodel.synthetic_batch(1, 64, 128, seed=21)

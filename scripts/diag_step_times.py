@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'jpd-se_amd'))
 import torch
 from ctu.trainers import get_trainer
-from oracle.ctu_cpu.model import synthetic_batch, default_opt
+from ctu.utils.synthetic import synthetic_batch, default_opt
 dev = torch.device('cuda', 0)
 opt = default_opt(gpu_ids=[0], print_losses=False, compute_dtype='bf16', use_compressed=True, batch_size=4)
 torch.manual_seed(1234)

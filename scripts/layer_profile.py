@@ -22,7 +22,7 @@ dev = torch.device('cuda', 0)
 import jpdse_hip
 from jpdse_hip import lib, ops
 from ctu.trainers import get_trainer
-from oracle.ctu_cpu.model import synthetic_batch, default_opt   # opt namespace + input generator only
+from ctu.utils.synthetic import synthetic_batch, default_opt
 
 lib().jpdse_debug_set_fast_path(args.fast)
 opt = default_opt(gpu_ids=[0], print_losses=False, compute_dtype=args.dtype, use_compressed=True,

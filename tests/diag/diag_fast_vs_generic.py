@@ -1,7 +1,7 @@
 """Per-layer cosine of the bf16 weight gradients: fast kernels (mode 1) vs generic kernels (mode 0),
 same weights and batch (ngf=64 generator at 128x256, batch 2)."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'jpd-se_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from jpdse_hip import lib

@@ -1,6 +1,6 @@
 """Diagnostic: forward rounding error of the HIP fp32 path vs torch-fp32, both against fp64."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'jpd-se_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch, torch.nn.functional as F
 from jpdse_hip import F32, PAD_REFLECT, ACT_NONE, ACT_RELU

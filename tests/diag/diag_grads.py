@@ -1,6 +1,6 @@
 """Diagnostic: per-parameter gradient error of one HIP train step vs the oracle."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'jpd-se_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from oracle.ctu_cpu import model as omodel

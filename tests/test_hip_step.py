@@ -258,7 +258,7 @@ def test_bf16_full_width_fast_kernels_in_situ():
         every weight gradient cosine > 0.995.  With split-K (the default at this size) 0.04 % of a
         conv's outputs move by one bf16 ulp (scripts/diag_splitk.py), and that alone decorrelates the
         deep gradients to cosine ~0.95 between two equally valid bf16 runs (scripts/
-        diag_fast_vs_generic.py: both are at 0.897 from fp32): the default path is therefore held to
+        tests/diag/diag_fast_vs_generic.py: both are at 0.897 from fp32): the default path is therefore held to
         "as close to fp32 as the generic kernels, minus 0.02";
     (3) against the fp32 oracle the gradients are only as faithful as bf16 STORAGE of activations and
         activation gradients allows (ReLU-mask / L1-sign flips; measured cosine 0.90-0.92 in the deep

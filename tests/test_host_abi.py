@@ -214,3 +214,25 @@ def test_workspace_and_pack_sizes_are_consistent():
     assert L.jpdse_conv_fwd_pack_size(ctypes.byref(d)) >= p['Ks'] * 7 * p['Lk_fwd'] * es
     need = 2 * p['Hp'] * p['Wp'] * p['Cs'] * es
     assert L.jpdse_conv_workspace_size(ctypes.byref(d)) >= need
+
+
+def test_product_synthetic_inputs_match_the_oracle_generator():
+  """bench.py's product leg must not import oracle/: ctu.utils.synthetic carries its own copy of the option
+  defaults and of the synthetic x_dict generator; this pins the two copies to each other."""
+  from ctu.utils import synthetic as prod
+  from oracle.ctu_cpu import model as omodel
+  a, b = vars(prod.default_opt(netG='local', ngf=32)), vars(omodel.default_opt(netG='local', ngf=32))
+  assert a == b
+  xa, xb = prod.synthetic_batch(2, 64, 96, seed=7), omodel.synthetic_batch(2, 64, 96, seed=7)
+  assert xa.keys() == xb.keys()
+  for k in xa:
+    if torch.is_tensor(xa[k]):
+      assert xa[k].dtype == xb[k].dtype and torch.equal(xa[k], xb[k]), k
+    else:
+      assert xa[k] == xb[k]
+
+
+def test_bench_product_leg_does_not_import_the_oracle():
+  src = open(os.path.join(os.path.dirname(__file__), '..', 'bench.py')).read()
+  body = src[src.index('def main'):]
+  assert 'oracle' not in body.replace('cpu_baseline', ''), 'only bench.py::cpu_baseline may touch oracle/'
