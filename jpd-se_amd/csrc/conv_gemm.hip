@@ -1380,6 +1380,9 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
           case 9: return launch_halo_cfg<2, 9>(h, s);
           case 11: return launch_halo_cfg<2, 11>(h, s);
           case 15: return launch_halo_cfg<2, 15>(h, s);
+          case 16: return launch_halo_cfg<2, 16>(h, s);
+          case 32: return launch_halo_cfg<2, 32>(h, s);
+          case 48: return launch_halo_cfg<2, 48>(h, s);
           default: break;
         }
       }

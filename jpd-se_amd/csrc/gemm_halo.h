@@ -37,7 +37,8 @@ struct HaloArgs {
 };
 
 // ABL: timing-only ablation bits (results are wrong when non-zero): 1 = no DMA after the prologue,
-// 2 = no barrier, 4 = fragments read once per tap-group only (no per-k-step LDS reads), 8 = no vmcnt waits
+// 2 = no barrier, 4 = fragments read once per tap-group only (no per-k-step LDS reads), 8 = no vmcnt waits,
+// 16 = every block reads the same weight rows, 32 = every block reads the same input patch (both: L2 hits only)
 // SINGLE: one patch buffer instead of two -- for 64-channel inputs (one slab per tile, nothing to prefetch).
 // With the 64-wide N tile the block then needs 74 KiB of LDS and TWO blocks share a CU, overlapping one
 // block's patch load / epilogue with the other's MFMAs (these K = 576 layers are prologue-bound).
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     const int swz_p = p;                              // the swizzle uses the LDS pixel index, also for clamped lanes
     p = p < NP ? p : NP - 1;
     const int hr = p / PW, wc = p - hr * PW;
-    int ih = oh0 - a.py + hr, iw = ow0 - a.px + wc;
+    int ih = ((ABL & 32) ? 0 : oh0) - a.py + hr, iw = ((ABL & 32) ? 0 : ow0) - a.px + wc;   // ABL 32: same patch
     bool ok = true;
     if (a.reflect) {
       ih = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
       ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
     }
     const int chunk = MF16 ? (lslot ^ (swz_p & 6)) : ((lslot ^ (swz_p >> 1)) & 7);
-    h_off[i] = ok ? (((long long)n * a.IH + ih) * a.IW + iw) * a.Cs + chunk * 8 : -1;
+    h_off[i] = ok ? (((long long)((ABL & 32) ? 0 : n) * a.IH + ih) * a.IW + iw) * a.Cs + chunk * 8 : -1;
     h_lds[i] = ug * 1024;
   }
   // ---- weight tile DMA units
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     b_on[j] = u < B_UNITS;
     const int uu = b_on[j] ? u : 0;
     const int row = uu * 8 + lrow;
-    int br = n0 + row;
+    int br = ((ABL & 16) ? 0 : n0) + row;       // ABL 16: every block streams the SAME weight rows (L2-resident)
     br = br < a.b_rows ? br : a.b_rows - 1;
     b_ptr[j] = a.B + (long long)br * ktot + (MF16 ? (lslot ^ (row & 6)) : ((lslot ^ (row >> 1)) & 7)) * 8;
     b_lds[j] = uu * 1024;
@@ -183,40 +184,40 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   for (int i = 0; i < HU; ++i)
     if (i < n_hu) issue_patch_unit(i, 0);
   issue_b(0);
-  if (T_total > 1) issue_b(1);
+  issue_b(1);                                         // T_total >= 9
 
-  int slab = 0, tap = 0;
-  for (int t = 0; t < T_total; ++t) {
-    // loads allowed to stay in flight: the group issued in iteration t-1 = [patch unit?, weight tile t+1]
-    if (ABL & 8) {
-    } else if (t + 1 < T_total) {
-      const int ptap = tap == 0 ? TAPS - 1 : tap - 1;           // tap index of iteration t-1
-      const int pslab = tap == 0 ? slab - 1 : slab;
-      const bool had_patch = t > 0 && ptap < n_hu && pslab + 1 < CC;
-      if (had_patch) {
-        if (n_b == BU) wait_vmcnt<BU + 1>(); else wait_vmcnt<BU>();
-      } else {
-        if (n_b == BU) wait_vmcnt<BU>(); else wait_vmcnt<(BU > 0 ? BU - 1 : 0)>();
-      }
-    } else {
-      wait_vmcnt<0>();
+  // Main loop: slabs outside, the 9 taps unrolled -- the tap offset, the ring stage (tap % 3), the patch unit to
+  // prefetch and every end-of-range test but "last slab?" are compile-time constants.  (With a runtime tap the
+  // selection of the patch unit and of the vmcnt count compiled to ~20 scalar branches per tap, sitting right after
+  // the barrier where all 8 waves wait for them.)
+  // In flight across the barrier: only weight tile t+1 (BU pieces per wave, issued last in iteration t-1); the patch
+  // unit issued before it is one iteration old by then, so a constant count suffices.
+  static_assert(B_UNITS % NW == 0, "every wave issues exactly BU weight pieces per tile");
+  auto tap_body = [&](const int tap, const int slab, const bool more, const char* const hb) {
+    if (!(ABL & 8)) {
+      if (tap < TAPS - 1 || more) wait_vmcnt<BU>(); else wait_vmcnt<0>();
     }
     if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
-    // issue group t+2: one patch unit of the NEXT slab (only from the slab's first tap on: its buffer was
-    // being read until the previous slab ended), then weight tile t+2
+    // issue group t+2: one patch unit of the NEXT slab (from the slab's first tap on: its buffer was being
+    // read until the previous slab ended), then weight tile t+2
     if (!(ABL & 1)) {
-      if (tap < n_hu && slab + 1 < CC) {
+      if constexpr (!SINGLE) {
+        if (tap < HU && tap < n_hu && more) {
 #pragma unroll
-        for (int i = 0; i < HU; ++i)
-          if (i == tap) issue_patch_unit(i, slab + 1);
+          for (int i = 0; i < HU; ++i)
+            if (i == tap) issue_patch_unit(i, slab + 1);          // tap is a constant here (unrolled caller)
+        }
       }
-      if (t + 2 < T_total) issue_b(t + 2);
+      const int tap2 = tap + 2 < TAPS ? tap + 2 : tap + 2 - TAPS;
+      if (tap + 2 < TAPS || more) {
+        char* const st2 = bring + (tap2 % 3) * B_STAGE;           // (t + 2) % 3 with t = 9 * slab + tap
+        const long long koff = (long long)tap2 * a.Cs + (slab + (tap + 2 < TAPS ? 0 : 1)) * 64;
+#pragma unroll
+        for (int jj = 0; jj < BU; ++jj) glds16(b_ptr[jj] + koff, st2 + b_lds[jj]);
+      }
     }
-
-    const char* const hb = halo0 + (slab & (NBUF - 1)) * HALO;
-    const char* const st = bring + (t % 3) * B_STAGE;
-    const int r = tap / S, s = tap - r * S;
-    const int tapoff = r * PW + s;
+    const char* const st = bring + (tap % 3) * B_STAGE;
+    const int tapoff = (tap / S) * PW + (tap % S);
     int a_base[FM], a_sw[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -243,7 +244,18 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
         }
     }
     __builtin_amdgcn_s_setprio(0);
-    if (++tap == TAPS) { tap = 0; ++slab; }
+  };
+  if constexpr (SINGLE) {
+    // one slab (Cs == 64), nothing to prefetch: the rolled loop keeps the kernel within 128 VGPRs (two blocks per CU)
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) tap_body(tap, 0, false, halo0);
+  } else {
+    for (int slab = 0; slab < CC; ++slab) {
+      const bool more = slab + 1 < CC;                  // wave-uniform
+      const char* const hb = halo0 + (slab & (NBUF - 1)) * HALO;
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) tap_body(tap, slab, more, hb);
+    }
   }
 
   // ---- epilogue: wave wm owns image row oh0+wm (2 x 32 consecutive pixels); staged through LDS so that the
