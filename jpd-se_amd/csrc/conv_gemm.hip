@@ -1977,12 +1977,12 @@ static bool wgrad_row_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
          p.OW % 64 == 0 && p.Ks % 256 == 0 && p.Cs % 128 == 0;
 }
 
-template <int ABL>
+template <int ABL, bool REFLECT>
 static int launch_wgrad_row_cfg(RowWgArgs a, hipStream_t s) {
   constexpr int lds = 3 * (64 * 512 + 17 * 1024);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_row_kernel<ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_row_kernel<ABL, REFLECT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_row: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
@@ -2002,14 +2002,14 @@ static int launch_wgrad_row_cfg(RowWgArgs a, hipStream_t s) {
     hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * 9 * a.C * sizeof(float), s);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(wgrad_row_kernel<ABL>, dim3((int)nblocks), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((wgrad_row_kernel<ABL, REFLECT>), dim3((int)nblocks), dim3(512), lds, s, a);
   return check_launch("wgrad_row_kernel");
 }
 
 static int launch_wgrad_row(const RowWgArgs& a, hipStream_t s) {
-  if (g_wgrad_abl == 1) return launch_wgrad_row_cfg<1>(a, s);
-  if (g_wgrad_abl == 2) return launch_wgrad_row_cfg<2>(a, s);
-  return launch_wgrad_row_cfg<0>(a, s);
+  if (g_wgrad_abl == 1) return launch_wgrad_row_cfg<1, true>(a, s);
+  if (g_wgrad_abl == 2) return launch_wgrad_row_cfg<2, true>(a, s);
+  return a.reflect ? launch_wgrad_row_cfg<0, true>(a, s) : launch_wgrad_row_cfg<0, false>(a, s);
 }
 
 // ---- all-taps weight gradient of the narrow high-resolution layers (wgrad_taps.h) -----------------

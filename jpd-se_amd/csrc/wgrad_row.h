@@ -43,7 +43,10 @@ __device__ __forceinline__ void mma_step(uint32_t sbase, const int (&a_tr)[4], c
 }
 
 // ABL: timing-only ablations (wrong results): 1 = no epilogue, 2 = plain stores instead of atomics
-template <int ABL>
+// REFLECT: padding mode as a template parameter -- with the incremental chunk coordinates and the select-based pixel
+// resolution below the loader has no branch and no division (it used to compile to ~30 scalar / exec branches and two
+// divisions per chunk, executed right behind the barrier by all 8 waves).
+template <int ABL, bool REFLECT>
 __global__ __launch_bounds__(512) void wgrad_row_kernel(const RowWgArgs a) {
   constexpr int NW = 8, WN = 4, TM = 4;
   constexpr int BM = 256, BN = 128, BKP = 64;
@@ -106,59 +109,75 @@ __global__ __launch_bounds__(512) void wgrad_row_kernel(const RowWgArgs a) {
     // the DMA itself, was what bound this kernel: ~450 VALU issue slots per chunk and wave against 48
     // MFMAs; now ~60).  A (dy): 4 units per wave, B (x): units wid, wid+8, wid+16 (< 17).
     constexpr int AU = A_UNITS / NW, BU = (B_UNITS + NW - 1) / NW;
-    int a_loff[AU], b_q[BU], b_sw[BU];
-#pragma unroll
-    for (int i = 0; i < AU; ++i) {
-      const int pix = (wid + NW * i) * 2 + (lane >> 5);
-      a_loff[i] = pix * a.Ks + k0 + (((lane & 31) ^ trswz<A_ROWB>(pix)) << 3);
-    }
-#pragma unroll
-    for (int j = 0; j < BU; ++j) {
-      const int q = (wid + NW * j) * 4 + (lane >> 4);
-      b_q[j] = q;
-      b_sw[j] = c0 + (((lane & 15) ^ trswz<B_ROWB>(q)) << 3);
-    }
-    auto issue = [&](int chunk, int stage) {
+    // the swizzle depends on (pixel & 3) only and the units of one wave are 16 (dy) / 32 (x) pixels apart: ONE lane
+    // offset per operand, the unit index goes into the wave-uniform base
+    const int a_pix0 = wid * 2 + (lane >> 5);
+    const int a_loff0 = a_pix0 * a.Ks + k0 + (((lane & 31) ^ trswz<A_ROWB>(a_pix0)) << 3);
+    const int b_q0 = wid * 4 + (lane >> 4);
+    const int b_sw0 = c0 + (((lane & 15) ^ trswz<B_ROWB>(b_q0)) << 3);
+    // coordinates of the next chunk to issue: (i_n, i_oh, i_cw), advanced incrementally
+    int i_cw = __builtin_amdgcn_readfirstlane(ch_begin % a.chunks_per_row);    // wave-uniform: keep them in SGPRs
+    int i_row = __builtin_amdgcn_readfirstlane(ch_begin / a.chunks_per_row);   // n*H + oh
+    int i_oh = __builtin_amdgcn_readfirstlane(i_row % a.H);
+    const int Hm1 = a.H - 1, Wm1 = a.W - 1;
+    auto issue = [&](int stage) {
       char* const st = smem + stage * STAGE;
-      const int cw = chunk % a.chunks_per_row;
-      const int row = chunk / a.chunks_per_row;       // n*H + oh
-      const int oh = row % a.H, n = row / a.H;
-      const int ow0 = cw * BKP;
-      int ih = oh + r - 1;
+      const int ow0 = i_cw * BKP;
+      int ih = i_oh + r - 1;
       bool row_ok = true;
-      if (a.reflect) ih = ih < 0 ? -ih : (ih >= a.H ? 2 * (a.H - 1) - ih : ih);
-      else row_ok = (unsigned)ih < (unsigned)a.H;
-      const bf16_t* const dy_base = a.DY + ((long long)row * a.W + ow0) * a.Ks;        // wave-uniform
-      const bf16_t* const x_row = a.X + (((long long)n * a.H + ih) * a.W) * a.Cs;       // wave-uniform
+      if constexpr (REFLECT) {
+        ih = ih < 0 ? -ih : ih;
+        ih = ih > Hm1 ? 2 * Hm1 - ih : ih;
+      } else {
+        row_ok = (unsigned)ih < (unsigned)a.H;
+        ih = row_ok ? ih : 0;
+      }
+      const bf16_t* const dy_base = a.DY + ((long long)i_row * a.W + ow0) * a.Ks;                          // wave-uniform
+      const bf16_t* const x_row = a.X + ((long long)(i_row - i_oh + ih) * a.W) * a.Cs;                    // wave-uniform
 #pragma unroll
-      for (int i = 0; i < AU; ++i) glds16(dy_base + a_loff[i], st + (wid + NW * i) * 1024);
-#pragma unroll
-      for (int j = 0; j < BU; ++j) {
-        if (wid + NW * j < B_UNITS) {
-          int iw = ow0 - 1 + b_q[j];
-          bool ok = row_ok && b_q[j] < B_PIX;
-          if (a.reflect) iw = iw < 0 ? -iw : (iw >= a.W ? 2 * (a.W - 1) - iw : iw);
-          else ok = ok && (unsigned)iw < (unsigned)a.W;
-          const bf16_t* src = ok ? x_row + (__mul24(iw, a.Cs) + b_sw[j]) : zero;
-          glds16(src, st + (A_UNITS + wid + NW * j) * 1024);
+      for (int i = 0; i < AU; ++i) glds16(dy_base + (long long)(i * 2 * NW) * a.Ks + (unsigned)a_loff0, st + (wid + NW * i) * 1024);
+      auto b_unit = [&](int j, int q, int sw, bool last) {
+        int iw = ow0 - 1 + q;
+        if constexpr (REFLECT) {
+          // every lane reads a real pixel (pixels 66, 67 of the last unit are never consumed): no zero page, and the
+          // address is uniform base + 32-bit lane offset
+          iw = iw < 0 ? -iw : iw;
+          iw = iw > Wm1 ? 2 * Wm1 - iw : iw;
+          glds16(x_row + (unsigned)(__mul24(iw, a.Cs) + sw), st + (A_UNITS + wid + NW * j) * 1024);
+        } else {
+          bool ok = row_ok & ((unsigned)iw < (unsigned)a.W);
+          if (last) ok = ok & (q < B_PIX);
+          const bf16_t* const src = x_row + (unsigned)(__mul24(ok ? iw : 0, a.Cs) + sw);
+          glds16(ok ? src : zero, st + (A_UNITS + wid + NW * j) * 1024);
         }
+      };
+      b_unit(0, b_q0, b_sw0, false);
+      b_unit(1, b_q0 + 4 * NW, b_sw0, false);
+      if (wid == 0) {                                 // unit 16 = pixels 64..67 (64, 65 live); lane constants rebuilt
+        int l4 = lane >> 4;                           // from the lane id, in place: hoisted out of the loop it is
+        asm volatile("" : "+v"(l4));                  // spilled, and the reload drains this wave's DMAs (vmcnt(0))
+        const int q = 64 + l4;
+        b_unit(2, q, c0 + (((lane & 15) ^ trswz<B_ROWB>(q)) << 3), true);
+      }
+      if (++i_cw == a.chunks_per_row) {
+        i_cw = 0;
+        ++i_row;
+        if (++i_oh == a.H) i_oh = 0;
       }
     };
 
     // 3-stage ring, counted vmcnt: chunk c+1 stays in flight across the barrier while chunk c is consumed
-    // and chunk c+2 is issued (the DMA latency, not its bandwidth, is what a 2-stage ring exposes)
-    issue(ch_begin, 0);
-    if (ch_begin + 1 < ch_end) issue(ch_begin + 1, 1);
+    // and chunk c+2 is issued (the DMA latency, not its bandwidth, is what a 2-stage ring exposes).  Wave 0 issues
+    // 7 pieces per chunk, the others 6; one count (6) for all: wave 0 then also waits for the oldest piece of chunk
+    // c+1, issued a whole iteration earlier.
+    issue(0);
+    if (ch_begin + 1 < ch_end) issue(1);
     int cstage = 0, istage = 2;
     for (int c = ch_begin; c < ch_end; ++c) {
-      if (c + 1 < ch_end) {
-        if (wid == 0) wait_vmcnt<(UNITS + NW - 1) / NW>(); else wait_vmcnt<UNITS / NW>();
-      } else {
-        wait_vmcnt<0>();
-      }
+      if (c + 1 < ch_end) wait_vmcnt<UNITS / NW>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       if (c + 2 < ch_end) {
-        issue(c + 2, istage);
+        issue(istage);
         istage = istage == 2 ? 0 : istage + 1;
       }
       const uint32_t sbase = lds0 + cstage * STAGE;
