@@ -267,18 +267,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   int ic = t_begin % CC, is = (t_begin / CC) % a.S, ir = (t_begin / CC) / a.S;
   const bf16_t* a_src[AU];
   int a_step[AU];
+  // Branch-free: the reflected coordinates are computed for both padding modes (they are in range for any input),
+  // zero padding only adds the in-range predicate to the final select.  (The if / else form compiled to four exec
+  // branches per unit, executed behind the barrier whenever the tap changes -- every K-tile for 64-channel inputs.)
+  const int IHm1 = a.IH - 1, IWm1 = a.IW - 1;
+  const bool refl = a.reflect != 0;
   auto retap = [&]() {
 #pragma unroll
     for (int i = 0; i < AU; ++i) {
-      int ih = a_oh[i] + ir, iw = a_ow[i] + is;
-      bool ok = true;
-      if (a.reflect) {
-        ih = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
-        iw = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
-      } else {
-        ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
-      }
-      a_src[i] = ok ? a.X + a_nbase[i] + (long long)ih * x_sh + (long long)iw * a.Cs + a_choff[i] : zero;
+      const int ih = a_oh[i] + ir, iw = a_ow[i] + is;
+      int rh = ih < 0 ? -ih : ih, rw = iw < 0 ? -iw : iw;
+      rh = rh > IHm1 ? 2 * IHm1 - rh : rh;
+      rw = rw > IWm1 ? 2 * IWm1 - rw : rw;
+      rh = rh < 0 ? 0 : rh;                             // zero padding wider than the image: any in-range pixel
+      rw = rw < 0 ? 0 : rw;
+      const bool ok = refl | (((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW));
+      const bf16_t* const src = a.X + (a_nbase[i] + (long long)rh * x_sh + (long long)rw * a.Cs + a_choff[i]);
+      a_src[i] = ok ? src : zero;
       a_step[i] = ok ? 64 : 0;
     }
   };
