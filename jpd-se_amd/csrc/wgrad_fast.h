@@ -225,6 +225,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_fast_kernel(const FastWgAr
   const int adv_w = BKP * a.sx * a.Cs, wrap_w = a.OW * a.sx * a.Cs, adv_h = a.sy * row_el;
   const int wrap_h = a.OH * a.sy * row_el - a.IH * row_el;   // leaving the last output row of an image
   int ich = ch_begin;       // next chunk to issue
+  const int IHm1 = a.IH - 1, IWm1 = a.IW - 1;
+  const bool use_refl = !a.run_mode && a.reflect;          // wave-uniform
+  const bool no_test = a.run_mode || a.reflect;            // every pixel readable: no zero page
+  const bool narrow = a.OW < BKP;
   auto issue = [&](int stage) {
     char* const st = smem + stage * STAGE;
     const int pbase = ich * BKP;
@@ -234,32 +238,42 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_fast_kernel(const FastWgAr
       glds16(src, st + a_lds[i]);
       a_off[i] += BKP * a.Ks;
     }
+    // Branch-free (the if / else-if padding chain and the per-lane `while` of the cursor compiled to exec-mask loops
+    // behind every DMA): reflected coordinates are the identity for in-range pixels, so they are computed for every
+    // mode and only applied / tested through the wave-uniform flags; with OW >= 64 the cursor wraps at most once.
 #pragma unroll
     for (int i = 0; i < BU; ++i) {
       const int ih = boh[i] * a.sy + tap_dh, iw = bow[i] * a.sx + tap_dw;
-      int off = x_off[i] + tap_off;
-      bool ok = true;
-      if (a.run_mode) {
-        // already padded: (ih, iw) is in range by construction
-      } else if (a.reflect) {
-        const int ih2 = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
-        const int iw2 = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
-        off += __mul24(ih2 - ih, row_el) + __mul24(iw2 - iw, a.Cs);
-      } else {
-        ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
-      }
-      const bf16_t* src = ok ? a.X + off : zero;
-      glds16(src, st + b_lds[i]);
+      int ih2 = ih < 0 ? -ih : ih, iw2 = iw < 0 ? -iw : iw;
+      ih2 = ih2 > IHm1 ? 2 * IHm1 - ih2 : ih2;
+      iw2 = iw2 > IWm1 ? 2 * IWm1 - iw2 : iw2;
+      const int fix = __mul24(ih2 - ih, row_el) + __mul24(iw2 - iw, a.Cs);
+      const int off = x_off[i] + tap_off + (use_refl ? fix : 0);
+      const bool ok = no_test | (((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW));
+      const bf16_t* const src = a.X + (ok ? off : 0);
+      glds16(ok ? src : zero, st + b_lds[i]);
       // advance the cursor by one chunk (clamped at the last pixel: its dy row is the zero page)
-      if (pbase + BKP + b_pix[i] < a.M) {
-        bow[i] += BKP;
-        x_off[i] += adv_w;
-        while (bow[i] >= a.OW) {
-          bow[i] -= a.OW;
-          x_off[i] += adv_h - wrap_w;
-          if (++boh[i] == a.OH) { boh[i] = 0; x_off[i] -= wrap_h; }
+      const bool adv = pbase + BKP + b_pix[i] < a.M;
+      int nbow = bow[i] + BKP, nboh = boh[i], nx = x_off[i] + adv_w;
+      {
+        const bool w1 = nbow >= a.OW;
+        nbow -= w1 ? a.OW : 0;
+        nx += w1 ? adv_h - wrap_w : 0;
+        nboh += w1 ? 1 : 0;
+        const bool h1 = nboh == a.OH;
+        nboh = h1 ? 0 : nboh;
+        nx -= h1 ? wrap_h : 0;
+      }
+      if (narrow) {                                   // wave-uniform: output rows shorter than a chunk
+        while (nbow >= a.OW) {
+          nbow -= a.OW;
+          nx += adv_h - wrap_w;
+          if (++nboh == a.OH) { nboh = 0; nx -= wrap_h; }
         }
       }
+      bow[i] = adv ? nbow : bow[i];
+      boh[i] = adv ? nboh : boh[i];
+      x_off[i] = adv ? nx : x_off[i];
     }
     ++ich;
   };
