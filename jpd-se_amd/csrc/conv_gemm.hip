@@ -1017,6 +1017,8 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
     const FastArgs& a = b.p[i];
     if ((a.Y == nullptr && !a.no_finish) || ((a.splits > 1 || a.no_finish) && a.partial == nullptr))
       return set_error(JPDSE_EINVAL, "gemm_fast: problem %d has no output buffer", i);
+    if ((a.x_sh ? a.x_sh : (long long)a.IW * a.Cs) * a.IH >= (1LL << 31))
+      return set_error(JPDSE_EINVAL, "gemm_fast: one image spans >= 2^31 elements (in-image offsets are 32-bit)");
     b.first_tile[i] = total;
     total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN) * (a.splits > 1 ? a.splits : 1);
     const long long kdim = (long long)a.R * a.S * a.Cs;

@@ -192,8 +192,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   const int lrow = lane >> 3, lslot = lane & 7;
 
   // ---- per-unit staging state -------------------------------------------------------------
-  long long a_nbase[AU];
-  int a_oh[AU], a_ow[AU], a_choff[AU], a_lds[AU];
+  const bf16_t* a_xb[AU];             // image base + the lane's channel slot; in-image offsets are 32-bit (host-checked)
+  int a_oh[AU], a_ow[AU], a_lds[AU];
 #pragma unroll
   for (int i = 0; i < AU; ++i) {
     const int u = wid + i * NW;
@@ -201,10 +201,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     int m = m0 + row;
     m = m < a.M ? m : a.M - 1;
     const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
-    a_nbase[i] = (long long)n * (a.x_sn ? a.x_sn : (long long)a.IH * a.IW * a.Cs);
+    a_xb[i] = a.X + (long long)n * (a.x_sn ? a.x_sn : (long long)a.IH * a.IW * a.Cs) + ((lslot ^ (row >> 1)) & 7) * 8;
     a_oh[i] = oh * a.sy - a.py;
     a_ow[i] = ow * a.sx - a.px;
-    a_choff[i] = ((lslot ^ (row >> 1)) & 7) * 8;
     a_lds[i] = u * 1024;
   }
   const bf16_t* b_ptr[BU];
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
 #pragma unroll
   for (int j = 0; j < BU; ++j) {
     const int u = wid + j * NW;
-    b_on[j] = u < B_UNITS;
+    b_on[j] = (B_UNITS % NW == 0) || u < B_UNITS;      // compile-time true for every shipped configuration
     const int uu = b_on[j] ? u : 0;
     const int row = uu * 8 + lrow;
     int br = n0 + row;
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   int n_b = 0;
 #pragma unroll
   for (int j = 0; j < BU; ++j) n_b += b_on[j] ? 1 : 0;   // wave-uniform
-  const int LW = AU + n_b;                               // DMA instructions per wave per K-tile
+  const int LW = (B_UNITS % NW == 0) ? AU + BU : AU + n_b;   // DMA instructions per wave per K-tile
 
   int a_rd[TM][4], b_rd[TN][4];       // byte offset of the lane's fragment for each of the 4 k16-steps
   {
@@ -271,6 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   // zero padding only adds the in-range predicate to the final select.  (The if / else form compiled to four exec
   // branches per unit, executed behind the barrier whenever the tap changes -- every K-tile for 64-channel inputs.)
   const int IHm1 = a.IH - 1, IWm1 = a.IW - 1;
+  const int x_sh32 = (int)x_sh;
   const bool refl = a.reflect != 0;
   auto retap = [&]() {
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
       rh = rh < 0 ? 0 : rh;                             // zero padding wider than the image: any in-range pixel
       rw = rw < 0 ? 0 : rw;
       const bool ok = refl | (((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW));
-      const bf16_t* const src = a.X + (a_nbase[i] + (long long)rh * x_sh + (long long)rw * a.Cs + a_choff[i]);
+      const bf16_t* const src = a_xb[i] + (unsigned)(rh * x_sh32 + rw * a.Cs);
       a_src[i] = ok ? src : zero;
       a_step[i] = ok ? 64 : 0;
     }

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libjpdse_hip.so')
+# JPDSE_HIP_LIB: developer override (same-box A/B of two builds of this library); the default is the in-tree build
+LIB_PATH = os.environ.get('JPDSE_HIP_LIB') or os.path.join(_HERE, 'libjpdse_hip.so')
 
 F32, BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
