@@ -193,7 +193,8 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   // In flight across the barrier: only weight tile t+1 (BU pieces per wave, issued last in iteration t-1); the patch
   // unit issued before it is one iteration old by then, so a constant count suffices.
   static_assert(B_UNITS % NW == 0, "every wave issues exactly BU weight pieces per tile");
-  auto tap_body = [&](const int tap, const int slab, const bool more, const char* const hb) {
+  auto tap_body = [&](const int tap_r, const int tap_s, const int slab, const bool more, const char* const hb) {
+    const int tap = tap_r * S + tap_s;               // tap_s is a compile-time constant in both callers
     if (!(ABL & 8)) {
       if (tap < TAPS - 1 || more) wait_vmcnt<BU>(); else wait_vmcnt<0>();
     }
@@ -210,14 +211,14 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
       }
       const int tap2 = tap + 2 < TAPS ? tap + 2 : tap + 2 - TAPS;
       if (tap + 2 < TAPS || more) {
-        char* const st2 = bring + (tap2 % 3) * B_STAGE;           // (t + 2) % 3 with t = 9 * slab + tap
+        char* const st2 = bring + ((tap_s + 2) % 3) * B_STAGE;    // (t + 2) % 3 with t = 9 * slab + 3 * tap_r + tap_s
         const long long koff = (long long)tap2 * a.Cs + (slab + (tap + 2 < TAPS ? 0 : 1)) * 64;
 #pragma unroll
         for (int jj = 0; jj < BU; ++jj) glds16(b_ptr[jj] + koff, st2 + b_lds[jj]);
       }
     }
-    const char* const st = bring + (tap % 3) * B_STAGE;
-    const int tapoff = (tap / S) * PW + (tap % S);
+    const char* const st = bring + tap_s * B_STAGE;    // tap % 3
+    const int tapoff = tap_r * PW + tap_s;
     int a_base[FM], a_sw[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -247,14 +248,18 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   };
   if constexpr (SINGLE) {
     // one slab (Cs == 64), nothing to prefetch: the rolled loop keeps the kernel within 128 VGPRs (two blocks per CU)
+    // (filter rows rolled, the 3 taps of a row unrolled: ring stage and tap column stay compile-time constants)
 #pragma unroll 1
-    for (int tap = 0; tap < TAPS; ++tap) tap_body(tap, 0, false, halo0);
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int sx = 0; sx < S; ++sx) tap_body(r, sx, 0, false, halo0);
+    }
   } else {
     for (int slab = 0; slab < CC; ++slab) {
       const bool more = slab + 1 < CC;                  // wave-uniform
       const char* const hb = halo0 + (slab & (NBUF - 1)) * HALO;
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) tap_body(tap, slab, more, hb);
+      for (int tap = 0; tap < TAPS; ++tap) tap_body(tap / S, tap % S, slab, more, hb);
     }
   }
 
