@@ -135,62 +135,87 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
   const int a_lane_off = a_pl * a.Ks + a_slot_off;
   constexpr int CS = PITCH == 80 ? 40 : PITCH;        // channel storage when the pitch is a compile-time constant
   static_assert(A_PPU % 4 == 0 || A_ROWB >= 256, "swizzle must not depend on the unit index");
-  auto issue = [&](int strip, int stage) {
+  // strips are issued in order: their coordinates advance incrementally (wave-uniform, no division per strip)
+  int i_chunk = __builtin_amdgcn_readfirstlane(s_begin % a.chunks_per_row);
+  int i_row = __builtin_amdgcn_readfirstlane(s_begin / a.chunks_per_row);       // n*OH + oh
+  int i_oh = __builtin_amdgcn_readfirstlane(i_row % a.OH);
+  int i_n = __builtin_amdgcn_readfirstlane(i_row / a.OH);
+  auto issue = [&](int /*strip*/, int stage) {
     char* const st = smem + stage * stage_bytes;
-    const int chunk = strip % a.chunks_per_row;
-    const int row = strip / a.chunks_per_row;       // n*OH + oh
-    const int oh = row % a.OH, n = row / a.OH;
-    const int ow0 = chunk * 64;
+    const int row = i_row, oh = i_oh, n = i_n;
+    const int ow0 = i_chunk * 64;
+    if (++i_chunk == a.chunks_per_row) {
+      i_chunk = 0;
+      ++i_row;
+      if (++i_oh == a.OH) { i_oh = 0; ++i_n; }
+    }
     const bf16_t* const dy_base = a.DY + ((long long)row * a.OW + ow0) * a.Ks;                       // uniform
     const long long x_base = (((long long)n * a.Hp + oh * a.st + r0) * a.Wp + (long long)ow0 * a.st) * a.Cs;
     const long long x_row = (long long)a.Wp * a.Cs;
     const int px_left = a.OW - ow0;                  // valid output pixels from ow0 on
-    for (int u = wid; u < units; u += NW) {
-      const bf16_t* src;
-      if (u < A_UNITS) {
-        const int pix0 = u * A_PPU;                   // uniform
-        if (!a.unpadded) {
-          src = pix0 + a_pl < px_left ? dy_base + (pix0 * a.Ks + a_lane_off) : zero;
-        } else {
-          // virtual (oh, ow0 + pix) of the padded grid -> pixel of the real tensor
-          int ay = oh - a.a_pad, ax = ow0 + pix0 + a_pl - a.a_pad;
-          if (a.a_reflect) {
-            ay = ay < 0 ? -ay : (ay >= a.AH ? 2 * (a.AH - 1) - ay : ay);
-            ax = ax < 0 ? -ax : (ax >= a.AW ? 2 * (a.AW - 1) - ax : ax);
-          }
-          const bool arow_ok = (unsigned)ay < (unsigned)a.AH;                                      // uniform
-          const bf16_t* const arow = a.DY + ((long long)n * a.AH + (arow_ok ? ay : 0)) * a.AW * a.Ks;
-          const bool ok = arow_ok && pix0 + a_pl < px_left && (unsigned)ax < (unsigned)a.AW;
-          src = ok ? arow + (__mul24(ax, a.Ks) + a_slot_off) : zero;
-        }
-      } else {
-        const int ub = u - A_UNITS;
+    // Two flat passes (dy-side units, then run units), the padded / in-loader-padding variants split ONCE per strip:
+    // the single loop with nested if / else per unit compiled to ~15 scalar and exec branches per DMA.
+    constexpr int A_ITERS = (A_UNITS + NW - 1) / NW;
+    if (!a.unpadded) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        const int u = wid + it * NW;
+        if (A_UNITS % NW != 0 && u >= A_UNITS) break;               // wave-uniform
+        const int pix0 = u * A_PPU;
+        const bool ok = pix0 + a_pl < px_left;
+        const bf16_t* const src = dy_base + (ok ? pix0 * a.Ks + a_lane_off : 0);
+        glds16(ok ? src : zero, st + u * 1024);
+      }
+      for (int ub = wid; ub < RR * a.x_units; ub += NW) {
         int rr = 0, uu = ub;
         if constexpr (RR > 1) {       // wave-uniform; RR == 1 keeps the division out of the loader
           rr = ub / a.x_units;
           uu = ub - rr * a.x_units;
         }
-        const bool row_ok = r0 + rr < a.R;
-        if (!a.unpadded) {
-          const long long e0 = x_base + rr * x_row + (long long)uu * 512;   // uniform: first element of the unit
-          src = (row_ok && e0 + lane * 8 + 8 <= a.x_limit) ? a.XP + e0 + lane * 8 : zero;
-        } else {
-          // element offset inside the virtual padded row -> (pixel, channel slot) -> real pixel
-          const int el = uu * 512 + lane * 8;
-          const int pxo = PITCH ? el / CS : el / a.Cs;
-          const int ch = el - pxo * (PITCH ? CS : a.Cs);
-          int ry = oh * a.st + r0 + rr - a.r_pad, rx = ow0 * a.st + pxo - a.r_pad;
-          if (a.r_reflect) {
-            ry = ry < 0 ? -ry : (ry >= a.RH ? 2 * (a.RH - 1) - ry : ry);
-            rx = rx < 0 ? -rx : (rx >= a.RW ? 2 * (a.RW - 1) - rx : rx);
-          }
-          const bool rrow_ok = row_ok && oh * a.st + r0 + rr < a.Hp && (unsigned)ry < (unsigned)a.RH;   // uniform
-          const bf16_t* const rrow = a.XP + ((long long)n * a.RH + (rrow_ok ? ry : 0)) * a.RW * (PITCH ? CS : a.Cs);
-          const bool ok = rrow_ok && ow0 * a.st + pxo < a.Wp && (unsigned)rx < (unsigned)a.RW;
-          src = ok ? rrow + (__mul24(rx, PITCH ? CS : a.Cs) + ch) : zero;
-        }
+        const long long e0 = x_base + rr * x_row + (long long)uu * 512;   // uniform: first element of the unit
+        const bool ok = (r0 + rr < a.R) & (e0 + lane * 8 + 8 <= a.x_limit);
+        const bf16_t* const src = a.XP + (ok ? e0 + lane * 8 : 0);
+        glds16(ok ? src : zero, st + (A_UNITS + ub) * 1024);
       }
-      glds16(src, st + u * 1024);
+    } else {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        const int u = wid + it * NW;
+        if (A_UNITS % NW != 0 && u >= A_UNITS) break;               // wave-uniform
+        const int pix0 = u * A_PPU;
+        // virtual (oh, ow0 + pix) of the padded grid -> pixel of the real tensor
+        int ay = oh - a.a_pad, ax = ow0 + pix0 + a_pl - a.a_pad;
+        if (a.a_reflect) {
+          ay = ay < 0 ? -ay : (ay >= a.AH ? 2 * (a.AH - 1) - ay : ay);
+          ax = ax < 0 ? -ax : (ax >= a.AW ? 2 * (a.AW - 1) - ax : ax);
+        }
+        const bool arow_ok = (unsigned)ay < (unsigned)a.AH;                                      // uniform
+        const bf16_t* const arow = a.DY + ((long long)n * a.AH + (arow_ok ? ay : 0)) * a.AW * a.Ks;
+        const bool ok = arow_ok & (pix0 + a_pl < px_left) & ((unsigned)ax < (unsigned)a.AW);
+        const bf16_t* const src = arow + (ok ? __mul24(ax, a.Ks) + a_slot_off : 0);
+        glds16(ok ? src : zero, st + u * 1024);
+      }
+      for (int ub = wid; ub < RR * a.x_units; ub += NW) {
+        int rr = 0, uu = ub;
+        if constexpr (RR > 1) {
+          rr = ub / a.x_units;
+          uu = ub - rr * a.x_units;
+        }
+        // element offset inside the virtual padded row -> (pixel, channel slot) -> real pixel
+        const int el = uu * 512 + lane * 8;
+        const int pxo = PITCH ? el / CS : el / a.Cs;
+        const int ch = el - pxo * (PITCH ? CS : a.Cs);
+        int ry = oh * a.st + r0 + rr - a.r_pad, rx = ow0 * a.st + pxo - a.r_pad;
+        if (a.r_reflect) {
+          ry = ry < 0 ? -ry : (ry >= a.RH ? 2 * (a.RH - 1) - ry : ry);
+          rx = rx < 0 ? -rx : (rx >= a.RW ? 2 * (a.RW - 1) - rx : rx);
+        }
+        const bool rrow_ok = (r0 + rr < a.R) & (oh * a.st + r0 + rr < a.Hp) & ((unsigned)ry < (unsigned)a.RH);   // uniform
+        const bf16_t* const rrow = a.XP + ((long long)n * a.RH + (rrow_ok ? ry : 0)) * a.RW * (PITCH ? CS : a.Cs);
+        const bool ok = rrow_ok & (ow0 * a.st + pxo < a.Wp) & ((unsigned)rx < (unsigned)a.RW);
+        const bf16_t* const src = rrow + (ok ? __mul24(rx, PITCH ? CS : a.Cs) + ch : 0);
+        glds16(ok ? src : zero, st + (A_UNITS + ub) * 1024);
+      }
     }
   };
 
