@@ -106,38 +106,50 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_taps_kernel(const TapsWgAr
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][i][e] = 0.f;
 
-  auto issue = [&](int chunk, int stage) {
+  // chunks are issued in order: coordinates advance incrementally (wave-uniform, no division per chunk); padding is
+  // resolved with selects -- reflected coordinates are the identity in range, so they are computed for both modes
+  int i_cw = __builtin_amdgcn_readfirstlane(ch_begin % a.chunks_per_row);
+  int i_row = __builtin_amdgcn_readfirstlane(ch_begin / a.chunks_per_row);       // n*OH + oh
+  int i_oh = __builtin_amdgcn_readfirstlane(i_row % a.OH);
+  int i_n = __builtin_amdgcn_readfirstlane(i_row / a.OH);
+  const int IHm1 = a.IH - 1, IWm1 = a.IW - 1;
+  const bool refl = a.reflect != 0;
+  auto issue = [&](int /*chunk*/, int stage) {
     char* const st = smem + stage * STAGE;
-    const int cw = chunk % a.chunks_per_row;
-    const int row = chunk / a.chunks_per_row;        // n*OH + oh
-    const int oh = row % a.OH, n = row / a.OH;
-    const int ow0 = cw * BKP;
+    const int row = i_row, oh = i_oh, n = i_n;
+    const int ow0 = i_cw * BKP;
+    if (++i_cw == a.chunks_per_row) {
+      i_cw = 0;
+      ++i_row;
+      if (++i_oh == a.OH) { i_oh = 0; ++i_n; }
+    }
     const int px_left = a.OW - ow0;
     const bf16_t* const dy_base = a.DY + ((long long)row * a.OW + ow0) * a.Ks;      // uniform
     const bf16_t* const x_img = a.X + (long long)n * a.IH * row_el;                  // uniform
     const int ih0 = oh * ST + r0 - a.pad, iw0 = ow0 * ST - a.pad;
 #pragma unroll
     for (int i = 0; i < AU; ++i) {
-      if (wid + NW * i < A_UNITS) {
-        const bf16_t* src = (wid + NW * i) * A_PPU + a_pl < px_left ? dy_base + a_loff[i] : zero;
-        glds16(src, st + (wid + NW * i) * 1024);
+      if (A_UNITS % NW == 0 || wid + NW * i < A_UNITS) {
+        const bool ok = (wid + NW * i) * A_PPU + a_pl < px_left;
+        const bf16_t* const src = dy_base + (ok ? a_loff[i] : 0);
+        glds16(ok ? src : zero, st + (wid + NW * i) * 1024);
       }
     }
 #pragma unroll
     for (int i = 0; i < BU; ++i) {
-      if (wid + NW * i < B_UNITS) {
+      if (B_UNITS % NW == 0 || wid + NW * i < B_UNITS) {
         const int rr = b_rj[i] >> 16;
-        int ih = ih0 + rr, iw = iw0 + (b_rj[i] & 0xffff);
-        bool ok = r0 + rr < a.R;                     // also false for the lanes beyond the patch
-        if (a.reflect) {
-          ih = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
-          iw = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
-          ok = ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;   // ragged chunks overhang
-        } else {
-          ok = ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
-        }
-        const bf16_t* src = ok ? x_img + (__mul24(ih, row_el) + __mul24(iw, a.Cs) + b_sw[i]) : zero;
-        glds16(src, st + (A_UNITS + wid + NW * i) * 1024);
+        const int ih = ih0 + rr, iw = iw0 + (b_rj[i] & 0xffff);
+        int rh = ih < 0 ? -ih : ih, rw = iw < 0 ? -iw : iw;
+        rh = rh > IHm1 ? 2 * IHm1 - rh : rh;
+        rw = rw > IWm1 ? 2 * IWm1 - rw : rw;
+        // in range after reflection?  (false for ragged chunks overhanging by more than the image, and for zero padding
+        // whenever the raw coordinate is outside); r0 + rr >= R also covers the lanes beyond the patch
+        const bool inr = refl ? (((unsigned)rh <= (unsigned)IHm1) & ((unsigned)rw <= (unsigned)IWm1))
+                              : (((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW));
+        const bool ok = (r0 + rr < a.R) & inr;
+        const bf16_t* const src = x_img + (ok ? __mul24(rh, row_el) + __mul24(rw, a.Cs) + b_sw[i] : 0);
+        glds16(ok ? src : zero, st + (A_UNITS + wid + NW * i) * 1024);
       }
     }
   };
