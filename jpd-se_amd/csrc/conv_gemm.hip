@@ -890,7 +890,7 @@ static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
   p->toep = (p->ES == 2 && p->Ks == 8 && st == 1) ? 1 : 0;
   p->Lk_toep = p->toep ? round_up((d->S + 3) * p->Cs, p->BKE) : 0;
   p->fwd_pack_bytes = p->fwd_pack_plain_bytes + (p->toep ? align_up((size_t)32 * d->R * p->Lk_toep * p->ES, 256) : 0);
-  p->thinf = (p->ES == 2 && p->Cs % 64 != 0 && p->Cs > 8 && p->Cs <= 48 && st <= 2 && (p->Ks == 32 || p->Ks == 64) && d->K == p->Ks) ? 1 : 0;
+  p->thinf = (p->ES == 2 && p->Cs % 64 != 0 && p->Cs <= 48 && st <= 2 && (p->Ks == 32 || p->Ks == 64) && d->K == p->Ks) ? 1 : 0;
   p->KP_thin = p->thinf ? round_up(d->S * p->Cs, 16) + 8 : 0;
   p->thin_pack_off = p->fwd_pack_bytes;
   if (p->thinf) p->fwd_pack_bytes += align_up((size_t)d->R * p->Ks * p->KP_thin * 2, 256);
@@ -1209,7 +1209,9 @@ static bool thin_fwd_geom(const jpdse_conv_desc* d, const ConvPlan& p, ThinFwdGe
   const int st = d->stride;
   g->w_units = (p.Ks * p.KP_thin * 2 + 1023) / 1024;
   static const int cand[3][2] = {{8, 64}, {4, 64}, {4, 32}};
-  for (int c = 0; c < 3; ++c) {
+  // 8-channel inputs (VGG conv1_1) are output-write bound: the smaller block keeps the epilogue tile at 48 KiB so that
+  // three blocks share a CU
+  for (int c = (p.Cs <= 8 && p.Ks == 64) ? 1 : 0; c < 3; ++c) {
     const int TH = cand[c][0], TW = cand[c][1];
     if (TH == 4 && p.Ks != 64) break;                 // 4 rows x 2 column groups needs K = 64 (32 per group)
     g->strip_units = (((TW - 1) * st + d->S) * p.Cs * 2 + 16 + 1023) / 1024;
