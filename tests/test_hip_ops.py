@@ -448,3 +448,50 @@ def test_fused_adam_matches_torch():
     assert mine[i]._jpdse_cast_wver == mine[i]._jpdse_wver == 3
   sd = o_hip.state_dict()
   assert set(sd['state'][0].keys()) >= {'step', 'exp_avg', 'exp_avg_sq'} and float(sd['state'][0]['step']) == 3.0
+
+
+# ---- full-size, oracle-free: the three convolution kernels of a layer are mutually adjoint -------------------------
+# <conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)>.  The oracle finishes these shapes in minutes, not seconds, so at
+# BASELINE.json's sizes (batch 4 @ 1024x512) parity is checked through this size-independent property: it ties the
+# forward, data-gradient and weight-gradient kernels (three different tilings, loaders and epilogues) to one number.
+FULL_SIZE_LAYERS = [
+    # name,                  N, H,   W,    C,    K,    k, st, pad, mode
+    ('resblock_1024',        4, 32,  64,   1024, 1024, 3, 1,  1,   PAD_REFLECT),
+    ('g_first_7x7',          4, 512, 1024, 39,   64,   7, 1,  3,   PAD_REFLECT),
+    ('g_down_64_128',        4, 512, 1024, 64,   128,  3, 2,  1,   PAD_ZERO),
+    ('vgg_conv1_2',          4, 512, 1024, 64,   64,   3, 1,  1,   PAD_ZERO),
+    ('d_layer0',             8, 512, 1024, 39,   64,   4, 2,  2,   PAD_ZERO),
+    ('d_layer3',             8, 65,  129,  256,  512,  4, 1,  2,   PAD_ZERO),
+]
+
+
+@pytest.mark.parametrize('case', FULL_SIZE_LAYERS, ids=[c[0] for c in FULL_SIZE_LAYERS])
+def test_full_size_adjointness_bf16(case):
+  name, N, H, W, C, K, k, st, pad, mode = case
+  g = torch.Generator(device=DEV).manual_seed(zlib.crc32(name.encode()) % 1000)
+  layer = HipConv2d(C, K, k, st, pad, mode, act=ACT_NONE, apply_bias=False, dtype=BF16, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(torch.randn(layer.weight.shape, generator=g, device=DEV) * (1.0 / (C * k * k) ** 0.5))
+  x = Act.empty(N, H, W, C, BF16, DEV)
+  x.t.zero_()
+  x.t[..., :C] = torch.randn((N, H, W, C), generator=g, device=DEV).to(torch.bfloat16)
+  y, ctx = layer.fwd(x)
+  dy = y.empty_like()
+  dy.t.zero_()
+  dy.t[..., :K] = torch.randn(tuple(y.t.shape[:3]) + (K,), generator=g, device=DEV).to(torch.bfloat16)
+  dx = layer.bwd(ctx, dy, need_dx=True, need_dw=True)
+  torch.cuda.synchronize()
+  dot = lambda a, b: (a.double() * b.double()).sum().item()
+  wq = layer.weight.detach().to(torch.bfloat16)             # the packed panel holds the bf16-rounded master
+  lhs = dot(y.t, dy.t)
+  via_dx = dot(x.t, dx.t)
+  via_dw = dot(wq, layer.weight.grad)
+  scale = (dot(y.t, y.t) * dot(dy.t, dy.t)) ** 0.5          # Cauchy-Schwarz bound of the three products
+  # Random x, dy make <y,dy> itself ~1e-4 of scale (n ~ 1e8 terms of random sign); measured residuals are 4e-8 .. 1.1e-6
+  # of scale (bf16 storage of y / dx, fp32 atomics in wgrad).  A bound of 4e-6 of scale = ~4 % of the product: dropping
+  # 0.2 % of the terms (one border ring at 1024x512) moves it by more than that.
+  print('%s: |<y,dy>-<x,dx>|/scale = %.2e, |<y,dy>-<w,dw>|/scale = %.2e, <y,dy>/scale = %.2e' % (
+      name, abs(lhs - via_dx) / scale, abs(lhs - via_dw) / scale, lhs / scale))
+  assert abs(lhs - via_dx) <= 4e-6 * scale, '%s: <y,dy> %.6e vs <x,dx> %.6e (scale %.3e)' % (name, lhs, via_dx, scale)
+  assert abs(lhs - via_dw) <= 4e-6 * scale, '%s: <y,dy> %.6e vs <w,dw> %.6e (scale %.3e)' % (name, lhs, via_dw, scale)
+  assert scale > 0 and abs(lhs) < scale
