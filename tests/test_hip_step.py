@@ -348,3 +348,46 @@ def test_unsupported_flags_fail_loudly():
     get_trainer(_opts(no_generator_binarization=False))(_opts(no_generator_binarization=False), 'train')
   with pytest.raises(NotImplementedError):
     get_trainer(_opts(pool_size=5))(_opts(pool_size=5), 'train')
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_full_size_batch_gradient_is_mean_of_per_image_gradients(dtype):
+  """Oracle-free property at BASELINE.json's size (1024x512, full ngf=64 generator, 2-scale D, VGG): no op of the
+  loss graph couples samples (InstanceNorm is per (n, c), every loss is a batch mean), so the generator gradient of
+  a 2-image batch is the mean of the two single-image gradients -- the premise of sharding images over ranks
+  (SURVEY.md 8e).  fp32: all layers to 1e-3.  bf16: the layers next to the output to 2e-2; deeper ones only in
+  direction -- 1-ulp differences of bf16-stored gradients (the split-K factor depends on the batch) decorrelate
+  chaotically through 40 layers, as between any two correct bf16 runs."""
+  opt = _opts(compute_dtype=dtype, use_compressed=True)
+  torch.manual_seed(7)
+  tr = get_trainer(opt)(opt, 'train')
+  m = tr.model
+  xd = omodel.synthetic_batch(2, 512, 1024, seed=11)
+  w = dict(w_gan=1.0, w_feat=opt.lambda_feat, w_vgg=opt.lambda_feat, w_dist=opt.lambda_distortion)
+  top = ['model.38.weight', 'model.38.bias', 'model.34.weight']
+  deep = ['model.24.conv_block.5.weight', 'model.16.conv_block.1.weight', 'model.4.weight', 'model.1.weight']
+  names = top + deep
+  params = dict(m.netG.named_parameters())
+
+  def grads(x_dict):
+    state, slots, layout = m._forward_losses(x_dict, grad_w=dict(feat=w['w_feat'], vgg=w['w_vgg'], dist=w['w_dist']))
+    assert m.backward_G(state, w['w_gan'], w['w_feat'], w['w_vgg'], w['w_dist'])
+    torch.cuda.synchronize()
+    return {k: params[k].grad.detach().double().clone() for k in names}
+
+  def one(i):
+    return {k: v[i:i + 1] for k, v in xd.items()}
+
+  g_batch = grads(xd)
+  g0, g1 = grads(one(0)), grads(one(1))
+  for k in names:
+    mean = 0.5 * (g0[k] + g1[k])
+    err = ((g_batch[k] - mean).norm() / mean.norm().clamp_min(1e-30)).item()
+    cos = ((g_batch[k] * mean).sum() / (g_batch[k].norm() * mean.norm()).clamp_min(1e-30)).item()
+    print('%s %s: rel L2 %.3e cos %.5f' % (dtype, k, err, cos))
+    if dtype == 'fp32':
+      assert err <= 1e-3, '%s: batch gradient deviates from the per-image mean by %.3e (relative L2)' % (k, err)
+    elif k in top:
+      assert err <= 2e-2, '%s: batch gradient deviates from the per-image mean by %.3e (relative L2)' % (k, err)
+    else:
+      assert cos >= 0.9, '%s: batch gradient points away from the per-image mean (cos %.4f)' % (k, cos)
