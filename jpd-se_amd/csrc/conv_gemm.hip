@@ -752,6 +752,39 @@ __global__ __launch_bounds__(256) void pack_dgrad_tile_many_kernel(const jpdse_p
   const int c0 = bx * 64, k0 = by * 64;
   const int up = bz / e.Uw, wp = bz % e.Uw;
   const int r = e.qh + e.st * (e.Uh - 1 - up), s = e.qw + e.st * (e.Uw - 1 - wp);
+  const int t = threadIdx.x;
+  if ((e.C & 3) == 0) {
+    // 16-byte loads along c (4 per thread), 16-byte stores along k (2 per thread): a quarter of the memory instructions
+    // of the scalar form below (0.34 -> 0.2 ms for the generator's 182 M weights)
+    const int cq = (t & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = (t >> 4) + 16 * i;
+      const int k = k0 + kk, c = c0 + cq;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k < e.K && c < e.C) v = *reinterpret_cast<const f32x4*>(e.w + (((long long)k * e.R + r) * e.S + s) * e.C + c);
+      tile[kk][cq] = v[0];
+      tile[kk][cq + 1] = v[1];
+      tile[kk][cq + 2] = v[2];
+      tile[kk][cq + 3] = v[3];
+    }
+    __syncthreads();
+    bf16_t* const out = reinterpret_cast<bf16_t*>(e.out);
+    const int kq = (t & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cc = (t >> 3) + 32 * i;
+      const int c = c0 + cc, k = k0 + kq;
+      if (c < e.Cs && k < e.Ks) {                       // Ks % 8 == 0: the 8 channels are in range together
+        u32x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          pk[j] = (uint32_t)f2bf(tile[kq + 2 * j][cc]) | ((uint32_t)f2bf(tile[kq + 2 * j + 1][cc]) << 16);
+        *reinterpret_cast<u32x4*>(out + ((long long)c * e.Uh + up) * e.Lk + wp * e.Ks + k) = pk;
+      }
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int kk = ty; kk < 64; kk += 4) {
     const int k = k0 + kk, c = c0 + tx;
