@@ -393,9 +393,9 @@ class Pix2PixHDModel(BaseModel):
           else:
             row.append(ops.l1_bwd(ff, fr, one, w_feat / opt.num_D))
         dres.append(row)
-      d_in = self.netD.bwd(state['d_ctx'], dres, need_dx=True, need_dw=False, batch=(0, B))
-      d_fake = Act(torch.zeros_like(fake.t), fake.C)
-      ops.channel_copy(d_in, self.label_nc, d_fake, 0, fake.C)
+      # only the image channels of D's concatenated input carry a gradient back to G
+      d_fake = self.netD.bwd(state['d_ctx'], dres, need_dx=True, need_dw=False, batch=(0, B),
+                             dx_channels=(self.label_nc, self.label_nc + fake.C))
     if w_vgg != 0.0 and state['v_ctx'] is not None:
       wk = networks.VGGLoss.weights
       dmaps = state.get('d_vgg') or [ops.l1_bwd(state['vf'][k], state['vr'][k], one, w_vgg * wk[k], relu_a=True)

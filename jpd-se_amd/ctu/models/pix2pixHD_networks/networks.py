@@ -262,15 +262,19 @@ class NLayerDiscriminator(nn.Module):
       ctxs.append(c)
     return feats, ctxs
 
-  def bwd(self, ctxs, dfeats, need_dx=False, need_dw=True):
-    """dfeats[j]: gradient w.r.t. feature j (Act) or None."""
+  def bwd(self, ctxs, dfeats, need_dx=False, need_dw=True, dx_channels=None):
+    """dfeats[j]: gradient w.r.t. feature j (Act) or None.  dx_channels=(c0, c1): return the input gradient of
+    those channels only (needs need_dw False: the generator's pass through D)."""
     d = None
     for j in range(len(self._stages) - 1, -1, -1):
       if dfeats[j] is not None:
         d = dfeats[j] if d is None else ops.add_(d, dfeats[j])
       if d is None:
         continue
-      d = self._stages[j].bwd(ctxs[j], d, need_dx or j > 0, need_dw)
+      if j == 0 and dx_channels is not None and need_dx and not need_dw:
+        d = self._stages[0].bwd_input_slice(ctxs[0], d, dx_channels[0], dx_channels[1])
+      else:
+        d = self._stages[j].bwd(ctxs[j], d, need_dx or j > 0, need_dw)
     return d
 
 
@@ -303,15 +307,16 @@ class MultiscaleDiscriminator(nn.Module):
         h = ops.avgpool3s2_fwd(h)
     return result, ctxs
 
-  def bwd(self, ctxs, dresult, need_dx=False, need_dw=True, batch=None):
+  def bwd(self, ctxs, dresult, need_dx=False, need_dw=True, batch=None, dx_channels=None):
     """dresult[i][j]: Act or None.  `batch=(b0,b1)` back-propagates only that sub-batch of the
-    saved forward (per-sample InstanceNorm makes sub-batches independent)."""
+    saved forward (per-sample InstanceNorm makes sub-batches independent).  dx_channels=(c0, c1): the returned
+    input gradient covers those input channels only (AvgPool between the scales acts per channel)."""
     dx = None
     for i in range(self.num_D - 1, -1, -1):
       c, H, W = ctxs[i]
       if batch is not None:
         c = [ci.slice(batch[0], batch[1]) for ci in c]
-      d = self._scales[self.num_D - 1 - i].bwd(c, dresult[i], need_dx, need_dw)
+      d = self._scales[self.num_D - 1 - i].bwd(c, dresult[i], need_dx, need_dw, dx_channels)
       if need_dx:
         if dx is not None:          # gradient arriving from the coarser scale through AvgPool
           d = ops.add_(d, ops.avgpool3s2_bwd(dx, H, W))
