@@ -266,13 +266,19 @@ class NLayerDiscriminator(nn.Module):
     """dfeats[j]: gradient w.r.t. feature j (Act) or None.  dx_channels=(c0, c1): return the input gradient of
     those channels only (needs need_dw False: the generator's pass through D)."""
     d = None
+    fused = False           # dfeats[j] already summed into d by the data-gradient epilogue of stage j+1
     for j in range(len(self._stages) - 1, -1, -1):
-      if dfeats[j] is not None:
+      if dfeats[j] is not None and not fused:
         d = dfeats[j] if d is None else ops.add_(d, dfeats[j])
+      fused = False
       if d is None:
         continue
       if j == 0 and dx_channels is not None and need_dx and not need_dw:
         d = self._stages[0].bwd_input_slice(ctxs[0], d, dx_channels[0], dx_channels[1])
+      elif j > 0 and dfeats[j - 1] is not None:
+        # the feature-matching gradient of feature j-1 joins in the epilogue of this stage's data gradient
+        d = self._stages[j].bwd(ctxs[j], d, True, need_dw, addend=dfeats[j - 1])
+        fused = True
       else:
         d = self._stages[j].bwd(ctxs[j], d, need_dx or j > 0, need_dw)
     return d

@@ -296,10 +296,10 @@ class ConvNormAct(object):
     y, c2 = self.norm.fwd(h)
     return y, Ctx(c1, c2)
 
-  def bwd(self, ctx, dy, need_dx=True, need_dw=True):
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True, addend=None):
     c1, c2 = ctx.items
     dh = self.norm.bwd(c2, dy)
-    return self.conv.bwd(c1, dh, need_dx, need_dw)
+    return self.conv.bwd(c1, dh, need_dx, need_dw, addend=addend)
 
 
 class _Slot(nn.Module):
