@@ -148,10 +148,25 @@ __device__ __forceinline__ void reduce_splits(const float* __restrict__ partial,
                                               int sub, float& a, float& b) {
   a = 0.f;
   b = 0.f;
-  for (int s = sub; s < splits; s += 8) {
-    const float* p = partial + (((long long)n * splits + s) * Cs + c) * 2;
-    a += p[0];
-    b += p[1];
+  // four partials per trip, loaded before any is added: the serial form (one L2 round trip per split) made these
+  // tiny kernels ~8 us each, 72 of them per step
+  const long long stride = (long long)Cs * 2;
+  const float* p = partial + (((long long)n * splits + sub) * Cs + c) * 2;
+  int s = sub;
+  for (; s + 24 < splits; s += 32, p += 32 * stride) {
+    const float2 v0 = *reinterpret_cast<const float2*>(p);
+    const float2 v1 = *reinterpret_cast<const float2*>(p + 8 * stride);
+    const float2 v2 = *reinterpret_cast<const float2*>(p + 16 * stride);
+    const float2 v3 = *reinterpret_cast<const float2*>(p + 24 * stride);
+    a += v0.x; b += v0.y;
+    a += v1.x; b += v1.y;
+    a += v2.x; b += v2.y;
+    a += v3.x; b += v3.y;
+  }
+  for (; s < splits; s += 8, p += 8 * stride) {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    a += v.x;
+    b += v.y;
   }
 #pragma unroll
   for (int off = 4; off > 0; off >>= 1) {
