@@ -1533,8 +1533,25 @@ struct RingFoldArgs {
 };
 __device__ __forceinline__ void ring_acc(float (&acc)[8], const float* slab, int splits, long long slab_elems,
                                          long long row, int Cs, int c0) {
-  for (int sp = 0; sp < splits; ++sp) {
-    const float4* src = reinterpret_cast<const float4*>(slab + sp * slab_elems + row * Cs + c0);
+  // slabs are read four at a time before they are added (same order): one L2 round trip per split otherwise
+  const float* base = slab + row * Cs + c0;
+  int sp = 0;
+  for (; sp + 4 <= splits; sp += 4) {
+    float4 lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4* src = reinterpret_cast<const float4*>(base + (sp + u) * slab_elems);
+      lo[u] = src[0];
+      hi[u] = src[1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] += lo[u].x; acc[1] += lo[u].y; acc[2] += lo[u].z; acc[3] += lo[u].w;
+      acc[4] += hi[u].x; acc[5] += hi[u].y; acc[6] += hi[u].z; acc[7] += hi[u].w;
+    }
+  }
+  for (; sp < splits; ++sp) {
+    const float4* src = reinterpret_cast<const float4*>(base + sp * slab_elems);
     const float4 lo = src[0], hi = src[1];
     acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w;
     acc[4] += hi.x; acc[5] += hi.y; acc[6] += hi.z; acc[7] += hi.w;

@@ -398,8 +398,26 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const FastArgs a, lo
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int sidx = 0; sidx < a.splits; ++sidx) {
-    const float4* src = reinterpret_cast<const float4*>(a.partial + ((long long)sidx * a.M + m) * a.Ks + c0);
+  // slabs are read four at a time before they are added (same order): one L2 / HBM round trip per split otherwise
+  const float* const base = a.partial + (long long)m * a.Ks + c0;
+  const long long slab_elems = (long long)a.M * a.Ks;
+  int sidx = 0;
+  for (; sidx + 4 <= a.splits; sidx += 4) {
+    float4 lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4* src = reinterpret_cast<const float4*>(base + (sidx + u) * slab_elems);
+      lo[u] = src[0];
+      hi[u] = src[1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] += lo[u].x; acc[1] += lo[u].y; acc[2] += lo[u].z; acc[3] += lo[u].w;
+      acc[4] += hi[u].x; acc[5] += hi[u].y; acc[6] += hi[u].z; acc[7] += hi[u].w;
+    }
+  }
+  for (; sidx < a.splits; ++sidx) {
+    const float4* src = reinterpret_cast<const float4*>(base + sidx * slab_elems);
     const float4 lo = src[0], hi = src[1];
     acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w;
     acc[4] += hi.x; acc[5] += hi.y; acc[6] += hi.z; acc[7] += hi.w;
