@@ -3,7 +3,10 @@
 (G fwd/bwd + batched 2-scale PatchGAN + 2x VGG19 + both Adam updates) at 1024x512.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+N > 1 works both ways: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or invoked directly, in which case this process
+-- BEFORE it makes any GPU call -- starts that very launcher as a child, relays rank 0's JSON line and exits with the
+child's code (no exec of a process that has touched the GPU).
 
 Workload (BASELINE.json metric / configs[3] at N GPUs): script-default
 GlobalGenerator ngf=64, 4 downsamples, 9 ResnetBlocks; 39 input channels; num_D=2; LSGAN +
@@ -51,6 +54,15 @@ def parse():
                   help='BASELINE config 2: GlobalGenerator + 2-scale PatchGAN step without the VGG loss '
                        '(no_vgg_loss + skip_unused_losses: VGG is not run at all)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                  help='collective backend for N > 1: nccl == RCCL over xGMI (the product path); gloo only to rehearse '
+                       'the multi-rank schedule on a box with fewer GPUs than ranks (with --share-gpu)')
+  ap.add_argument('--share-gpu', action='store_true',
+                  help='rehearsal: ranks take device LOCAL_RANK %% device_count (several ranks per GPU; needs --backend gloo)')
+  ap.add_argument('--bf16-reduce', action='store_true',
+                  help='all-reduce the gradients in bf16 (half the xGMI bytes) instead of fp32; reported next to the fp32 '
+                       'reduce (SURVEY.md 8d config 4)')
+  ap.add_argument('--master-port', type=int, default=0, help='self-launch only: rendezvous port (0 = pick a free one)')
   ap.add_argument('--debug-mode', type=int, default=None,
                   help='developer A/B switch: value for jpdse_debug_set_fast_path (kernel selection), default untouched')
   return ap.parse_args()
@@ -59,45 +71,95 @@ def parse():
 def make_opt(args, device_index):
   from ctu.utils.synthetic import default_opt
   kw = dict(gpu_ids=[device_index], print_losses=False, compute_dtype=args.dtype, use_compressed=True,
-            netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch)
+            netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch,
+            bf16_grad_reduce=args.bf16_reduce)
   if args.no_vgg:
     kw.update(no_vgg_loss=True, skip_unused_losses=True)
   return default_opt(**kw)
 
 
-def cpu_baseline(args):
-  """The oracle (a port: kind 'port') on this box's host cores: one 512x256 step, then -- if that
-  took < 20 s -- one 1024x512 step, batch 1, fp32; the larger one that ran is reported."""
+def cpu_baseline(args, budget_s=30.0):
+  """The oracle (a port: kind 'port') on this box's host cores, SURVEY.md 8(d): fp32, batch 1, all host cores, warm-up
+  then >= 3 timed steps at 512x256; when those are fast enough that three 1024x512 steps (4x the work) fit the budget
+  as well, one warm-up + 3 timed steps at the reported size, and that figure is the one quoted.  Bounded: about
+  `budget_s` seconds of CPU work."""
   from oracle.ctu_cpu import model as omodel
   cores = torch.get_num_threads()
   opt = omodel.default_opt(netG=args.netG, ngf=64 if args.netG == 'global' else 32, use_compressed=True)
   torch.manual_seed(1234)
   ora = omodel.OracleTrainer(opt)
-  t0 = time.time()
-  ora.step(omodel.synthetic_batch(1, 256, 512, seed=1))
-  t_small = time.time() - t0
-  sample, secs = '1 step, batch 1, 512x256, fp32 torch-CPU oracle', t_small
-  if t_small < 20.0:
-    t0 = time.time()
-    ora.step(omodel.synthetic_batch(1, 512, 1024, seed=2))
-    secs = time.time() - t0
-    sample = '1 step, batch 1, 1024x512, fp32 torch-CPU oracle (after one 512x256 step)'
-  return dict(value=round(1.0 / secs, 5), unit='images/sec', cores=cores, kind='port', sample=sample)
+
+  def timed(h, w, warm, steps, seed):
+    for i in range(warm):
+      ora.step(omodel.synthetic_batch(1, h, w, seed=seed + i))
+    ts = []
+    for i in range(steps):
+      xd = omodel.synthetic_batch(1, h, w, seed=seed + warm + i)
+      t0 = time.perf_counter()
+      ora.step(xd)
+      ts.append(time.perf_counter() - t0)
+    return ts
+
+  t0 = time.perf_counter()
+  small = timed(256, 512, 1, 3, 1)
+  spent = time.perf_counter() - t0
+  med = sorted(small)[1]
+  value, sample = 1.0 / med, '1 warm-up + 3 timed steps (median %.2f s), batch 1, 512x256, fp32 torch-CPU oracle' % med
+  if spent + 4 * 4.2 * med <= budget_s:       # warm-up + 3 steps at 4x the pixels
+    big = timed(512, 1024, 1, 3, 11)
+    med = sorted(big)[1]
+    value = 1.0 / med
+    sample = ('1 warm-up + 3 timed steps (median %.2f s), batch 1, 1024x512, fp32 torch-CPU oracle '
+              '(after 4 steps at 512x256)' % med)
+  return dict(value=round(value, 5), unit='images/sec', cores=cores, kind='port', sample=sample)
+
+
+def self_launch(args):
+  """`python bench.py --gpus N` (N > 1) without a launcher: start `torch.distributed.run` with N ranks as a CHILD process
+  and relay its output.  Nothing in this process has touched the GPU at this point (argparse and `import torch` only;
+  `torch.cuda.device_count()` does not initialise HIP on this image), and it never execs."""
+  import socket
+  import subprocess
+  port = args.master_port
+  if port == 0:
+    with socket.socket() as sk:
+      sk.bind(('127.0.0.1', 0))
+      port = sk.getsockname()[1]
+  ndev = torch.cuda.device_count()
+  if ndev < args.gpus and not args.share_gpu:
+    sys.stderr.write('bench.py: --gpus %d but %d GPU(s) visible (rehearse with --backend gloo --share-gpu)\n' % (args.gpus, ndev))
+    return 2
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this pool (RCCL across processes)
+  env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+  sys.stdout.write(proc.stdout)
+  sys.stdout.flush()
+  return proc.returncode
 
 
 def main():
   args = parse()
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    sys.exit(self_launch(args))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    sys.stderr.write('bench.py: WORLD_SIZE=%d but --gpus %d (launch with --nproc-per-node %d)\n' % (world, args.gpus, args.gpus))
+    sys.exit(2)
+  dev_index = 0
   if world > 1:
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world,
-                            device_id=torch.device('cuda', local_rank))
+    dev_index = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    if args.backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev_index))
+    else:
+      dist.init_process_group('gloo', rank=rank, world_size=world)
   else:
     torch.cuda.set_device(0)
-  assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-  dev_index = local_rank if world > 1 else 0
   dev = torch.device('cuda', dev_index)
 
   import jpdse_hip
@@ -186,6 +248,7 @@ def main():
                                'Adam x2, batch %d/GPU' % (args.width, args.height, args.netG, opt.ngf,
                                                           '' if args.no_vgg else 'VGG19+', args.batch),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                   'grad_reduce': ('bf16' if args.bf16_reduce else 'fp32') if world > 1 else None,
                    'step_mfma_frac': (round(f_alg * value / 1e3 / peak, 4) if f_alg else None),
                    'f_alg_gflop_per_image': f_alg},
         'roofline': roof,

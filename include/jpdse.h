@@ -211,6 +211,9 @@ int jpdse_concat_channels(int32_t dtype, int64_t npix, const void* base, int32_t
                           int32_t img_cs, int32_t c0, int32_t nch, void* out, void* stream);
 /* fill n elements with zero */
 int jpdse_zero(int32_t dtype, int64_t n, void* p, void* stream);
+/* dst = (dst_dtype) src, fp32 <-> bf16, n a multiple of 8: the gradient buckets of the optional bf16 all-reduce
+ * (no reference counterpart: the reference has no collective, ctu/parsers/base_parser.py:234-237) */
+int jpdse_cast(int32_t src_dtype, int32_t dst_dtype, int64_t n, const void* src, void* dst, void* stream);
 
 /* ---- API-boundary layout conversion ---------------------------------------------------- */
 /* fp32 NCHW (the x_dict tensors of ctu_dataset.py:124-128) -> NHWC compute dtype, C padded */
@@ -257,6 +260,16 @@ int jpdse_mse_const_fwd(int32_t dtype, int64_t npix, int32_t cs, float target, c
                         float* out, void* ws, size_t ws_bytes, void* stream);
 int jpdse_mse_const_bwd(int32_t dtype, int64_t npix, int32_t cs, float target, const void* x,
                         const float* gout, float scale, void* dx, void* stream);
+
+/* Evaluation distortion on de-normalised, clipped, uint8-TRUNCATED images (ctu/utils/misc.py:64-95 `tensor2im`,
+ * pix2pixHD_model.py:636-641): q(x) = uint8(clip((x * std[c] + mean[c]) * 255, 0, 255)) evaluated in IEEE double as
+ * numpy does, then out[0] = mean |q(a) - q(b)| (mse = 0) or mean (q(a) - q(b))^2 (mse = 1) over npix * C elements,
+ * on the 0..255 scale.  a, b: NHWC images with CPAD(C) storage channels, each fp32 or bf16; mean / std: HOST arrays
+ * of C doubles (opt.normalize_mean / opt.normalize_std).  Replaces two device->host copies + numpy per call. */
+size_t jpdse_quant_loss_workspace_size(void);
+int jpdse_quant_loss(int32_t dtype_a, int32_t dtype_b, int64_t npix, int32_t C, const void* a, const void* b,
+                     const double* mean, const double* std, int32_t mse, float* out, void* ws, size_t ws_bytes,
+                     void* stream);
 
 /* ---- optimizer ---------------------------------------------------------------------- */
 /* torch.optim.Adam (model.py:275,279) over a table of tensors, one launch.  `table` is a

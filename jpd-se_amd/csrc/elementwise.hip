@@ -482,6 +482,70 @@ __global__ __launch_bounds__(256) void adam_kernel(const jpdse_adam_entry* __res
   }
 }
 
+// ---- fp32 <-> bf16 streams (gradient buckets of the bf16 all-reduce option) ---------------------
+// 8 elements per lane: 32 B of fp32 <-> 16 B of bf16
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long total8) {
+  GRID_STRIDE(idx, total8) {
+    float v[8];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + idx * 8), b = *reinterpret_cast<const f32x4*>(src + idx * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    Vec16<bf16_t>::store(dst + idx * 8, v);
+  }
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long total8) {
+  GRID_STRIDE(idx, total8) {
+    float v[8];
+    Vec16<bf16_t>::load(src + idx * 8, v);
+    const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(dst + idx * 8) = a;
+    *reinterpret_cast<f32x4*>(dst + idx * 8 + 4) = b;
+  }
+}
+
+// ---- evaluation distortion on uint8-quantised images (ctu/utils/misc.py:64-95, pix2pixHD_model.py:636-641) ------
+// q(x) = uint8( clip( (double(x) * std[c] + mean[c]) * 255.0, 0, 255 ) )  -- numpy evaluates this in float64 (the
+// std / mean lists become float64 arrays) and astype(uint8) truncates; the same IEEE double operations, unfused, are
+// done here, so the quantised images are bit-identical.  The |qa - qb| / (qa - qb)^2 sums are integers, kept exactly
+// in double.
+struct QuantParams { double mean[8]; double std[8]; };
+__device__ __forceinline__ int quant_u8(float x, double sd, double mu) {
+  double v = __dmul_rn(__dadd_rn(__dmul_rn((double)x, sd), mu), 255.0);
+  v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+  return (int)v;           // truncation, as ndarray.astype(np.uint8) on a value in [0, 255]
+}
+template <typename TA, typename TB, int MODE>
+__global__ __launch_bounds__(256) void quant_loss_partial_kernel(const TA* __restrict__ a, const TB* __restrict__ b,
+                                                                int C, int cs, long long npix, QuantParams qp,
+                                                                double* __restrict__ partial) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  GRID_STRIDE(p, npix) {
+    for (int c = 0; c < C; ++c) {
+      const int qa = quant_u8(ElemOps<TA>::ld(a + p * cs + c), qp.std[c], qp.mean[c]);
+      const int qb = quant_u8(ElemOps<TB>::ld(b + p * cs + c), qp.std[c], qp.mean[c]);
+      const int d = qa - qb;
+      acc += (MODE == RED_L1) ? (double)(d < 0 ? -d : d) : (double)(d * d);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void quant_loss_final_kernel(const double* __restrict__ partial, int n, double inv_count,
+                                                              float* __restrict__ out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * inv_count);
+}
+
 static int bad_dtype(int dtype) { return !(dtype == JPDSE_F32 || dtype == JPDSE_BF16); }
 
 #define DISPATCH(dtype, KERNEL, grid, s, ...)                                                    \
@@ -832,6 +896,62 @@ int jpdse_adam_step(const jpdse_adam_entry* table, int32_t n_entries, int64_t to
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), table, n_entries,
                      (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
   return check_launch("adam_step");
+}
+
+int jpdse_cast(int32_t src_dtype, int32_t dst_dtype, int64_t n, const void* src, void* dst, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(src_dtype) && !bad_dtype(dst_dtype) && src_dtype != dst_dtype, "cast: fp32 <-> bf16 only");
+  JPDSE_REQUIRE(src && dst && n > 0 && n % 8 == 0, "cast: n=%lld must be a positive multiple of 8", (long long)n);
+  const long long t8 = n / 8;
+  if (src_dtype == JPDSE_F32)
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_blocks(t8)), dim3(256), 0, as_stream(stream), cptr<float>(src),
+                       mptr<bf16_t>(dst), t8);
+  else
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_blocks(t8)), dim3(256), 0, as_stream(stream), cptr<bf16_t>(src),
+                       mptr<float>(dst), t8);
+  return check_launch("cast");
+}
+
+size_t jpdse_quant_loss_workspace_size(void) { return kRedBlocks * sizeof(double); }
+
+}  // extern "C"
+
+template <typename TA, typename TB>
+static int quant_loss_launch(int mse, const void* a, const void* b, int C, int cs, long long npix, const QuantParams& qp,
+                             double* partial, int grid, hipStream_t s) {
+  if (mse)
+    hipLaunchKernelGGL((quant_loss_partial_kernel<TA, TB, RED_MSE>), dim3(grid), dim3(256), 0, s, cptr<TA>(a), cptr<TB>(b),
+                       C, cs, npix, qp, partial);
+  else
+    hipLaunchKernelGGL((quant_loss_partial_kernel<TA, TB, RED_L1>), dim3(grid), dim3(256), 0, s, cptr<TA>(a), cptr<TB>(b),
+                       C, cs, npix, qp, partial);
+  return check_launch("quant_loss");
+}
+
+extern "C" {
+
+int jpdse_quant_loss(int32_t dtype_a, int32_t dtype_b, int64_t npix, int32_t C, const void* a, const void* b,
+                     const double* mean, const double* std, int32_t mse, float* out, void* ws, size_t ws_bytes,
+                     void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype_a) && !bad_dtype(dtype_b) && a && b && out && mean && std && npix > 0,
+                "quant_loss: bad argument");
+  JPDSE_REQUIRE(C >= 1 && C <= 8, "quant_loss: %d channels (1..8 supported)", C);
+  if (ws == nullptr || ws_bytes < kRedBlocks * sizeof(double))
+    return set_error(JPDSE_EWORKSPACE, "quant_loss: workspace too small");
+  QuantParams qp = {};
+  for (int c = 0; c < C; ++c) { qp.mean[c] = mean[c]; qp.std[c] = std[c]; }
+  int grid = ew_blocks(npix);
+  if (grid > kRedBlocks) grid = kRedBlocks;
+  double* partial = reinterpret_cast<double*>(ws);
+  hipStream_t s = as_stream(stream);
+  const int cs = cpad(C);
+  int rc;
+  if (dtype_a == JPDSE_BF16 && dtype_b == JPDSE_BF16) rc = quant_loss_launch<bf16_t, bf16_t>(mse, a, b, C, cs, npix, qp, partial, grid, s);
+  else if (dtype_a == JPDSE_BF16) rc = quant_loss_launch<bf16_t, float>(mse, a, b, C, cs, npix, qp, partial, grid, s);
+  else if (dtype_b == JPDSE_BF16) rc = quant_loss_launch<float, bf16_t>(mse, a, b, C, cs, npix, qp, partial, grid, s);
+  else rc = quant_loss_launch<float, float>(mse, a, b, C, cs, npix, qp, partial, grid, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(quant_loss_final_kernel, dim3(1), dim3(256), 0, s, partial, grid, 1.0 / ((double)npix * C), out);
+  return check_launch("quant_loss");
 }
 
 }  // extern "C"

@@ -17,9 +17,7 @@ Only the flag subset used by scripts/pix2pixHD_bpg_train.sh is accelerated; othe
 raise NotImplementedError.
 """
 import os
-import subprocess
 
-import numpy as np
 import torch
 
 from jpdse_hip import F32, BF16, JpdseError, require_gpu
@@ -28,7 +26,6 @@ from jpdse_hip.ops import Act
 from jpdse_hip.optim import FusedAdam
 from jpdse_hip.layers import PackBatcher
 from ctu.utils.image_pool import ImagePool
-from ctu.utils.misc import tensor2im
 from ctu.models.pix2pixHD_networks.base_model import BaseModel
 from ctu.models.pix2pixHD_networks import networks
 
@@ -39,8 +36,11 @@ class Pix2PixHDModel(BaseModel):
 
   @staticmethod
   def modify_commandline_options(parser, train):
-    """Same flag names/defaults as the reference setter (pix2pixHD_model.py:21-102) for the
-    options the hot path reads, plus --compute_dtype."""
+    """Every flag of the reference setter (pix2pixHD_model.py:21-102) with the same name, type, default and choices
+    (pinned by tests/golden/option_setter_flags.json, dumped from the reference), so that a reference command line or
+    opt.pkl parses unchanged; flags of branches outside the accelerated path are accepted here and refused in
+    __init__ when they would change the computation.  Extensions: --compute_dtype, --skip_unused_losses,
+    --vgg19_state_dict, --vgg_random_init."""
     a = parser.add_argument
     a('--num_D', type=int, default=2)
     a('--n_layers_D', type=int, default=3)
@@ -90,6 +90,28 @@ class Pix2PixHDModel(BaseModel):
     a('--bin_generator_before_res', action='store_true')
     a('--generator_binarizer_out_channels', type=int, default=128)
     a('--use_netE_output', action='store_true')
+    # learned-codec / masking branches: parsed for command-line compatibility only
+    a('--binary_mask', action='store_true')
+    a('--netE_groups', type=int, default=1)
+    a('--inst_wise_pool', action='store_true')
+    a('--use_dropout', action='store_true',
+      help='declared by the reference but never read there (ResnetBlock is always built without dropout)')
+    a('--feat_num', type=int, default=3)
+    a('--n_downsample_E', type=int, default=4)
+    a('--nef', type=int, default=64)
+    a('--label_encoder_out_channels', type=int, default=36)
+    a('--n_downsample_E4label', type=int, default=4)
+    a('--ne4lf', type=int, default=64)
+    a('--no_encoder_binarization', action='store_true')
+    a('--encoder_binarizer_out_channels', type=int, default=128)
+    a('--no_label_encoder_binarization', action='store_true')
+    a('--label_encoder_binarizer_out_channels', type=int, default=128)
+    a('--vgg19_state_dict', type=str, default=None,
+      help='extension: local torchvision-format vgg19 state_dict (keys features.<i>.weight/bias) for the VGG loss; the '
+           'reference downloads models.vgg19(pretrained=True) (networks.py:477), which needs network access')
+    a('--vgg_random_init', action='store_true',
+      help='extension: explicitly accept a seeded random-weight VGG19 for the VGG loss (tests, benchmarks); without '
+           'this flag training with the VGG loss and no --vgg19_state_dict is refused')
     return parser
 
   # ------------------------------------------------------------------------------------------
@@ -102,7 +124,7 @@ class Pix2PixHDModel(BaseModel):
     if not g('no_generator_binarization'):
       unsupported.append('generator binarization (run with --no_generator_binarization)')
     for flag in ('sem_masking', 'no_label', 'no_feat', 'match_raw_feat', 'no_lsgan', 'use_netE_output',
-                 'zero_sem', 'zero_ins', 'zero_vis'):
+                 'zero_sem', 'zero_ins', 'zero_vis', 'binary_mask', 'inst_wise_pool'):
       if g(flag):
         unsupported.append('--' + flag)
     if g('norm', 'instance') != 'instance':
@@ -140,9 +162,16 @@ class Pix2PixHDModel(BaseModel):
       self.fake_pool = ImagePool(opt.pool_size)
       self.criterionGAN = networks.GANLoss(use_lsgan=True)
       self.criterionVGG = networks.VGGLoss(self.gpu_ids, compute_dtype=cd)
+      # The reference always optimises against ImageNet VGG19 features (networks.py:477).  A random-weight VGG is a
+      # different objective, so it must be asked for by name; it is what tests and bench.py use (same FLOPs / bytes).
       vgg_path = g('vgg19_state_dict', None)
+      vgg_needed = not (g('no_vgg_loss') and g('skip_unused_losses'))
       if vgg_path:
         self.criterionVGG.vgg.load_torchvision_state_dict(torch.load(vgg_path, map_location='cpu'))
+      elif vgg_needed and not g('no_vgg_loss') and not g('vgg_random_init'):
+        raise ValueError('the VGG loss needs ImageNet weights: pass --vgg19_state_dict <torchvision vgg19 state_dict> '
+                         '(the reference downloads them, networks.py:477), or --vgg_random_init to accept a seeded '
+                         'random-weight VGG19 (tests / benchmarks only), or --no_vgg_loss')
       self.loss_names = LOSS_NAMES
     else:
       self.loss_names = ('G_Distortion')
@@ -177,6 +206,12 @@ class Pix2PixHDModel(BaseModel):
     if opt.niter_fix_global > 0:
       prefix = 'model' + str(opt.n_local_enhancers)
       params = [p for k, p in self.netG.named_parameters() if k.startswith(prefix)]
+      # the reference leaves requires_grad on and lets autograd compute gradients nobody applies; here the fixed
+      # parameters are frozen, so their weight gradients -- and the whole backward of the coarse generator, which
+      # only leads to frozen weights -- are not computed at all (LocalEnhancer.bwd)
+      keep = {id(p) for p in params}
+      for p in self.netG.parameters():
+        p.requires_grad_(id(p) in keep)
       print('------------- only training the local enhancer network (for %d epochs) ------------'
             % opt.niter_fix_global)
     else:
@@ -193,37 +228,16 @@ class Pix2PixHDModel(BaseModel):
   def converter(filename, ext, quality):
     """Round-trip `filename` through an outside codec, return the path of the decoded image
     (pix2pixHD_model.py:287-321).  BPG shells out to bpgenc/bpgdec when they are installed."""
-    from PIL import Image
-    stem = os.path.splitext(filename)[0]
-    out = stem + '.' + ext
-    if ext in ('jpg', 'webp'):
-      Image.open(filename).save(out, quality=quality)
-      return out
-    if ext == 'j2k':
-      Image.open(filename).save(out, quality_mode='rates', quality_layers=[quality])
-      return out
-    if ext == 'bpg':
-      decoded = stem + '_decoded_from_bpg.png'
-      subprocess.run(['bpgenc', '-q', str(quality), '-o', out, filename], check=True)
-      subprocess.run(['bpgdec', '-o', decoded, out], check=True)
-      return decoded
-    raise ValueError('format must be one of jpg, webp, j2k, or bpg')
+    from ctu.utils import codec
+    return codec.converter(filename, ext, quality)
 
-  def compress(self, x_dict, tmp_folder):
-    """Decoded frame(s) of x_dict['image'] after the codec, normalised like the input
-    (pix2pixHD_model.py:324-359); unlike the reference this loops over the batch."""
-    from PIL import Image
-    imgs = tensor2im(x_dict['image'], self.opt)
-    mean = torch.tensor(self.opt.normalize_mean, dtype=torch.float32)[:, None, None]
-    std = torch.tensor(self.opt.normalize_std, dtype=torch.float32)[:, None, None]
-    out = []
-    for b in range(imgs.shape[0]):
-      name = os.path.join(tmp_folder, 'tmp_image_%d.png' % b)
-      Image.fromarray(imgs[b]).save(name)
-      decoded = np.asarray(Image.open(self.converter(name, self.opt.ext, self.opt.quality[0])).convert('RGB'))
-      t = torch.from_numpy(decoded.astype(np.float32) / 255.0).permute(2, 0, 1)
-      out.append((t - mean) / std)
-    return torch.stack(out, 0)
+  def compress(self, x_dict, tmp_folder=None):
+    """Decoded frame(s) of x_dict['image'] after the codec, normalised like the input (pix2pixHD_model.py:324-359).
+    Synchronous fallback for batches that arrive without 'compressed_img'; unlike the reference it handles any batch
+    size and never shares file names between processes (ctu.utils.codec).  The prefetched form is
+    ctu.utils.codec.CodecCollate in the DataLoader."""
+    from ctu.utils import codec
+    return codec.compress_images(x_dict['image'], self.opt, tmp_folder)
 
   # ---- input builder ------------------------------------------------------------------------
   def preprocess(self, x_dict):
@@ -236,9 +250,7 @@ class Pix2PixHDModel(BaseModel):
     if opt.use_compressed:
       comp = x_dict.get('compressed_img')
       if comp is None:
-        tmp_dir = os.path.join(opt.save_dir, 'tmp_imgs')
-        os.makedirs(tmp_dir, exist_ok=True)
-        comp = self.compress(x_dict, tmp_dir)
+        comp = self.compress(x_dict, os.path.join(opt.save_dir, 'tmp_imgs'))   # a private sub-directory per process
     label = x_dict['label'].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
     inst = x_dict['instance'].to(dev, dtype=torch.int64, non_blocking=True).contiguous()
     image = x_dict['image'].to(dev, dtype=torch.float32, non_blocking=True).contiguous()
@@ -265,16 +277,17 @@ class Pix2PixHDModel(BaseModel):
       return ops.nhwc_to_nchw(fake)
 
   def get_eval_loss(self, x_dict):
-    """Distortion on de-normalised, clipped, uint8-truncated images (0..255 scale), as the
-    reference does on the host (pix2pixHD_model.py:636-641)."""
-    recon = self.get_img(x_dict)
-    a = torch.tensor(tensor2im(recon, self.opt).transpose(0, 3, 1, 2)).to(torch.float)
-    b = torch.tensor(tensor2im(x_dict['image'], self.opt).transpose(0, 3, 1, 2)).to(torch.float)
-    dev = self._device()
-    A, Bm = ops.nchw_to_nhwc(a.to(dev).contiguous(), F32), ops.nchw_to_nhwc(b.to(dev).contiguous(), F32)
-    slot = torch.zeros(1, dtype=torch.float32, device=dev)
-    (ops.l1_fwd if self.opt.distortion_loss_fn == 'l1' else ops.mse_fwd)(A, Bm, slot)
-    return slot[0]
+    """Distortion on de-normalised, clipped, uint8-truncated images (0..255 scale), as the reference computes it on
+    the host through tensor2im (pix2pixHD_model.py:636-641, utils/misc.py:64-95) -- here one device pass
+    (jpdse_quant_loss: the same float64 arithmetic, bit-identical quantisation, no device->host image copies)."""
+    with torch.no_grad():
+      pre = self.preprocess(x_dict)
+      fake, _ = self.netG.fwd(self._with_image(pre['base'], pre['src']))
+      real32 = ops.nchw_to_nhwc(pre['image_nchw'], F32)       # the original image un-rounded, as the reference uses it
+      slot = torch.zeros(1, dtype=torch.float32, device=self._device())
+      ops.quant_loss(fake, real32, self.opt.normalize_mean, self.opt.normalize_std,
+                     self.opt.distortion_loss_fn == 'mse', slot)
+      return slot[0]
 
   # ---- training -------------------------------------------------------------------------------
   def _forward_losses(self, x_dict, grad_w=None):
@@ -465,8 +478,13 @@ class Pix2PixHDModel(BaseModel):
     self.save_network(self.netD, 'D', self.opt)
 
   def update_fixed_params(self, optimizer_G):
-    """After niter_fix_global epochs also fine-tune the coarse generator (model.py:795-804)."""
+    """After niter_fix_global epochs also fine-tune the coarse generator (model.py:795-804): a fresh Adam over ALL
+    generator parameters (beta2 hard-wired to 0.999 as in the reference), carrying the old optimizer's gradient scale.
+    Under data parallelism call Pix2PixHDTrainer.update_fixed_params, which also re-buckets the gradients."""
+    for p in self.netG.parameters():
+      p.requires_grad_(True)
     for m in self.netG.modules():
       if hasattr(m, 'ensure_grads'):
         m.ensure_grads()
-    return FusedAdam(list(self.netG.parameters()), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
+    return FusedAdam(list(self.netG.parameters()), lr=self.opt.lr, betas=(self.opt.beta1, 0.999),
+                     grad_scale=getattr(optimizer_G, 'grad_scale', 1.0))

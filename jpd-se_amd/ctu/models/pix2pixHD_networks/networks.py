@@ -189,7 +189,8 @@ class LocalEnhancer(nn.Module):
       dh = run_chain_bwd(self._up[n], uctx, dy, True, need_dw)
       run_chain_bwd(self._down[n], dctx, dh, False, need_dw)
       dy = dh                       # the sum feeds both branches
-    run_chain_bwd(self._core, core_ctx, dy, False, need_dw)
+    if any(p.requires_grad for p in self.model.parameters()):     # frozen during the niter_fix_global phase
+      run_chain_bwd(self._core, core_ctx, dy, False, need_dw)
     return None
 
   def forward(self, input):

@@ -31,13 +31,16 @@ class Pix2PixHDTrainer(BaseTrainer):
         self.scheduler_D = ReduceLROnPlateau(self.optimizer_D, 'min', factor=opt.lr_decay_factor,
                                              patience=opt.lr_decay_patience)
       self.lambda_distortion_weight = 1.
+      self._dp = None
       if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        self.enable_data_parallel()
+        self.enable_data_parallel(reduce_dtype=torch.bfloat16 if getattr(opt, 'bf16_grad_reduce', False) else None)
 
   # ---- data parallelism (no reference counterpart: base_parser.py:234-237 refuses >1 GPU) ----
-  def enable_data_parallel(self, bucket_bytes=64 << 20, process_group=None):
-    """Replicate-and-average: broadcast rank 0's weights once, re-home every gradient into flat
-    all-reduce buckets, and let Adam divide by the world size."""
+  def enable_data_parallel(self, bucket_bytes=64 << 20, process_group=None, reduce_dtype=None):
+    """Replicate-and-average: broadcast rank 0's weights once, re-home every gradient into flat all-reduce buckets, and
+    let Adam divide by the world size.  Runs for any initialised process group, world size 1 included (the RCCL
+    calls are then no-ops in value, which is how the path is exercised on a one-GPU box).  reduce_dtype
+    torch.bfloat16 halves the bytes on the wire (SURVEY.md 8d config 4 reports both)."""
     world = dist.get_world_size(process_group)
     for net in (self.model.netG, self.model.netD):
       for p in net.parameters():
@@ -46,15 +49,35 @@ class Pix2PixHDTrainer(BaseTrainer):
         assert dense.is_contiguous()
         dist.broadcast(dense, src=0, group=process_group)
     bump_weights_epoch()
-    for tag, net, optim in (('G', self.model.netG, self.optimizer_G), ('D', self.model.netD, self.optimizer_D)):
-      trained = {id(p) for grp in optim.param_groups for p in grp['params']}
-      named = [(n, p) for n, p in net.named_parameters() if id(p) in trained]
-      buckets = GradBuckets(named, bucket_bytes=bucket_bytes, process_group=process_group)
-      self.model.grad_buckets[tag] = buckets
-      optim.grad_scale = 1.0 / world
-      for m in net.modules():
-        if isinstance(m, HipConv2d):
-          m.grad_ready_hook = (lambda mod, b=buckets: (b.mark_ready(mod.weight), b.mark_ready(mod.bias)))
+    self._dp = dict(bucket_bytes=bucket_bytes, process_group=process_group, reduce_dtype=reduce_dtype, world=world)
+    self._rebuild_buckets('G', self.model.netG, self.optimizer_G)
+    self._rebuild_buckets('D', self.model.netD, self.optimizer_D)
+
+  def _rebuild_buckets(self, tag, net, optim):
+    """(Re)create the gradient buckets of one network over the parameters its optimizer trains, fold 1/world into the
+    optimizer and point every conv's gradient-ready hook at the new buckets."""
+    dp = self._dp
+    trained = {id(p) for grp in optim.param_groups for p in grp['params']}
+    named = [(n, p) for n, p in net.named_parameters() if id(p) in trained]
+    buckets = GradBuckets(named, bucket_bytes=dp['bucket_bytes'], process_group=dp['process_group'],
+                          reduce_dtype=dp['reduce_dtype'], always_reduce=True)
+    self.model.grad_buckets[tag] = buckets
+    optim.grad_scale = 1.0 / dp['world']
+    for m in net.modules():
+      if isinstance(m, HipConv2d):
+        m.grad_ready_hook = (lambda mod, b=buckets: (b.mark_ready(mod.weight), b.mark_ready(mod.bias)))
+
+  def update_fixed_params(self):
+    """End of the `niter_fix_global` phase (train.py calls model.update_fixed_params and swaps the optimizer,
+    pix2pixHD_model.py:795-804): from now on the coarse generator trains too.  The trainer owns the transition so
+    that, under data parallelism, the new parameters get gradient buckets, hooks and the 1/world scale as well."""
+    self.optimizer_G = self.model.update_fixed_params(self.optimizer_G)
+    if getattr(self, '_dp', None) is not None:
+      self._rebuild_buckets('G', self.model.netG, self.optimizer_G)
+    if getattr(self.opt, 'schedule_lr', False):
+      self.scheduler_G = ReduceLROnPlateau(self.optimizer_G, 'min', factor=self.opt.lr_decay_factor,
+                                           patience=self.opt.lr_decay_patience)
+    return self.optimizer_G
 
   def scheduler_step(self, val_loss_value):
     self.scheduler_G.step(val_loss_value)
@@ -89,46 +112,54 @@ class Pix2PixHDTrainer(BaseTrainer):
     self.eval()
     return self.model(x_dict, self.opt, mode='get_img')
 
-  # ---- checkpoints (stats_and_optim.pt + net_{G,D}.pth: pix2pixHD_trainer.py:119-176) --------
+  # ---- checkpoints ------------------------------------------------------------------------------
+  # File contract of the reference (pix2pixHD_trainer.py:119-176, base_model.py:54-59): <save_dir>/net_G.pth,
+  # net_D.pth (state dicts) and stats_and_optim.pt with the keys below.  Optional entries are written / read only when
+  # their feature is on, and a checkpoint without them still loads.
+  _OPTIONAL_STATE = (('scheduler_G_state_dict', 'schedule_lr'), ('scheduler_D_state_dict', 'schedule_lr'),
+                     ('lambda_distortion_weight', 'anneal_lambda'))
+
+  def _is_writer(self):
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
   def save(self, epoch, val_loss_value):
+    """Rank 0 writes (replicas are identical); the other ranks wait at a barrier so that nobody races ahead and
+    reads a half-written checkpoint."""
     self.best_val_loss = val_loss_value
-    os.makedirs(self.opt.save_dir, exist_ok=True)
-    print('\nsaving checkpoints to {}...\n'.format(self.opt.save_dir))
-    states = {'epoch': epoch, 'steps_taken': self.steps_taken,
-              'optimizer_G_state_dict': self.optimizer_G.state_dict(),
-              'optimizer_D_state_dict': self.optimizer_D.state_dict(),
-              'best_val_loss': self.best_val_loss}
-    if getattr(self.opt, 'schedule_lr', False):
-      states['scheduler_G_state_dict'] = self.scheduler_G.state_dict()
-      states['scheduler_D_state_dict'] = self.scheduler_D.state_dict()
-    if self.opt.anneal_lambda:
-      states['lambda_distortion_weight'] = self.lambda_distortion_weight
-    torch.save(states, os.path.join(self.opt.save_dir, 'stats_and_optim.pt'))
-    self.model.save()
-    print('\ncheckpoint saved!\n')
+    if self._is_writer():
+      os.makedirs(self.opt.save_dir, exist_ok=True)
+      print('\nwriting checkpoint (epoch %d) to %s\n' % (epoch, self.opt.save_dir))
+      record = dict(epoch=epoch, steps_taken=self.steps_taken, best_val_loss=self.best_val_loss,
+                    optimizer_G_state_dict=self.optimizer_G.state_dict(),
+                    optimizer_D_state_dict=self.optimizer_D.state_dict())
+      for key, flag in self._OPTIONAL_STATE:
+        if getattr(self.opt, flag, False):
+          src = getattr(self, key[:-len('_state_dict')], None) if key.endswith('_state_dict') else getattr(self, key)
+          record[key] = src.state_dict() if key.endswith('_state_dict') else src
+      torch.save(record, os.path.join(self.opt.save_dir, 'stats_and_optim.pt'))
+      self.model.save()
+    if dist.is_available() and dist.is_initialized():
+      dist.barrier()
 
   def load(self):
-    print('\nloading checkpoints from {}...\n'.format(self.opt.checkpoints_dir))
     path = os.path.join(self.opt.checkpoints_dir, 'stats_and_optim.pt')
     where = 'cuda:' + str(self.opt.gpu_ids[0]) if self.model.use_gpu() else 'cpu'
-    saved = torch.load(path, map_location=where)
-    if self.mode == 'train':
-      self.optimizer_G.load_state_dict(saved['optimizer_G_state_dict'])
-      self.optimizer_D.load_state_dict(saved['optimizer_D_state_dict'])
-      if getattr(self.opt, 'schedule_lr', False):
-        if 'scheduler_G_state_dict' in saved:
-          self.scheduler_G.load_state_dict(saved['scheduler_G_state_dict'])
-          self.scheduler_D.load_state_dict(saved['scheduler_D_state_dict'])
-        else:
-          print('Did not find scheduler state dicts from checkpoint. Not loading them...')
-      self.best_val_loss = saved['best_val_loss']
-      self.steps_taken = saved['steps_taken']
-      if self.opt.anneal_lambda:
-        if 'lambda_distortion_weight' in saved:
-          self.lambda_distortion_weight = saved['lambda_distortion_weight']
-        else:
-          print('Did not find lambda distortion weight from checkpoint. Not loading it...')
-      self.start_epoch = saved['epoch'] + 1
-      print('\ncurrent best val loss: {:.4f}\n'.format(self.best_val_loss))
-      print('\nnow starting from epoch {}...\n'.format(self.start_epoch + 1))
-    print('\ncheckpoint loaded!\n')
+    record = torch.load(path, map_location=where)
+    if self.mode != 'train':
+      return
+    self.optimizer_G.load_state_dict(record['optimizer_G_state_dict'])
+    self.optimizer_D.load_state_dict(record['optimizer_D_state_dict'])
+    for key, flag in self._OPTIONAL_STATE:
+      if not getattr(self.opt, flag, False):
+        continue
+      if key not in record:
+        print('checkpoint has no %s: keeping the fresh one' % key)
+      elif key.endswith('_state_dict'):
+        getattr(self, key[:-len('_state_dict')]).load_state_dict(record[key])
+      else:
+        setattr(self, key, record[key])
+    self.best_val_loss = record['best_val_loss']
+    self.steps_taken = record['steps_taken']
+    self.start_epoch = record['epoch'] + 1
+    print('\nresumed %s: best val loss %.4f, continuing with epoch %d\n'
+          % (path, self.best_val_loss, self.start_epoch + 1))

@@ -87,6 +87,10 @@ SIGNATURES = {
     'jpdse_channel_copy': (_I32, [_I32, _I64, _P, _I32, _I32, _P, _I32, _I32, _I32, _P]),
     'jpdse_concat_channels': (_I32, [_I32, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _P]),
     'jpdse_zero': (_I32, [_I32, _I64, _P, _P]),
+    'jpdse_cast': (_I32, [_I32, _I32, _I64, _P, _P, _P]),
+    'jpdse_quant_loss_workspace_size': (_SZ, []),
+    'jpdse_quant_loss': (_I32, [_I32, _I32, _I64, _I32, _P, _P, ctypes.POINTER(ctypes.c_double),
+                                ctypes.POINTER(ctypes.c_double), _I32, _P, _P, _SZ, _P]),
     'jpdse_nchw_to_nhwc': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     'jpdse_nhwc_to_nchw': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     'jpdse_onehot_edge': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),

@@ -19,9 +19,14 @@ import torch.distributed as dist
 
 class GradBuckets(object):
 
-  def __init__(self, named_params, bucket_bytes=64 << 20, process_group=None, reverse=True):
-    """named_params: iterable of (name, param) in FORWARD order."""
+  def __init__(self, named_params, bucket_bytes=64 << 20, process_group=None, reverse=True, reduce_dtype=None,
+               always_reduce=False):
+    """named_params: iterable of (name, param) in FORWARD order.  reduce_dtype=torch.bfloat16: the bucket is cast
+    to a bf16 wire buffer before the all-reduce and back afterwards (half the xGMI bytes; the sum then carries bf16
+    rounding).  always_reduce: issue the collective even at world size 1 (exercises the RCCL path on one GPU)."""
     self.group = process_group
+    self.reduce_dtype = reduce_dtype
+    self.always_reduce = always_reduce
     items = [(n, p) for n, p in named_params if p.requires_grad]
     if reverse:
       items = items[::-1]
@@ -46,6 +51,7 @@ class GradBuckets(object):
   def _make_bucket(items):
     dev, dt = items[0][1].device, items[0][1].dtype    # fp32 masters on the GPU (fp64 in CPU tests)
     total = sum(((p.numel() + 3) // 4) * 4 for _, p in items)   # keep every view >= 16-byte aligned
+    total = (total + 7) // 8 * 8                                # whole 16-byte bf16 vectors for the wire copy
     flat = torch.zeros(total, dtype=dt, device=dev)
     params, off = [], 0
     for n, p in items:
@@ -56,7 +62,7 @@ class GradBuckets(object):
       p.grad = view
       params.append((n, p, off, numel))
       off += ((numel + 3) // 4) * 4
-    return dict(flat=flat, params=params, pending=len(params), handle=None)
+    return dict(flat=flat, params=params, pending=len(params), handle=None, wire=None)
 
   def reset(self):
     for b in self.buckets:
@@ -76,19 +82,39 @@ class GradBuckets(object):
     if b['pending'] == 0:
       self._launch(b)
 
+  def _active(self):
+    return dist.is_available() and dist.is_initialized() and (self.world_size() > 1 or self.always_reduce)
+
+  @staticmethod
+  def _convert(src, dst):
+    if src.is_cuda:
+      from . import ops
+      ops.cast_(src, dst)          # HIP kernel on the current stream (the one the gradients were written on)
+    else:
+      dst.copy_(src)               # CPU rehearsal (gloo tests)
+
   def _launch(self, b):
-    if self.world_size() > 1 and b['handle'] is None:
-      b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    if not self._active() or b['handle'] is not None:
+      return
+    buf = b['flat']
+    if self.reduce_dtype is not None and self.reduce_dtype != buf.dtype:
+      if b['wire'] is None:
+        b['wire'] = torch.empty(buf.numel(), dtype=self.reduce_dtype, device=buf.device)
+      self._convert(buf, b['wire'])
+      buf = b['wire']
+    b['handle'] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
   def finish(self):
     """Launch whatever has not been launched (parameters without a gradient this step) and make
     the current stream wait for every bucket; no host synchronisation with RCCL."""
     for b in self.buckets:
-      if b['handle'] is None and self.world_size() > 1:
+      if b['handle'] is None:
         self._launch(b)
     for b in self.buckets:
       if b['handle'] is not None:
         b['handle'].wait()
+        if b['wire'] is not None:
+          self._convert(b['wire'], b['flat'])
     self.reset()
 
   def total_bytes(self):

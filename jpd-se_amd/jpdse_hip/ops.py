@@ -60,12 +60,16 @@ class Act(object):
     return Act(torch.empty_like(self.t), self.C)
 
 
-# ---- shared workspace (all ops are enqueued on one stream, so one arena suffices) ------------
+# ---- shared workspace --------------------------------------------------------------------------
+# One scratch arena per (device, stream): ops enqueued on one stream execute in order, so they may share scratch;
+# a caller that runs a second torch stream (prefetch, eval overlap) gets its own arena instead of a silent race.
+# Growing an arena hands the old buffer back to torch's caching allocator, which keeps it stream-ordered.
 _ws = {}
 
 
 def workspace(nbytes, device):
-  key = (device.index if device.index is not None else torch.cuda.current_device())
+  index = device.index if device.index is not None else torch.cuda.current_device()
+  key = (index, torch.cuda.current_stream(index).cuda_stream)
   cur = _ws.get(key)
   if cur is None or cur.numel() < nbytes:
     nbytes = int(nbytes * 1.25) + (1 << 20)
@@ -205,6 +209,24 @@ def add_(a, b):
 def zero_(t):
   check(lib().jpdse_zero(code_of(t.dtype), t.numel(), _p(t), _stream()), 'zero')
   return t
+
+
+def cast_(src, dst):
+  """dst = src converted fp32 <-> bf16 (flat device tensors of equal numel, a multiple of 8)."""
+  assert src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous()
+  check(lib().jpdse_cast(code_of(src.dtype), code_of(dst.dtype), src.numel(), _p(src), _p(dst), _stream()), 'cast')
+  return dst
+
+
+def quant_loss(a, b, mean, std, mse, out):
+  """Distortion between the uint8-quantised de-normalised images a, b (Acts, fp32 or bf16 each) into the fp32
+  device slot `out` (0..255 scale): tensor2im + L1Loss/MSELoss of get_eval_loss, on the device."""
+  assert a.t.shape == b.t.shape and a.C == b.C and len(mean) == a.C and len(std) == a.C
+  ws = workspace(lib().jpdse_quant_loss_workspace_size(), a.t.device)
+  arr = ctypes.c_double * a.C
+  check(lib().jpdse_quant_loss(a.dtype, b.dtype, a.N * a.H * a.W, a.C, _p(a.t), _p(b.t), arr(*[float(v) for v in mean]),
+                               arr(*[float(v) for v in std]), int(bool(mse)), _p(out), _p(ws), ws.numel(), _stream()),
+        'quant_loss')
 
 
 def channel_sum(dy, out):

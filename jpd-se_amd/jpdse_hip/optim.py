@@ -29,6 +29,26 @@ class FusedAdam(torch.optim.Optimizer):
     (pix2pixHD_trainer.py:64,73)."""
     return None
 
+  def load_state_dict(self, state_dict):
+    """torch.optim.Adam checkpoints (the reference's stats_and_optim.pt, pix2pixHD_trainer.py:124-136,147-148) keep
+    exp_avg / exp_avg_sq in the memory order the REFERENCE's parameters had (NCHW-contiguous) while the masters here
+    are channels_last; torch's loader preserves the saved strides, and the fused kernel needs param / grad / state in
+    one memory order.  Re-lay every state tensor into its parameter's strides (values unchanged) and accept the int
+    `step` of old-torch checkpoints."""
+    super(FusedAdam, self).load_state_dict(state_dict)
+    for group in self.param_groups:
+      for p in group['params']:
+        st = self.state.get(p)
+        if not st:
+          continue
+        for key in ('exp_avg', 'exp_avg_sq'):
+          v = st.get(key)
+          if v is not None and (v.stride() != p.stride() or v.device != p.device or v.dtype != p.dtype):
+            st[key] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(v)
+        step = st.get('step', 0)
+        st['step'] = torch.tensor(float(step.item() if torch.is_tensor(step) else step), dtype=torch.float32)
+    self._table = {}
+
   def _ensure_state(self, p):
     st = self.state[p]
     if len(st) == 0:

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, wire='fp64'):
   for p in (ROOT, os.path.join(ROOT, 'jpd-se_amd')):
     if p not in sys.path:
       sys.path.insert(0, p)
@@ -31,12 +31,14 @@ def _worker(rank, world, port, q):
     gG, gD = ora.grads_in_dtype(shard, torch.float64)     # this rank's shard
     # parameters in channels_last like the product's, gradients re-homed into flat buckets
     params = []
+    pdt = torch.float64 if wire == 'fp64' else torch.float32
     for k, v in ora.G.items():
-      p = torch.nn.Parameter(v.detach().double().clone())
+      p = torch.nn.Parameter(v.detach().to(pdt).clone())
       if p.dim() == 4:
         p.data = p.data.contiguous(memory_format=torch.channels_last)
       params.append((k, p))
-    buckets = GradBuckets(params, bucket_bytes=64 << 10)   # small buckets: several per network
+    buckets = GradBuckets(params, bucket_bytes=64 << 10,   # small buckets: several per network
+                          reduce_dtype=torch.bfloat16 if wire == 'bf16' else None)
     assert len(buckets.buckets) > 2
     for k, p in reversed(params):                          # backward order
       p.grad.copy_(gG[k])
@@ -58,11 +60,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_average_equals_global_batch():
+@pytest.mark.parametrize('wire', ['fp64', 'bf16'])
+def test_two_rank_gradient_average_equals_global_batch(wire):
+  """wire = bf16: the optional half-width all-reduce: fp32 buckets cast to a bf16 wire buffer,
+  summed over the ranks, cast back -- the average then carries bf16 rounding (2^-8 relative per element)."""
   ctx = mp.get_context('spawn')
   q = ctx.Queue()
-  port = 29500 + (os.getpid() % 2000)
-  procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+  port = 29500 + (os.getpid() % 2000) + (17 if wire == 'bf16' else 0)
+  procs = [ctx.Process(target=_worker, args=(r, 2, port, q, wire)) for r in range(2)]
   for p in procs:
     p.start()
   status, worst, n_buckets, nbytes = q.get(timeout=600)
@@ -70,7 +75,10 @@ def test_two_rank_gradient_average_equals_global_batch():
     p.join(timeout=120)
   assert status == 'ok', worst
   assert all(p.exitcode == 0 for p in procs)
-  assert worst < 1e-9, worst       # fp64: only summation order differs
+  if wire == 'fp64':
+    assert worst < 1e-9, worst       # fp64: only summation order differs
+  else:
+    assert 1e-6 < worst < 1.5e-2, worst   # bf16 wire: rounding of each rank's contribution and of the sum
   assert n_buckets > 2 and nbytes > 0
 
 
@@ -99,3 +107,32 @@ def test_buckets_single_process_views_and_order():
     b.mark_ready(p)
   b.finish()      # world size 1: no collective, just resets the counters
   assert all(x['pending'] == len(x['params']) for x in b.buckets)
+
+
+def test_world_size_one_group_still_runs_the_collective():
+  """always_reduce (what the trainer's data-parallel mode sets): with a process group of ONE rank the buckets still go
+  through all_reduce + wait -- the way the RCCL path is exercised on a one-GPU box (tests/test_hip_ddp.py)."""
+  sys.path.insert(0, os.path.join(ROOT, 'jpd-se_amd'))
+  from jpdse_hip.ddp import GradBuckets
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29900 + os.getpid() % 90))
+  dist.init_process_group('gloo', rank=0, world_size=1)
+  try:
+    ps = [('w', torch.nn.Parameter(torch.randn(4, 3, 3, 3).contiguous(memory_format=torch.channels_last))),
+          ('b', torch.nn.Parameter(torch.randn(5)))]
+    for _, p in ps:
+      p.grad = torch.randn_like(p, memory_format=torch.preserve_format)
+    want = [p.grad.clone() for _, p in ps]
+    plain = GradBuckets(ps, bucket_bytes=1 << 20)
+    forced = GradBuckets(ps, bucket_bytes=1 << 20, always_reduce=True, reduce_dtype=torch.bfloat16)
+    for _, p in ps:
+      plain.mark_ready(p)
+    assert plain.buckets[0]['handle'] is None           # world size 1, not forced: no collective
+    plain.finish()
+    for _, p in ps:
+      forced.mark_ready(p)
+    assert forced.buckets[0]['handle'] is not None and forced.buckets[0]['wire'].dtype == torch.bfloat16
+    forced.finish()
+    for (_, p), w in zip(ps, want):
+      assert torch.equal(p.grad, w.to(torch.bfloat16).to(torch.float32))   # through the bf16 wire and back
+  finally:
+    dist.destroy_process_group()

@@ -108,14 +108,31 @@ def _torch_conv(x, w, b, st, pad, mode, act):
   return y
 
 
+def _act_grad_from_output(y, act):
+  """d act / d pre-activation as the layer computes it: from the activation OUTPUT (y > 0 <=> pre-activation > 0)."""
+  if act == ACT_RELU:
+    return (y > 0).to(y.dtype)
+  if act == ACT_LRELU:
+    return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2))
+  if act == ACT_TANH:
+    return 1.0 - y * y
+  return torch.ones_like(y)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_fwd_dgrad_wgrad(case, dtype):
+def test_conv_fwd_dgrad_wgrad(case, dtype, seed):
+  """Forward, data gradient, weight gradient and bias gradient of one layer against torch-CPU.
+
+  Robust to ReLU / LeakyReLU mask flips instead of seed-tuned (round 1 fixed one seed per case because ~25 % of random
+  draws failed): where a pre-activation lies within rounding distance of 0, two correct implementations may take
+  different sides, which changes the gradient of that element by O(1).  So the reference backward is evaluated with the
+  mask the DEVICE produced (the linear part -- conv data / weight / bias gradient -- is what the kernels compute), and
+  the mask itself is checked separately: it may disagree with the reference's only where |pre-activation| is below the
+  forward tolerance."""
   name, N, H, W, C, K, k, st, pad, mode, act = case
-  # crc32, not hash(): str hashes are salted per process, and a run-dependent seed turns the rare case of a
-  # pre-activation within rounding distance of 0 (ReLU mask flips between two correct fp32 results:
-  # ~25 % of random draws at these sizes) into an intermittent failure
-  g = G(zlib.crc32(name.encode()) % 1000)
+  g = G(zlib.crc32(name.encode()) % 1000 + 7919 * seed)
   x = quantize_like(torch.randn(N, C, H, W, generator=g), dtype)
   w = torch.randn(K, C, k, k, generator=g) * (1.0 / (C * k * k) ** 0.5)
   b = torch.randn(K, generator=g) * 0.1
@@ -127,14 +144,21 @@ def test_conv_fwd_dgrad_wgrad(case, dtype):
   xr = x.clone().requires_grad_(True)
   wr = wq.clone().requires_grad_(True)
   br = b.clone().requires_grad_(True)
-  y_ref = _torch_conv(xr, wr, br, st, pad, mode, act)
+  z_ref = _torch_conv(xr, wr, br, st, pad, mode, ACT_NONE)          # pre-activation
+  y_ref = _torch_conv(xr, wr, br, st, pad, mode, act).detach()
   gy = quantize_like(torch.randn(y_ref.shape, generator=g), dtype)
-  y_ref.backward(gy)
 
   y, ctx = layer.fwd(to_act(x, dtype))
   tol = RTOL[dtype]
-  assert_close(to_nchw(y), y_ref.detach(), tol, name + ' fwd')
+  y_dev = to_nchw(y)
+  assert_close(y_dev, y_ref, tol, name + ' fwd')
   assert (y.t[..., K:] == 0).all(), 'padding lanes of the output must stay zero'
+  # the activation mask of the device vs the reference's: only elements inside the forward tolerance band may differ
+  if act in (ACT_RELU, ACT_LRELU):
+    flipped = (y_dev > 0) != (z_ref.detach() > 0)
+    band = tol * float(y_ref.abs().max())
+    assert (z_ref.detach().abs()[flipped] <= band).all(), '%s: activation mask differs outside the rounding band' % name
+  z_ref.backward(gy * _act_grad_from_output(y_dev, act))            # reference backward through the device's mask
   dx = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=True)
   torch.cuda.synchronize()
   assert_close(to_nchw(dx), xr.grad, 2 * tol, name + ' dgrad')
@@ -150,7 +174,7 @@ def test_halo_kernel_mfma_16x16x32_variant(name):
   case = [c for c in CONV_CASES if c[0] == name][0]
   lib().jpdse_debug_set_fast_path(19)
   try:
-    test_conv_fwd_dgrad_wgrad(case, BF16)
+    test_conv_fwd_dgrad_wgrad(case, BF16, 0)
   finally:
     lib().jpdse_debug_set_fast_path(1)
 
