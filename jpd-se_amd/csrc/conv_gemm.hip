@@ -73,6 +73,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "wgrad_fast.h"
 #include "wgrad_thin.h"
 #include "wgrad_row.h"
+#include "wgrad_nine.h"
 #include "wgrad_taps.h"
 #include "head_fwd.h"
 #include "thin_fwd.h"
@@ -2163,6 +2164,80 @@ static int launch_wgrad_taps(const jpdse_conv_desc* d, const ConvPlan& p, int cf
   }
 }
 
+// ---- all-nine-taps weight gradient of the wide 3x3 stride-1 layers (wgrad_nine.h): no atomics, no partial tiles ----
+static int g_wgrad_nine_enabled = 1;
+static bool wgrad_nine_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
+  return g_fast_enabled && g_wgrad_nine_enabled && p.ES == 2 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
+         p.OW % 64 == 0 && p.Ks % 64 == 0 && p.Cs % 64 == 0 && d->H >= 2 && d->W >= 8 &&
+         (long long)d->N * d->H * d->W * (p.Ks > p.Cs ? p.Ks : p.Cs) < (1LL << 31);
+}
+
+static void nine_partition(const jpdse_conv_desc* d, const ConvPlan& p, NineWgArgs* a) {
+  a->strips = d->W / 64;
+  a->chunks_total = d->N * a->strips * d->H;
+  a->k_tiles = p.Ks / 64;
+  a->c_tiles = p.Cs / 64;
+  const int tiles = a->k_tiles * a->c_tiles;
+  int splits = 1;
+  if (tiles < 192) {                         // fewer tiles than CUs: cut the pixel range (fp32 slabs + fixed-order reduce)
+    splits = 256 / tiles;
+    const int max_splits = a->chunks_total / 4 > 0 ? a->chunks_total / 4 : 1;    // >= 4 chunks per block
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 32) splits = 32;
+    if (splits < 1) splits = 1;
+  }
+  a->chunks_per_split = (a->chunks_total + splits - 1) / splits;
+  a->splits = (a->chunks_total + a->chunks_per_split - 1) / a->chunks_per_split;
+  a->xcd_map = (a->k_tiles % 4 == 0 && a->c_tiles % 8 == 0 && tiles % 256 == 0) ? 1 : 0;
+}
+
+static size_t wgrad_nine_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
+  if (!wgrad_nine_ok(d, p)) return 0;
+  NineWgArgs a = {};
+  nine_partition(d, p, &a);
+  return a.splits > 1 ? (size_t)a.splits * d->K * 9 * d->C * sizeof(float) : 0;
+}
+
+template <bool REFLECT>
+static int launch_wgrad_nine_cfg(const NineWgArgs& a, hipStream_t s) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_nine_kernel<REFLECT, 0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kNineLds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_nine: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  const int blocks = a.k_tiles * a.c_tiles * a.splits;
+  hipLaunchKernelGGL((wgrad_nine_kernel<REFLECT, 0>), dim3(blocks), dim3(512), kNineLds, s, a);
+  if (int rc = check_launch("wgrad_nine_kernel")) return rc;
+  if (a.splits > 1) {
+    const long long n4 = (long long)a.K * 9 * a.C / 4;
+    hipLaunchKernelGGL(wgrad_nine_reduce_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, a.partial, a.DW, n4, a.splits);
+    return check_launch("wgrad_nine_reduce_kernel");
+  }
+  return JPDSE_OK;
+}
+
+static int launch_wgrad_nine(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* dy, float* dw,
+                             void* ws, hipStream_t s) {
+  NineWgArgs a = {};
+  a.X = reinterpret_cast<const bf16_t*>(x);
+  a.DY = reinterpret_cast<const bf16_t*>(dy);
+  a.DW = dw;
+  a.partial = reinterpret_cast<float*>(ws);
+  a.N = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.Cs = p.Cs;
+  a.C = d->C;
+  a.Ks = p.Ks;
+  a.K = d->K;
+  nine_partition(d, p, &a);
+  if (a.splits > 1 && ((long long)d->K * 9 * d->C) % 4 != 0)
+    return set_error(JPDSE_EINVAL, "wgrad_nine: K*9*C = %lld is not a multiple of 4", (long long)d->K * 9 * d->C);
+  return d->pad_mode == JPDSE_PAD_REFLECT ? launch_wgrad_nine_cfg<true>(a, s) : launch_wgrad_nine_cfg<false>(a, s);
+}
+
 // heads with <= 8 output channels on a 32- / 64-channel input, stride 1 (64->3, 32->3 7x7)
 static bool wgrad_head_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
   return g_fast_enabled && p.Ks == 8 && d->stride == 1 && (p.Cs == 32 || p.Cs == 64) && d->S * 8 <= 64 && d->R <= 7 &&
@@ -2209,6 +2284,7 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       return launch_wgrad_fast(f, s);
     }
     if (const int tcfg = wgrad_taps_cfg(d, p)) return launch_wgrad_taps(d, p, tcfg, x, dy, dw, ws, s);
+    if (wgrad_nine_ok(d, p) && ((long long)d->K * 9 * d->C) % 4 == 0) return launch_wgrad_nine(d, p, x, dy, dw, ws, s);
     if (wgrad_row_ok(d, p)) {
       RowWgArgs w = {};
       w.X = reinterpret_cast<const bf16_t*>(x);
@@ -2382,6 +2458,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_wgrad_row_enabled = enable != 4;
+  g_wgrad_nine_enabled = enable != 4 && enable != 20;   // 20: per-filter-row (stream-K, atomics) weight gradient instead of the all-nine-taps one (A/B)
   g_wgrad_taps_enabled = enable != 12;   // 12: fast kernels without the all-taps weight gradient (A/B)
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
   g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
@@ -2493,6 +2570,8 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   }
   const size_t taps = wgrad_taps_ws_bytes(d, p);
   m = m > taps ? m : taps;
+  const size_t nine = wgrad_nine_ws_bytes(d, p);
+  m = m > nine ? m : nine;
   return m > sk ? m : sk;
 }
 

@@ -85,6 +85,14 @@ CONV_CASES = [
     # per-filter-row weight gradient (wgrad_row.h): 3 taps share the staged dy / input row; stream-K segments
     ('wgrad_row_refl', 1, 6,  64,  128, 256, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
     ('wgrad_row_zero', 2, 5,  128, 256, 256, 3, 1, 1,  PAD_ZERO,    ACT_RELU),
+    # all-nine-taps weight gradient (wgrad_nine.h): rolling input-row slots, pixel halves summed through LDS; two column
+    # strips + split pixel ranges (slabs), zero padding through the slot of zeros, ragged K / C inside the last tiles,
+    # batch boundaries inside a split, a single-row-pair image
+    ('nine_strips',    2, 7,  128, 64,  128, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    ('nine_zero',      3, 5,  64,  128, 64,  3, 1, 1,  PAD_ZERO,    ACT_RELU),
+    ('nine_ragged',    1, 9,  64,  120, 200, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    ('nine_h2',        4, 2,  64,  64,  192, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    ('nine_wide_nosplit', 1, 4, 64, 512, 512, 3, 1, 1, PAD_ZERO,    ACT_NONE),
     # reflect data gradient = halo kernel on the interior + ring strips (split-K) folded back
     ('ring_dgrad_64',  2, 8,  64,  64,  128, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
     ('ring_dgrad_192', 1, 12, 128, 192, 64,  3, 1, 1,  PAD_REFLECT, ACT_NONE),
