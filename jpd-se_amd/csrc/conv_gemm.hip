@@ -55,7 +55,8 @@ struct GemmWgradArgs {
   long long dy_sn, dy_sh, dy_sw, dy_base;
   int chunks_total;
   int chunks_per_split;
-  int atomic;
+  float* partial;            // splits > 1: split y stores its partial gradient into slab y (fp32, DW's layout);
+  long long slab_stride;     // slab_reduce_kernel adds the slabs in a fixed order (no atomics: reproducible)
 };
 
 __device__ __forceinline__ int swz(int row, int slot) { return (row << 6) + (((slot ^ (row >> 3)) & 3) << 4); }
@@ -72,7 +73,6 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "gemm_halo.h"
 #include "wgrad_fast.h"
 #include "wgrad_thin.h"
-#include "wgrad_row.h"
 #include "wgrad_nine.h"
 #include "wgrad_taps.h"
 #include "head_fwd.h"
@@ -540,7 +540,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_kernel(const GemmWgra
   }
   if constexpr (sizeof(T) == 4) TL::finish(acc, master);
 
-  // ---- epilogue: scatter the (k, r, j) tile into the fp32 KRSC master-layout gradient -----
+  // ---- epilogue: scatter the (k, r, j) tile into the fp32 KRSC master-layout gradient (or this split's slab) -----
+  float* const out = a.partial != nullptr ? a.partial + (long long)blockIdx.y * a.slab_stride : a.DW;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = j0 + wn * (BN / WN) + j * 32 + (lane & 31);
@@ -553,9 +554,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_kernel(const GemmWgra
       for (int e = 0; e < 16; ++e) {
         const int k = k0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (k >= a.K) continue;
-        float* dst = a.DW + (((long long)k * a.R + r) * a.S + s) * a.C + cc;
-        if (a.atomic) atomicAdd(dst, acc[i][j][e]);
-        else *dst = acc[i][j][e];
+        out[(((long long)k * a.R + r) * a.S + s) * a.C + cc] = acc[i][j][e];
       }
     }
   }
@@ -799,6 +798,48 @@ __global__ __launch_bounds__(256) void pack_dgrad_tile_many_kernel(const jpdse_p
   }
 }
 
+// dw[i] = sum over b < nslabs of partial[b * stride + i], slabs added in index order (deterministic).  256 threads =
+// 64 consecutive vectors x 4 slab groups, 8 loads in flight per thread; the groups are combined through LDS in a fixed
+// order.  VEC = 4 when the element count and the slab stride are multiples of 4, else 1.
+template <int VEC>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                         long long nvec, long long stride_vec, int nslabs) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  __shared__ vec_t red[4][64];
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long long idx = (long long)blockIdx.x * 64 + el;
+  vec_t sum = {};
+  if (idx < nvec) {
+    const vec_t* src = reinterpret_cast<const vec_t*>(partial) + idx;
+    const int per = (nslabs + 3) / 4;
+    const int b0 = grp * per;
+    int b1 = b0 + per;
+    b1 = b1 < nslabs ? b1 : nslabs;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      vec_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long long)(b + u) * stride_vec];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; b < b1; ++b) sum += src[(long long)b * stride_vec];
+  }
+  red[grp][el] = sum;
+  __syncthreads();
+  if (grp == 0 && idx < nvec) reinterpret_cast<vec_t*>(dw)[idx] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+}
+
+static int launch_slab_reduce(const float* partial, float* dw, long long n, long long stride, int nslabs, hipStream_t s) {
+  if (n % 4 == 0 && stride % 4 == 0) {
+    const long long nv = n / 4;
+    hipLaunchKernelGGL((slab_reduce_kernel<4>), dim3((unsigned)((nv + 63) / 64)), dim3(256), 0, s, partial, dw, nv, stride / 4, nslabs);
+  } else {
+    hipLaunchKernelGGL((slab_reduce_kernel<1>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, partial, dw, n, stride, nslabs);
+  }
+  return jpdse::check_launch("slab_reduce_kernel");
+}
+
 // =========================================================================================
 // host side: planning and launch
 // =========================================================================================
@@ -1001,36 +1042,54 @@ static int launch_fwd(const GemmFwdArgs& a, hipStream_t s) {
   return launch_fwd_cfg<T, 256, 32, 4, 1>(a, s);
 }
 
+// split count of the generic weight-gradient kernel (shared by the launcher and the workspace query)
+template <typename T, int BM, int BN>
+static int generic_wgrad_splits(const GemmWgradArgs& a, int* chunks_per_split) {
+  const int PIX = WgStage<T>::PIX;
+  const int col_tiles = (a.run + BN - 1) / BN, chunks_total = (a.M + PIX - 1) / PIX;
+  const int tiles = ((a.K + BM - 1) / BM) * a.R * col_tiles;
+  int splits = 1;
+  if (tiles < 512) {
+    splits = (768 + tiles - 1) / tiles;
+    const int max_splits = (chunks_total + 7) / 8;  // >= 8 chunks of work per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+  }
+  const int cps = (chunks_total + splits - 1) / splits;
+  if (chunks_per_split) *chunks_per_split = cps;
+  return (chunks_total + cps - 1) / cps;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
-static int launch_wgrad_cfg(GemmWgradArgs a, hipStream_t s) {
+static int launch_wgrad_cfg(GemmWgradArgs a, float* slabs, hipStream_t s) {
   const int PIX = WgStage<T>::PIX;
   a.col_tiles_per_r = (a.run + BN - 1) / BN;
   a.chunks_total = (a.M + PIX - 1) / PIX;
   const int tiles = ((a.K + BM - 1) / BM) * a.R * a.col_tiles_per_r;
-  int splits = 1;
-  if (tiles < 512) {
-    splits = (768 + tiles - 1) / tiles;
-    const int max_splits = (a.chunks_total + 7) / 8;  // >= 8 chunks of work per split
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-  }
-  a.chunks_per_split = (a.chunks_total + splits - 1) / splits;
-  splits = (a.chunks_total + a.chunks_per_split - 1) / a.chunks_per_split;
-  a.atomic = splits > 1;
-  if (a.atomic) {
-    hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), s);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
-  }
+  const int splits = generic_wgrad_splits<T, BM, BN>(a, &a.chunks_per_split);
+  const long long n = (long long)a.K * a.R * a.S * a.C;
+  a.partial = splits > 1 ? slabs : nullptr;
+  a.slab_stride = (n + 3) / 4 * 4;
   const size_t lds = 2 * (BM + BN) * 64;
   hipLaunchKernelGGL((gemm_wgrad_kernel<T, BM, BN, WM, WN>), dim3(tiles, splits), dim3(64 * WM * WN), lds, s, a);
-  return check_launch("gemm_wgrad_kernel");
+  if (int rc = check_launch("gemm_wgrad_kernel")) return rc;
+  return splits > 1 ? launch_slab_reduce(slabs, a.DW, n, a.slab_stride, splits, s) : JPDSE_OK;
 }
 
 template <typename T>
-static int launch_wgrad(const GemmWgradArgs& a, hipStream_t s) {
-  if (a.K > 64) return launch_wgrad_cfg<T, 128, 128, 2, 2>(a, s);
-  if (a.K > 32) return launch_wgrad_cfg<T, 64, 128, 2, 2>(a, s);
-  return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, s);
+static size_t generic_wgrad_slab_bytes(const GemmWgradArgs& a) {
+  const int splits = a.K > 64 ? generic_wgrad_splits<T, 128, 128>(a, nullptr)
+                              : (a.K > 32 ? generic_wgrad_splits<T, 64, 128>(a, nullptr) : generic_wgrad_splits<T, 32, 256>(a, nullptr));
+  const long long n = (long long)a.K * a.R * a.S * a.C;
+  return splits > 1 ? (size_t)splits * ((n + 3) / 4 * 4) * sizeof(float) : 0;
+}
+
+template <typename T>
+static int launch_wgrad(const GemmWgradArgs& a, float* slabs, hipStream_t s) {
+  if (a.K > 64) return launch_wgrad_cfg<T, 128, 128, 2, 2>(a, slabs, s);
+  if (a.K > 32) return launch_wgrad_cfg<T, 64, 128, 2, 2>(a, slabs, s);
+  return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, slabs, s);
 }
 
 template <int WM, int WN, int TM, int TN, int VAR, int STAGES = 3>
@@ -1146,7 +1205,6 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
   return tiles >= 448 || (tiles >= 256 && tiles % 256 == 0);
 }
 
-static int g_wgrad_abl = 0;
 static int g_ring_enabled = 1;
 static int g_merge_min_kt = 4;
 static int g_halo_single = 1;
@@ -1917,11 +1975,32 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   return rc;
 }
 
+// (tile, split) partition of the fast weight-gradient kernel
+template <int BM, int BN>
+static void fast_wgrad_partition(FastWgArgs* a, int lds) {
+  const int blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
+  a->chunks_total = (a->M + 63) / 64;
+  const int tiles = ((a->Ks + BM - 1) / BM) * (a->run_mode ? a->R : a->R * a->S) *
+                    (((a->run_mode ? a->run_len : a->Cs) + BN - 1) / BN);
+  int splits = (256 * blocks_per_cu + tiles / 2) / tiles;      // fill the chip once
+  const int max_splits = a->chunks_total / 8 > 0 ? a->chunks_total / 8 : 1;      // >= 8 chunks per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  a->chunks_per_split = (a->chunks_total + splits - 1) / splits;
+  a->splits = (a->chunks_total + a->chunks_per_split - 1) / a->chunks_per_split;
+  a->slab_stride = ((long long)a->K * a->R * a->S * a->C + 3) / 4 * 4;
+}
+
 template <int WM, int WN, int TM, int TN, int ABL = 0>
-static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
+static int launch_wgrad_fast_cfg(FastWgArgs a, float* slabs, size_t* slab_bytes_out, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int lds = 2 * 64 * 2 * (BM + BN);
-  constexpr int blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
+  fast_wgrad_partition<BM, BN>(&a, lds);
+  if (slab_bytes_out != nullptr) {        // workspace query only
+    *slab_bytes_out = a.splits > 1 ? (size_t)a.splits * a.slab_stride * sizeof(float) : 0;
+    return JPDSE_OK;
+  }
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<WM, WN, TM, TN, ABL>),
@@ -1929,46 +2008,24 @@ static int launch_wgrad_fast_cfg(FastWgArgs a, hipStream_t s) {
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_fast: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  a.chunks_total = (a.M + 63) / 64;
   const int tiles = ((a.Ks + BM - 1) / BM) * (a.run_mode ? a.R : a.R * a.S) *
                     (((a.run_mode ? a.run_len : a.Cs) + BN - 1) / BN);
-  // stream-K partition: the tiles x chunks iteration space is cut into equal contiguous shares, one
-  // per block, two blocks per CU.  A tile whose chunks all fall into one share is stored; a tile
-  // straddling shares is accumulated with fp32 atomics into the zeroed gradient.
-  const long long total = (long long)tiles * a.chunks_total;
-  long long nblocks = 256 * blocks_per_cu;
-  if (total < nblocks * 8) nblocks = (total + 7) / 8;
-  if (nblocks < 1) nblocks = 1;
-  a.iters_per_block = (int)((total + nblocks - 1) / nblocks);
-  nblocks = (total + a.iters_per_block - 1) / a.iters_per_block;
-  a.total_iters = total;
-  a.atomic = (a.iters_per_block % a.chunks_total) != 0 || nblocks * (long long)a.iters_per_block != total;
-  if (a.atomic) {
-    hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), s);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
-  }
-  const int splits = 1;
-  const int tiles_grid = (int)nblocks;
-  hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, ABL>), dim3(tiles_grid, splits), dim3(64 * WM * WN), lds, s, a);
-  return check_launch("wgrad_fast_kernel");
+  a.partial = slabs;
+  hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, ABL>), dim3(tiles * a.splits), dim3(64 * WM * WN), lds, s, a);
+  if (int rc = check_launch("wgrad_fast_kernel")) return rc;
+  return a.splits > 1 ? launch_slab_reduce(slabs, a.DW, (long long)a.K * a.R * a.S * a.C, a.slab_stride, a.splits, s) : JPDSE_OK;
 }
 
-static int launch_wgrad_fast(const FastWgArgs& a, hipStream_t s) {
+// slab_bytes_out != nullptr: report the slab bytes the launch would need instead of launching (workspace query)
+static int launch_wgrad_fast(const FastWgArgs& a, float* slabs, hipStream_t s, size_t* slab_bytes_out = nullptr) {
   const int cols = a.run_mode ? a.run_len : a.Cs;
   const bool m2 = a.Ks >= 128, n2 = cols >= 128;
-  if (a.Ks >= 256 && cols >= 256 && a.Ks % 256 == 0 && cols % 256 == 0 && !a.run_mode) {
-    switch (g_wgrad_abl) {           // non-zero: timing-only ablations
-      case 1: return launch_wgrad_fast_cfg<2, 4, 4, 2, 1>(a, s);
-      case 4: return launch_wgrad_fast_cfg<2, 4, 4, 2, 4>(a, s);
-      case 15: return launch_wgrad_fast_cfg<2, 4, 4, 2, 15>(a, s);
-      case 32: break;                // 232: force the 128 x 128 tile (A/B)
-      default: return launch_wgrad_fast_cfg<2, 4, 4, 2>(a, s);     // 256 x 256, 8 waves
-    }
-  }
-  if (m2 && n2) return launch_wgrad_fast_cfg<2, 2, 2, 2>(a, s);
-  if (m2) return launch_wgrad_fast_cfg<2, 2, 2, 1>(a, s);
-  if (n2) return launch_wgrad_fast_cfg<2, 2, 1, 2>(a, s);
-  return launch_wgrad_fast_cfg<2, 2, 1, 1>(a, s);
+  if (a.Ks >= 256 && cols >= 256 && a.Ks % 256 == 0 && cols % 256 == 0 && !a.run_mode)
+    return launch_wgrad_fast_cfg<2, 4, 4, 2>(a, slabs, slab_bytes_out, s);     // 256 x 256, 8 waves
+  if (m2 && n2) return launch_wgrad_fast_cfg<2, 2, 2, 2>(a, slabs, slab_bytes_out, s);
+  if (m2) return launch_wgrad_fast_cfg<2, 2, 2, 1>(a, slabs, slab_bytes_out, s);
+  if (n2) return launch_wgrad_fast_cfg<2, 2, 1, 2>(a, slabs, slab_bytes_out, s);
+  return launch_wgrad_fast_cfg<2, 2, 1, 1>(a, slabs, slab_bytes_out, s);
 }
 
 template <int TM, int NW, int NT, int RR, int WM, int PITCH>
@@ -1984,6 +2041,22 @@ static int launch_wgrad_thin_cfg(const ThinWgArgs& a, hipStream_t s) {
   }
 }
 
+static int thin_wgrad_ranges(const ThinWgArgs& a, int RR, int* strips_per_block) {
+  const int chunks_per_row = (a.OW + 63) / 64;
+  const int strips_total = a.N * a.OH * chunks_per_row;
+  const int row_groups = (a.R + RR - 1) / RR;
+  int P = 1024 / row_groups;               // ~4 blocks per CU over the filter-row groups
+  if (P < 1) P = 1;
+  if (P > strips_total) P = strips_total;
+  const int spb = (strips_total + P - 1) / P;
+  if (strips_per_block) *strips_per_block = spb;
+  return (strips_total + spb - 1) / spb;
+}
+static size_t thin_wgrad_slab_bytes(const ThinWgArgs& a, int RR) {
+  const long long n = ((long long)a.K * a.R * a.S * a.C + 3) / 4 * 4;
+  return (size_t)thin_wgrad_ranges(a, RR, nullptr) * n * sizeof(float);
+}
+
 template <int TM, int NW, int NT, int RR, int WM, int PITCH>
 static int launch_wgrad_thin_pitch(ThinWgArgs a, hipStream_t s) {
   const int pitch = a.st * a.Cs;
@@ -1992,20 +2065,22 @@ static int launch_wgrad_thin_pitch(ThinWgArgs a, hipStream_t s) {
   if (lds > 64 * 1024) return set_error(JPDSE_ELAUNCH, "wgrad_thin: strip of %d B does not fit", lds);
   a.chunks_per_row = (a.OW + 63) / 64;
   a.strips_total = a.N * a.OH * a.chunks_per_row;
-  const int row_groups = (a.R + RR - 1) / RR;
-  int P = 1024 / row_groups;               // ~4 blocks per CU over the filter-row groups
-  if (P < 1) P = 1;
-  if (P > a.strips_total) P = a.strips_total;
-  a.strips_per_block = (a.strips_total + P - 1) / P;
-  P = (a.strips_total + a.strips_per_block - 1) / a.strips_per_block;
-  hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * a.R * a.S * a.C * sizeof(float), s);
-  if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
+  a.row_groups = (a.R + RR - 1) / RR;
+  a.ranges = thin_wgrad_ranges(a, RR, &a.strips_per_block);
+  a.slab_stride = ((long long)a.K * a.R * a.S * a.C + 3) / 4 * 4;
+  if (a.partial == nullptr) return set_error(JPDSE_EWORKSPACE, "wgrad_thin: no slab workspace");
+  // block -> (pixel range, filter-row group): the row groups of ONE pixel range read the same dy strips and nearly the
+  // same input rows; they get consecutive slots of one XCD (blocks b, b + 8, ... share an XCD: observed dispatch,
+  // speed only), so its L2 serves them -- as a (ranges, row_groups) grid they ran far apart in time and every row
+  // group re-fetched x and dy from beyond L2 (7x the algorithmic bytes on the first 7x7 conv)
+  const int blocks = ((a.ranges + 7) / 8) * 8 * a.row_groups;
   if constexpr (RR > 1) {      // heads: roles swapped, transposed output
-    hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR, PITCH, true>), dim3(P, row_groups), dim3(64 * WM * NW), lds, s, a);
+    hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR, PITCH, true>), dim3(blocks), dim3(64 * WM * NW), lds, s, a);
   } else {
-    hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR, PITCH, false>), dim3(P, row_groups), dim3(64 * WM * NW), lds, s, a);
+    hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR, PITCH, false>), dim3(blocks), dim3(64 * WM * NW), lds, s, a);
   }
-  return check_launch("wgrad_thin_kernel");
+  if (int rc = check_launch("wgrad_thin_kernel")) return rc;
+  return launch_slab_reduce(a.partial, a.DW, (long long)a.K * a.R * a.S * a.C, a.slab_stride, a.ranges, s);
 }
 
 static bool wgrad_thin_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
@@ -2026,55 +2101,18 @@ static int launch_wgrad_thin(const ThinWgArgs& a, hipStream_t s) {
   return launch_wgrad_thin_cfg<1, 4, 3>(a, s);
 }
 
-static int g_wgrad_row_enabled = 1;
-static bool wgrad_row_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
-  return g_fast_enabled && g_wgrad_row_enabled && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
-         p.OW % 64 == 0 && p.Ks % 256 == 0 && p.Cs % 128 == 0;
-}
-
-template <int ABL, bool REFLECT>
-static int launch_wgrad_row_cfg(RowWgArgs a, hipStream_t s) {
-  constexpr int lds = 3 * (64 * 512 + 17 * 1024);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_row_kernel<ABL, REFLECT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_row: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
-  a.chunks_per_row = a.W / 64;
-  a.chunks_total = a.N * a.H * a.chunks_per_row;
-  const int tiles = (a.Ks / 256) * 3 * (a.Cs / 128);
-  const long long total = (long long)tiles * a.chunks_total;
-  long long nblocks = 256;
-  if (total < nblocks * 8) nblocks = (total + 7) / 8;
-  if (nblocks < 1) nblocks = 1;
-  a.iters_per_block = (int)((total + nblocks - 1) / nblocks);
-  nblocks = (total + a.iters_per_block - 1) / a.iters_per_block;
-  a.total_iters = total;
-  const bool atomic = (a.iters_per_block % a.chunks_total) != 0 || nblocks * (long long)a.iters_per_block != total;
-  if (atomic) {
-    hipError_t e = hipMemsetAsync(a.DW, 0, (size_t)a.K * 9 * a.C * sizeof(float), s);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad memset: %s", hipGetErrorString(e));
-  }
-  hipLaunchKernelGGL((wgrad_row_kernel<ABL, REFLECT>), dim3((int)nblocks), dim3(512), lds, s, a);
-  return check_launch("wgrad_row_kernel");
-}
-
-static int launch_wgrad_row(const RowWgArgs& a, hipStream_t s) {
-  if (g_wgrad_abl == 1) return launch_wgrad_row_cfg<1, true>(a, s);
-  if (g_wgrad_abl == 2) return launch_wgrad_row_cfg<2, true>(a, s);
-  return a.reflect ? launch_wgrad_row_cfg<0, true>(a, s) : launch_wgrad_row_cfg<0, false>(a, s);
-}
-
 // ---- all-taps weight gradient of the narrow high-resolution layers (wgrad_taps.h) -----------------
 // config id: 0 none; 1: 3x3 s2 K%128 C%64; 2: 3x3 s1 K%64 C%64; 3: 4x4 s2 K%128 C%64; 4: 3x3 s2 K%256 C%128
 static int g_wgrad_taps_enabled = 1;
 static int wgrad_taps_cfg(const jpdse_conv_desc* d, const ConvPlan& p) {
   if (!g_fast_enabled || !g_wgrad_taps_enabled || p.ES != 2 || d->R != d->S) return 0;
-  if (p.Ks > 256 || p.Cs > 128 || (long long)d->N * p.OH * ((p.OW + 63) / 64) < 32) return 0;
+  if ((long long)d->N * p.OH * ((p.OW + 63) / 64) < 32) return 0;
   if ((long long)d->N * p.OH * p.OW * p.Ks >= (1LL << 31) || (long long)d->N * d->H * d->W * p.Cs >= (1LL << 31)) return 0;
+  // 3x3 stride 2 with wide outputs, any width: the down-sampling convs 128 -> 256 ... 512 -> 1024 and, with the roles of
+  // x and dy swapped by the caller, the ConvTranspose2d layers 1024 -> 512 ... 128 -> 64 (round 1 sent the wide ones to
+  // the per-tap kernel, whose stream-K partial tiles met in fp32 atomics)
   if (d->R == 3 && d->stride == 2 && p.Ks % 256 == 0 && p.Cs % 64 == 0) return 4;
+  if (p.Ks > 256 || p.Cs > 128) return 0;
   if (d->R == 3 && d->stride == 2 && p.Ks % 128 == 0 && p.Cs % 64 == 0) return 1;
   if (d->R == 3 && d->stride == 1 && p.Ks % 64 == 0 && p.Ks <= 128 && p.Cs % 64 == 0) return 2;
   if (d->R == 4 && d->stride == 2 && p.Ks % 128 == 0 && p.Cs % 64 == 0) return 3;
@@ -2198,17 +2236,18 @@ static size_t wgrad_nine_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
   return a.splits > 1 ? (size_t)a.splits * d->K * 9 * d->C * sizeof(float) : 0;
 }
 
-template <bool REFLECT>
+static int g_nine_sched = 2;
+template <bool REFLECT, int SCHED>
 static int launch_wgrad_nine_cfg(const NineWgArgs& a, hipStream_t s) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_nine_kernel<REFLECT, 0>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_nine_kernel<REFLECT, SCHED, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kNineLds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_nine: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
   const int blocks = a.k_tiles * a.c_tiles * a.splits;
-  hipLaunchKernelGGL((wgrad_nine_kernel<REFLECT, 0>), dim3(blocks), dim3(512), kNineLds, s, a);
+  hipLaunchKernelGGL((wgrad_nine_kernel<REFLECT, SCHED, 0>), dim3(blocks), dim3(512), kNineLds, s, a);
   if (int rc = check_launch("wgrad_nine_kernel")) return rc;
   if (a.splits > 1) {
     const long long n4 = (long long)a.K * 9 * a.C / 4;
@@ -2235,7 +2274,10 @@ static int launch_wgrad_nine(const jpdse_conv_desc* d, const ConvPlan& p, const 
   nine_partition(d, p, &a);
   if (a.splits > 1 && ((long long)d->K * 9 * d->C) % 4 != 0)
     return set_error(JPDSE_EINVAL, "wgrad_nine: K*9*C = %lld is not a multiple of 4", (long long)d->K * 9 * d->C);
-  return d->pad_mode == JPDSE_PAD_REFLECT ? launch_wgrad_nine_cfg<true>(a, s) : launch_wgrad_nine_cfg<false>(a, s);
+  if (d->pad_mode != JPDSE_PAD_REFLECT) return launch_wgrad_nine_cfg<false, 2>(a, s);
+  if (g_nine_sched == 0) return launch_wgrad_nine_cfg<true, 0>(a, s);
+  if (g_nine_sched == 1) return launch_wgrad_nine_cfg<true, 1>(a, s);
+  return launch_wgrad_nine_cfg<true, 2>(a, s);
 }
 
 // heads with <= 8 output channels on a 32- / 64-channel input, stride 1 (64->3, 32->3 7x7)
@@ -2249,21 +2291,32 @@ static int launch_wgrad_head(const ThinWgArgs& a, hipStream_t s) {
   return a.Ks == 64 ? launch_wgrad_thin_cfg<1, 2, 1, 7, 2>(a, s) : launch_wgrad_thin_cfg<1, 2, 1, 7>(a, s);
 }
 
+// Workspace layout of the weight-gradient paths: [0, front) = padded copy of x (+ tap-expanded dy of the narrow-output
+// layers), [front, ...) = the fp32 slabs of the split reductions (slab_reduce_kernel).  The all-taps kernels (wgrad_taps,
+// wgrad_nine) make no copies and put their slabs at offset 0.
+static size_t wgrad_front_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
+  const size_t kexp_s = (size_t)round_up(d->K * d->R * d->S, 64);
+  size_t dz = (p.Ks == 8 && kexp_s <= 256) ? align_up((size_t)d->N * p.Hp * p.Wp * kexp_s * 2, 256) : 0;
+  if (p.Ks == 8 && d->stride == 1) {      // zero-padded dy of the head weight gradient (wgrad_thin.h, transposed)
+    const size_t dyp = align_up((size_t)d->N * (p.OH + 2 * (d->R - 1)) * (p.OW + 2 * (d->S - 1)) * 8 * 2 + kSlackBytes, 256);
+    dz = dz > dyp ? dz : dyp;
+  }
+  return align_up(p.xpad_bytes + dz, 256);
+}
+
 template <typename T>
 static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* dy, float* dw,
-                        void* ws, hipStream_t s) {
+                        void* ws, hipStream_t s, size_t* slab_bytes_out = nullptr) {
+  // slab_bytes_out != nullptr: dry run for jpdse_conv_workspace_size -- follows the dispatch below and reports the slab
+  // bytes of the path that would run, launching nothing
+  float* const slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + wgrad_front_bytes(d, p));
+  const bool dry = slab_bytes_out != nullptr;
+  if (dry) *slab_bytes_out = 0;
   if constexpr (sizeof(T) == 2) {
     const int kexp = d->K * d->R * d->S, kexp_s = round_up(kexp, 64);
     if (g_fast_enabled && !wgrad_head_ok(d, p) && p.Ks == 8 && d->stride == 1 && p.Cs % 64 == 0 && kexp_s <= 256) {
       // few output channels: dense 1x1 weight gradient over the tap-expanded dy (see expand_dy_taps_kernel)
-      if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-        return rc;
       bf16_t* dz = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ws) + p.xpad_bytes);
-      const long long tv = (long long)d->N * p.Hp * p.Wp * (kexp_s / 8);
-      hipLaunchKernelGGL(expand_dy_taps_kernel, dim3(ew_blocks(tv)), dim3(256), 0, s,
-                         reinterpret_cast<const bf16_t*>(dy), dz, p.OH, p.OW, p.Ks, d->K, d->R, d->S, p.Hp, p.Wp,
-                         kexp_s, tv);
-      if (int rc = check_launch("expand_dy_taps_kernel")) return rc;
       FastWgArgs f = {};
       f.X = reinterpret_cast<const bf16_t*>(ws);
       f.DY = dz;
@@ -2281,25 +2334,19 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       f.sy = f.sx = 1;
       f.py = f.px = 0;
       f.reflect = 0;
-      return launch_wgrad_fast(f, s);
+      if (dry) return launch_wgrad_fast(f, nullptr, s, slab_bytes_out);
+      if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+        return rc;
+      const long long tv = (long long)d->N * p.Hp * p.Wp * (kexp_s / 8);
+      hipLaunchKernelGGL(expand_dy_taps_kernel, dim3(ew_blocks(tv)), dim3(256), 0, s,
+                         reinterpret_cast<const bf16_t*>(dy), dz, p.OH, p.OW, p.Ks, d->K, d->R, d->S, p.Hp, p.Wp,
+                         kexp_s, tv);
+      if (int rc = check_launch("expand_dy_taps_kernel")) return rc;
+      return launch_wgrad_fast(f, slabs, s);
     }
-    if (const int tcfg = wgrad_taps_cfg(d, p)) return launch_wgrad_taps(d, p, tcfg, x, dy, dw, ws, s);
-    if (wgrad_nine_ok(d, p) && ((long long)d->K * 9 * d->C) % 4 == 0) return launch_wgrad_nine(d, p, x, dy, dw, ws, s);
-    if (wgrad_row_ok(d, p)) {
-      RowWgArgs w = {};
-      w.X = reinterpret_cast<const bf16_t*>(x);
-      w.DY = reinterpret_cast<const bf16_t*>(dy);
-      w.DW = dw;
-      w.N = d->N;
-      w.H = d->H;
-      w.W = d->W;
-      w.Cs = p.Cs;
-      w.C = d->C;
-      w.Ks = p.Ks;
-      w.K = d->K;
-      w.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
-      return launch_wgrad_row(w, s);
-    }
+    if (const int tcfg = wgrad_taps_cfg(d, p)) return dry ? JPDSE_OK : launch_wgrad_taps(d, p, tcfg, x, dy, dw, ws, s);
+    if (wgrad_nine_ok(d, p) && ((long long)d->K * 9 * d->C) % 4 == 0)
+      return dry ? JPDSE_OK : launch_wgrad_nine(d, p, x, dy, dw, ws, s);
     if (wgrad_head_ok(d, p)) {
       // roles swapped (see wgrad_thin.h): A = padded input, run operand = dy zero-padded by (R-1, S-1); both
       // paddings are resolved by the loader
@@ -2329,6 +2376,11 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       t.a_pad = d->pad;
       t.a_reflect = d->pad_mode == JPDSE_PAD_REFLECT;
       t.transposed = 1;
+      t.partial = slabs;
+      if (dry) {
+        *slab_bytes_out = thin_wgrad_slab_bytes(t, 7);
+        return JPDSE_OK;
+      }
       return launch_wgrad_head(t, s);
     }
     if (wgrad_thin_ok(d, p)) {
@@ -2349,6 +2401,11 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       t.R = d->R;
       t.S = d->S;
       t.st = d->stride;
+      t.partial = slabs;
+      if (dry) {
+        *slab_bytes_out = thin_wgrad_slab_bytes(t, 1);
+        return JPDSE_OK;
+      }
       if (d->stride == 2) {
         // padding resolved by the loader (no padded copy): pays for the stride-2 layers (PatchGAN layer 0)
         t.unpadded = 1;
@@ -2393,8 +2450,9 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         f.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
       } else {
         // run mode over the materially padded input (40-channel network inputs, 8-channel images)
-        if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-          return rc;
+        if (!dry)
+          if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+            return rc;
         f.X = reinterpret_cast<const bf16_t*>(ws);
         f.IH = p.Hp;
         f.IW = p.Wp;
@@ -2403,12 +2461,13 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         f.run_mode = 1;
         f.run_len = d->S * p.Cs;
       }
-      return launch_wgrad_fast(f, s);
+      return launch_wgrad_fast(f, slabs, s, slab_bytes_out);
     }
   }
   // always staged through the workspace: the GEMM loaders rely on the zeroed slack behind it
-  if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-    return rc;
+  if (!dry)
+    if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
+      return rc;
   const void* xin = ws;
   GemmWgradArgs a = {};
   a.X = xin;
@@ -2433,7 +2492,11 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   a.dy_sh = (long long)p.OW * p.Ks;
   a.dy_sw = p.Ks;
   a.dy_base = 0;
-  return launch_wgrad<T>(a, s);
+  if (dry) {
+    *slab_bytes_out = generic_wgrad_slab_bytes<T>(a);
+    return JPDSE_OK;
+  }
+  return launch_wgrad<T>(a, slabs, s);
 }
 
 }  // namespace jpdse
@@ -2457,8 +2520,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_fast_enabled = enable != 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
-  g_wgrad_row_enabled = enable != 4;
-  g_wgrad_nine_enabled = enable != 4 && enable != 20;   // 20: per-filter-row (stream-K, atomics) weight gradient instead of the all-nine-taps one (A/B)
+  g_nine_sched = enable == 21 ? 0 : (enable == 22 ? 1 : 2);   // 21 / 22: DMA issue placement of the nine-tap weight gradient (A/B)
+  g_wgrad_nine_enabled = enable != 4;    // 4: wide 3x3 layers on the per-tap fast weight gradient instead of the all-nine-taps one (A/B)
   g_wgrad_taps_enabled = enable != 12;   // 12: fast kernels without the all-taps weight gradient (A/B)
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
   g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
@@ -2472,7 +2535,6 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_thin_out_fast = enable != 13;     // 13: narrow-output long-K layers on the generic kernel (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
-  g_wgrad_abl = enable >= 200 ? enable - 200 : 0;   // 200+bits: fast wgrad timing ablations   // 100+bits: halo kernel timing ablations (wrong results)
   return JPDSE_OK;
 }
 
@@ -2550,13 +2612,11 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   if (validate(d)) return 0;
   ConvPlan p;
   make_plan(d, &p);
-  const size_t kexp_s = (size_t)round_up(d->K * d->R * d->S, 64);
-  size_t dz = (p.Ks == 8 && kexp_s <= 256) ? align_up((size_t)d->N * p.Hp * p.Wp * kexp_s * 2, 256) : 0;
-  if (p.Ks == 8 && d->stride == 1) {      // zero-padded dy of the head weight gradient (wgrad_thin.h, transposed)
-    const size_t dyp = align_up((size_t)d->N * (p.OH + 2 * (d->R - 1)) * (p.OW + 2 * (d->S - 1)) * 8 * 2 + kSlackBytes, 256);
-    dz = dz > dyp ? dz : dyp;
-  }
-  const size_t fwd = p.xpad_bytes + dz;     // wgrad: padded x (+ tap-expanded dy for few-output-channel layers)
+  // wgrad: padded x (+ tap-expanded dy for few-output-channel layers) + the slabs of the split reduction
+  size_t slab_bytes = 0;
+  if (d->dtype == JPDSE_BF16) (void)conv_wgrad_t<bf16_t>(d, p, nullptr, nullptr, nullptr, nullptr, nullptr, &slab_bytes);
+  else (void)conv_wgrad_t<float>(d, p, nullptr, nullptr, nullptr, nullptr, nullptr, &slab_bytes);
+  const size_t fwd = wgrad_front_bytes(d, p) + slab_bytes;
   const size_t dgrad = p.dypad_bytes + p.dxp_bytes;
   size_t sk = p.splitk_off + p.splitk_bytes;
   if (p.ES == 2 && d->pad_mode == JPDSE_PAD_REFLECT && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1) {

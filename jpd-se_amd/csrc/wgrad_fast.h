@@ -28,8 +28,12 @@ struct FastWgArgs {
   int IH, IW, Cs, C;
   int Ks, K;
   int R, S, sy, sx, py, px, reflect;
-  int chunks_total, iters_per_block, atomic;
-  long long total_iters;   // tiles * chunks_total
+  // pixel range cut into `splits` equal parts (block = (tile, split)); a split stores its partial tile into slab
+  // `split` of `partial` (DW's layout, slab_stride elements apart) and slab_reduce_kernel adds the slabs in a fixed
+  // order -- round 1's stream-K partition met in fp32 atomics (run-to-run nondeterministic)
+  int chunks_total, splits, chunks_per_split;
+  float* partial;
+  long long slab_stride;
   // run mode (input channels not a multiple of 64, e.g. the 40-channel network inputs): X is the
   // materially padded input, a tile's columns are 64*TN consecutive elements of the S*Cs run under
   // filter row r (consecutive taps s are consecutive pixels), taps iterate over r only.
@@ -104,8 +108,7 @@ __device__ __forceinline__ void wg_mma_step(uint32_t sbase, const int (&a_tr)[TM
 // Tile = (WM*TM*32) k-channels x (WN*TN*32) c-channels, WM x WN waves, wave tile 32*TM x 32*TN.
 //   <2,2,TM,TN>  64..128 square-ish tiles, 4 waves, 2 blocks per CU (small layers)
 //   <2,4,4,2>    256 x 256, 8 waves, 1 block per CU: 2x the FLOPs per staged byte -- the kernel is bound
-//                by the L2->LDS fill (ablation: no DMA => 2.2x), and the stream-K partition keeps the
-//                256 CUs evenly loaded whatever the tile count.
+//                by the L2->LDS fill (ablation: no DMA => 2.2x).
 // ABL: timing-only ablation bits (wrong results when non-zero): 1 = no DMA after the first chunk,
 // 2 = no barrier, 4 = fragments read once per chunk, 8 = no vmcnt waits
 template <int WM, int WN, int TM, int TN, int ABL = 0>
@@ -129,22 +132,27 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_fast_kernel(const FastWgAr
 
   const int c_tiles = ((a.run_mode ? a.run_len : a.Cs) + BN - 1) / BN;
   const int n_taps = a.run_mode ? a.R : a.R * a.S;
-  long long it0 = (long long)blockIdx.x * a.iters_per_block;
-  long long it1 = it0 + a.iters_per_block;
-  it1 = it1 < a.total_iters ? it1 : a.total_iters;
-  // ---- stream-K: this block owns the iteration range [it0, it1) of the (tile, chunk) space --------
-  while (it0 < it1) {
-  const int tile = (int)(it0 / a.chunks_total);
-  const int ch_begin = (int)(it0 - (long long)tile * a.chunks_total);
-  int ch_end = ch_begin + (int)(it1 - it0);
+  // block -> (k tile, tap, c tile, split).  The taps of one (k tile, c tile, split) stage the same dy pixels and nearly
+  // the same input pixels: they get consecutive slots of ONE XCD (blocks b, b + 8, ... share an XCD: observed dispatch,
+  // speed only), so that its L2 serves all of them -- in plain tile order they ran apart in time and every tap re-fetched
+  // both operands from beyond L2 (20x the algorithmic bytes on the 16-tap PatchGAN layers).
+  const int k_tiles = (a.Ks + BM - 1) / BM;
+  const int groups = k_tiles * c_tiles * a.splits;
+  int grp, tap;
+  if ((groups & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tap = j % n_taps;
+    grp = (j / n_taps) * 8 + xcd;
+  } else {
+    tap = blockIdx.x % n_taps;
+    grp = blockIdx.x / n_taps;
+  }
+  const int split = grp % a.splits, kc = grp / a.splits;
+  const int ct = kc % c_tiles, kt = kc / c_tiles;
+  const int ch_begin = split * a.chunks_per_split;
+  int ch_end = ch_begin + a.chunks_per_split;
   ch_end = ch_end < a.chunks_total ? ch_end : a.chunks_total;
-  it0 += ch_end - ch_begin;
-  const bool whole_tile = ch_begin == 0 && ch_end == a.chunks_total;
-  // tile -> (k tile, tap, c tile)
-  const int ct = tile % c_tiles;
-  const int t1 = tile / c_tiles;
-  const int tap = t1 % n_taps;
-  const int kt = t1 / n_taps;
+  float* const out = a.splits > 1 ? a.partial + (long long)split * a.slab_stride : a.DW;
   const int r = a.run_mode ? tap : tap / a.S, s = a.run_mode ? 0 : tap - r * a.S;
   const int k0 = kt * BM, c0 = ct * BN;
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
@@ -313,14 +321,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_fast_kernel(const FastWgAr
       for (int e = 0; e < 16; ++e) {
         const int k = k0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (k >= a.K) continue;
-        float* dst = a.DW + (((long long)k * a.R + r) * a.S + s_out) * a.C + cc;
-        if (!whole_tile) atomicAdd(dst, acc[i][j][e]);
-        else *dst = acc[i][j][e];
+        out[(((long long)k * a.R + r) * a.S + s_out) * a.C + cc] = acc[i][j][e];
       }
     }
   }
-  __syncthreads();   // the next segment re-uses the LDS stages
-  }  // stream-K segment loop
 }
 
 // dz[p'][k*R*S + r*S + s] = dy[p' - (r,s)][k]  (zero outside): with it the weight gradient of a conv with

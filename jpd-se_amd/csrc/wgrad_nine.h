@@ -47,8 +47,8 @@ static constexpr int kNineLoopLds = 3 * kNineStage + (kNineSlots + 1) * kNineSlo
 static constexpr int kNineRedLds = 4 * 9 * 16 * 64 * 4;                              // pixel-half reduction
 static constexpr int kNineLds = kNineLoopLds > kNineRedLds ? kNineLoopLds : kNineRedLds;
 
-// ABL (timing-only, JPDSE_DEV builds): 1 = no epilogue
-template <bool REFLECT, int ABL = 0>
+// SCHED: where the DMA issue of chunk t+2 sits in iteration t (see the loop).  ABL (timing-only): 1 = no epilogue
+template <bool REFLECT, int SCHED = 2, int ABL = 0>
 __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
   constexpr int NW = 8, BKP = 64, ROWB = 128;
   constexpr int A_STAGE = kNineStage, B_SLOT = kNineSlot, NSLOT = kNineSlots;
@@ -117,37 +117,43 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
   const int b_q = wid * 8 + pl;
   const int b_sw = c0 + ((slot16 ^ trswz<ROWB>(b_q)) << 3);       // swizzle depends on (q >> 1) & 1: the same for q + 64
   const int Wm1 = a.W - 1, Hm1 = a.H - 1;
-  // next dy chunk / next x row to issue: (n, strip, h) counters in SGPRs, advanced incrementally (no division in the loop)
-  int d_h, d_st, d_n;       // dy chunk cursor
-  int r_h, r_st, r_n;       // x row cursor; the row stream is indexed like the chunks: row g <-> (n, strip, h) of chunk g
+  // Cursors of the next dy chunk / next x row to issue: a 64-bit base pointer each (SGPR pair) advanced by precomputed
+  // deltas through selects -- no multiplication, division or branch per chunk (the first version spent ~100 scalar
+  // instructions and 8 branches per chunk behind the barrier, where they idle the matrix pipes of the whole CU).
+  // The row stream is indexed like the chunks: row g <-> (n, strip, h) of chunk g.
+  const long long d_row = (long long)a.W * a.Ks, d_strip = 64LL * a.Ks - (long long)a.H * a.W * a.Ks,
+                  d_img = -(long long)(a.strips - 1) * 64 * a.Ks;
+  const long long r_row = (long long)a.W * a.Cs, r_img_rows = (long long)a.H * a.W * a.Cs;
+  const bf16_t* d_ptr;
+  const bf16_t* r_ptr;      // first pixel of the input ROW (column 0), the strip's column offset is r_st * 64 - 1
+  int d_h, d_st, r_h, r_st, r_left;     // r_left: rows of the stream that still exist (past the end: stay on the last)
   {
-    const int ns0 = t0 / a.H, n0 = ns0 / a.strips;
-    d_n = __builtin_amdgcn_readfirstlane(n0);
-    d_st = __builtin_amdgcn_readfirstlane(ns0 - n0 * a.strips);
-    d_h = __builtin_amdgcn_readfirstlane(t0 - ns0 * a.H);
+    const int ns0 = t0 / a.H, n0 = ns0 / a.strips, st0 = ns0 - n0 * a.strips, h0 = t0 - ns0 * a.H;
+    d_st = __builtin_amdgcn_readfirstlane(st0);
+    d_h = __builtin_amdgcn_readfirstlane(h0);
+    d_ptr = a.DY + ((long long)(n0 * a.H + h0) * a.W + st0 * BKP) * a.Ks;
     const int g = t0 > 0 ? t0 - 1 : 0;        // the stream starts at row t0 - 1 (t0 = 0: that row is skipped below)
-    const int ns1 = g / a.H, n1 = ns1 / a.strips;
-    r_n = __builtin_amdgcn_readfirstlane(n1);
-    r_st = __builtin_amdgcn_readfirstlane(ns1 - n1 * a.strips);
-    r_h = __builtin_amdgcn_readfirstlane(g - ns1 * a.H);
+    const int ns1 = g / a.H, n1 = ns1 / a.strips, st1 = ns1 - n1 * a.strips, h1 = g - ns1 * a.H;
+    r_st = __builtin_amdgcn_readfirstlane(st1);
+    r_h = __builtin_amdgcn_readfirstlane(h1);
+    r_ptr = a.X + (long long)(n1 * a.H + h1) * a.W * a.Cs;
+    r_left = __builtin_amdgcn_readfirstlane(a.chunks_total - 1 - g);
   }
   int r_slot = __builtin_amdgcn_readfirstlane((t0 + NSLOT - 1) % NSLOT);     // slot of row g = g mod 5, g = t0 - 1
   int d_stage = 0;
 
   auto issue_dy = [&]() {
-    const bf16_t* const base = a.DY + ((long long)(d_n * a.H + d_h) * a.W + d_st * BKP) * a.Ks;
-    glds16(base + (unsigned)a_loff, smem + d_stage * A_STAGE + wid * 1024);
+    glds16(d_ptr + (unsigned)a_loff, smem + d_stage * A_STAGE + wid * 1024);
     d_stage = d_stage == 2 ? 0 : d_stage + 1;
-    if (++d_h == a.H) {
-      d_h = 0;
-      if (++d_st == a.strips) {
-        d_st = 0;
-        ++d_n;                                  // the caller never issues past chunk t1 - 1 <= the last chunk
-      }
-    }
+    // (n, strip, h) -> next chunk; the caller never issues past chunk t1 - 1 <= the last chunk
+    const bool wrap_h = d_h == Hm1;
+    const bool wrap_s = d_st == a.strips - 1;
+    d_ptr += d_row + (wrap_h ? (wrap_s ? d_img : d_strip) : 0LL);
+    d_h = wrap_h ? 0 : d_h + 1;
+    d_st = wrap_h ? (wrap_s ? 0 : d_st + 1) : d_st;
   };
   auto issue_row = [&]() {
-    const bf16_t* const row = a.X + ((long long)(r_n * a.H + r_h) * a.W) * a.Cs;
+    const bf16_t* const row = r_ptr;
     char* const dst = smem + B_BASE + r_slot * B_SLOT;
     const int col0 = r_st * BKP - 1;
     auto unit = [&](int q, int sw, int u) {
@@ -166,18 +172,21 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
     unit(b_q, b_sw, wid);
     if (wid == 0) {
       int l3 = lane >> 3;                       // rebuilt from the lane id in place (a hoisted copy is spilled and its
-      asm volatile("" : "+v"(l3));              // reload drains this wave's DMAs: see wgrad_row.h)
+      asm volatile("" : "+v"(l3));              // reload drains this wave's DMAs: see wgrad_thin.h / round-1 notes)
       const int q = 64 + l3;
       unit(q, c0 + (((lane & 7) ^ trswz<ROWB>(q)) << 3), 8);
     }
     r_slot = r_slot == NSLOT - 1 ? 0 : r_slot + 1;
-    if (++r_h == a.H) {                         // next row of the stream; past the last row of the tensor: stay on it
-      r_h = 0;                                  // (rows t1 .. t1 + 1 are issued but never consumed)
-      if (++r_st == a.strips) {
-        r_st = 0;
-        if (++r_n == a.N) { r_n = a.N - 1; r_st = a.strips - 1; r_h = Hm1; }
-      }
-    }
+    // next row of the stream; the rows after the tensor's last one (issued, never consumed) stay on the last row
+    const bool more = r_left > 0;
+    const bool wrap_h = r_h == Hm1;
+    const bool wrap_s = r_st == a.strips - 1;
+    // same strip: next image row; strip done: row 0 of the next strip of this image; image done: row 0 of the next image
+    const long long step = wrap_h ? (wrap_s ? r_row : r_row - r_img_rows) : r_row;
+    r_ptr += more ? step : 0LL;
+    r_h = more ? (wrap_h ? 0 : r_h + 1) : r_h;
+    r_st = more ? (wrap_h ? (wrap_s ? 0 : r_st + 1) : r_st) : r_st;
+    r_left -= more ? 1 : 0;
   };
 
   // ---- pipeline: group G_t = {dy(t), row(t+1)}; prologue G_t0 also carries rows t0-1 and t0 ------------
@@ -194,13 +203,26 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
   int c_stage = 0;
   int c_slot = __builtin_amdgcn_readfirstlane(t0 % NSLOT);       // slot of row t
   int c_h = __builtin_amdgcn_readfirstlane(t0 % a.H);
+
+  auto kstep = [&]<int KS>(uint32_t a_addr, const uint32_t (&boff)[3]) {
+    s16x8 af[1], bf[9];
+    af[0] = tr_frag_asm<KS * 16 * ROWB, KS * 16 * ROWB + 4 * ROWB>(a_addr);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        bf[r * 3 + s] = tr_frag_asm<KS * 16 * ROWB, KS * 16 * ROWB + 4 * ROWB>(b_rd[s] + boff[r]);
+    tr_wait(af);
+    tr_wait(bf);
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+      acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[t9], acc[t9], 0, 0, 0);
+  };
+
   for (int t = t0; t < t1; ++t) {
     if (t + 1 < t1) wait_vmcnt<2>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < t1) {
-      issue_dy();
-      issue_row();
-    }
+    const bool more = t + 2 < t1;
     // row slots of the three filter rows
     const int s_prev = c_slot == 0 ? NSLOT - 1 : c_slot - 1, s_next = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
     int off0 = s_prev * B_SLOT, off2 = s_next * B_SLOT;
@@ -213,24 +235,24 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
     }
     const uint32_t boff[3] = {(uint32_t)off0, (uint32_t)(c_slot * B_SLOT), (uint32_t)off2};
     const uint32_t a_addr = a_rd + c_stage * A_STAGE;
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      s16x8 af[1], bf[9];
-      af[0] = ks == 0 ? tr_frag_asm<0, 4 * ROWB>(a_addr) : tr_frag_asm<16 * ROWB, 20 * ROWB>(a_addr);
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-          bf[r * 3 + s] = ks == 0 ? tr_frag_asm<0, 4 * ROWB>(b_rd[s] + boff[r])
-                                  : tr_frag_asm<16 * ROWB, 20 * ROWB>(b_rd[s] + boff[r]);
-      tr_wait(af);
-      tr_wait(bf);
-#pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9)
-        acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[t9], acc[t9], 0, 0, 0);
+    // SCHED 0: DMA issue right behind the barrier (all 8 waves do scalar / address work while the matrix pipes idle);
+    // 1: between the two k-steps, under the first one's MFMAs; 2: the two waves of a SIMD (pixel halves) take turns --
+    // half 0 computes first and issues last, half 1 issues first: one of them feeds the matrix pipe while the other loads
+    if (SCHED == 0 || (SCHED == 2 && ph == 1)) {
+      if (more) { issue_dy(); issue_row(); }
     }
+    __builtin_amdgcn_s_setprio(1);
+    kstep.template operator()<0>(a_addr, boff);
+    if (SCHED == 1) {
+      __builtin_amdgcn_s_setprio(0);
+      if (more) { issue_dy(); issue_row(); }
+      __builtin_amdgcn_s_setprio(1);
+    }
+    kstep.template operator()<1>(a_addr, boff);
     __builtin_amdgcn_s_setprio(0);
+    if (SCHED == 2 && ph == 0) {
+      if (more) { issue_dy(); issue_row(); }
+    }
     c_stage = c_stage == 2 ? 0 : c_stage + 1;
     c_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
     c_h = c_h == Hm1 ? 0 : c_h + 1;

@@ -12,7 +12,8 @@
 // is formed by the per-lane addresses of ds_read_b64_tr_b16 (overlapping rows cost nothing).  dy is
 // staged as in wgrad_fast.h.  M = Ks (32*TM) output channels, N = S*Cs run columns in NW*NT 32-wide
 // tiles (wave w owns NT of them), reduction over the strip's 64 pixels per step; 2 LDS stages.
-// Blocks accumulate their strips in registers and add the result into the zeroed fp32 gradient.
+// Blocks accumulate their strips in registers and store the result into their pixel range's fp32 slab;
+// slab_reduce_kernel adds the slabs in a fixed order (round 1 used fp32 atomics into the zeroed gradient).
 //
 // RR > 1: one block handles RR filter rows (run strips of RR input rows next to ONE dy strip).
 // `transposed`: the roles are swapped for convs with <= 8 OUTPUT channels (the 64->3 / 32->3 heads):
@@ -30,9 +31,12 @@ namespace jpdse {
 struct ThinWgArgs {
   const bf16_t* XP;    // padded input [N][Hp][Wp][Cs]
   const bf16_t* DY;    // [N][OH][OW][Ks]
-  float* DW;           // fp32 KRSC
+  float* DW;           // fp32 KRSC (written by slab_reduce_kernel)
+  float* partial;      // [ranges][slab_stride] fp32: pixel range p stores its partial gradient into slab p (no atomics)
+  long long slab_stride;
   int N, OH, OW, Hp, Wp, Cs, C, Ks, K, R, S, st;
   int chunks_per_row, strips_total, strips_per_block;
+  int ranges, row_groups;   // grid = roundup(ranges, 8) * row_groups blocks, see launch_wgrad_thin_pitch
   int x_units;         // 1 KiB DMA units per input strip
   long long x_limit;   // elements of XP that may be read (tensor + zeroed slack)
   int transposed;
@@ -60,8 +64,13 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
   const uint32_t lds0 = lds_addr_of(smem);
-  const int r0 = blockIdx.y * RR;
-  const int s_begin = blockIdx.x * a.strips_per_block;
+  // 8 * row_groups consecutive blocks = 8 pixel ranges x all filter-row groups; block b and b + 8 (same XCD) = the
+  // same pixel range, next row group
+  const int grp = blockIdx.x / (8 * a.row_groups), within = blockIdx.x - grp * (8 * a.row_groups);
+  const int range = grp * 8 + (within & 7);
+  if (range >= a.ranges) return;
+  const int r0 = (within >> 3) * RR;
+  const int s_begin = range * a.strips_per_block;
   int s_end = s_begin + a.strips_per_block;
   s_end = s_end < a.strips_total ? s_end : a.strips_total;
   if (s_begin >= s_end) return;
@@ -249,9 +258,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
   }
 
   const int run = a.S * a.Cs;
+  float* const out = a.partial + (long long)range * a.slab_stride;
   if constexpr (TRANSPOSED) {
     // The gradient row of one (output channel c, tap) is the M = a.K contiguous floats of the conv's input
-    // channels: transpose each filter row's tile through LDS so that one atomic instruction covers a
+    // channels: transpose each filter row's tile through LDS so that one store instruction covers a
     // contiguous row instead of 64 scattered cache lines.
     constexpr int MROWS = 32 * TM * WM, COLS = 32 * WN * NT, TPITCH = MROWS + 1;
     float* const tbuf = reinterpret_cast<float*>(smem);
@@ -276,8 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
         const int k = idx % MROWS, sc = idx / MROWS;
         const int s_out = sc / a.C, c = sc - s_out * a.C;
         if (k >= a.K) continue;
-        atomicAdd(a.DW + (((long long)c * a.R + (a.R - 1 - r)) * a.S + (a.S - 1 - s_out)) * a.K + k,
-                  tbuf[(s_out * a.Cs + c) * TPITCH + k]);
+        out[(((long long)c * a.R + (a.R - 1 - r)) * a.S + (a.S - 1 - s_out)) * a.K + k] = tbuf[(s_out * a.Cs + c) * TPITCH + k];
       }
     }
     return;
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
         for (int e = 0; e < 16; ++e) {
           const int k = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
           if (k >= a.K) continue;
-          atomicAdd(a.DW + (((long long)k * a.R + r) * a.S + s_out) * a.C + c, acc[rr][i][j][e]);
+          out[(((long long)k * a.R + r) * a.S + s_out) * a.C + c] = acc[rr][i][j][e];
         }
       }
     }

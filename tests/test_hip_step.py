@@ -82,7 +82,10 @@ def _check_grads(tr, ora, xd, what):
   (north_star) where the problem is well conditioned; the L1 terms (distortion, D-feature and
   VGG matching) have sign() gradients, so on larger tensors two correct fp32 implementations
   differ by ~2*sqrt(fraction of flipped signs).  The yardstick is therefore the fp64 oracle:
-  HIP must be as close to it as the fp32 torch-CPU oracle is, within a factor 4."""
+  HIP must be as close to it as the fp32 torch-CPU oracle is, within a factor 2 (measured on MI355X,
+  gpurun_out of round 2: 0.23 .. 1.40 -- at full width the HIP path, with its two-level fp32 summation, is 4x CLOSER
+  to fp64 than torch-CPU fp32, which is why most tensors there miss the direct 1e-3 bound: the oracle is the noisier
+  of the two).  The report of which tensors took which route is printed (pytest -rA / -s shows it)."""
   g32, d32 = ora.grads_in_dtype(xd, torch.float32)
   g64, d64 = ora.grads_in_dtype(xd, torch.float64)
   report = []
@@ -93,7 +96,7 @@ def _check_grads(tr, ora, xd, what):
       direct = rel_err(p.grad.cpu(), r32[k])
       e_hip, e_t32 = _l2rel(p.grad.cpu(), r64[k]), _l2rel(r32[k], r64[k])
       report.append((k, direct, e_hip, e_t32))
-      assert direct <= GRAD_TOL or e_hip <= max(GRAD_TOL, 4.0 * e_t32), \
+      assert direct <= GRAD_TOL or e_hip <= max(GRAD_TOL, 2.0 * e_t32), \
           '%s grad %s: vs oracle-fp32 %.2e; vs fp64 HIP %.2e, torch-fp32 %.2e' % (what, k, direct, e_hip, e_t32)
   # which tensors needed the fp64 yardstick, and by how much (visible with -s / in the failure output)
   escaped = [r for r in report if r[1] > GRAD_TOL]
@@ -102,9 +105,6 @@ def _check_grads(tr, ora, xd, what):
   for k, direct, e_hip, e_t32 in escaped:
     print('   %-40s direct %.2e | vs fp64: HIP %.2e, torch-fp32 %.2e (ratio %.2f)' % (k, direct, e_hip, e_t32,
                                                                                      e_hip / max(e_t32, 1e-30)))
-  # the escape is for the few sign()-conditioned tensors, not a blanket pass: most must meet the direct bound, and
-  # none may be more than 2.5x further from fp64 than torch's own fp32 (bound 4x above; measured <= 1.6x)
-  assert len(escaped) <= max(2, len(report) // 3), '%s: %d of %d tensors needed the fp64 escape' % (what, len(escaped), len(report))
   return report
 
 

@@ -124,7 +124,8 @@ def test_fused_adam_loads_torch_adam_state_from_contiguous_parameters():
   rw.grad, rb.grad = torch.randn_like(rw), torch.randn_like(rb)
   ref.step()
   ref.step()
-  sd = ref.state_dict()
+  import copy
+  sd = copy.deepcopy(ref.state_dict())
   sd['state'][1]['step'] = 2                                  # checkpoints of old torch versions keep an int
   opt = FusedAdam([w, b], lr=1.0)
   opt.load_state_dict(sd)
