@@ -1211,14 +1211,14 @@ static int g_halo_single = 1;
 static int g_halo_enabled = 1;
 static int g_halo_abl = 0;
 
-template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false>
+template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false>
 static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   constexpr int BN = 2 * TN * 32;
   constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
   constexpr int lds = (SINGLE ? 1 : 2) * UH * 1024 + 3 * BN * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -1229,7 +1229,7 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16>), dim3(tiles), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG>), dim3(tiles), dim3(512), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
@@ -1239,6 +1239,7 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
 }
 
 static int g_halo_xcd = 0;
+static int g_halo_stag = 0;      // 23: waves 4..7 issue their DMA group after the MFMA cluster (A/B)
 static int g_halo_mf16 = 0;     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
 template <int TN, int ABL = 0>
 static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
@@ -1249,6 +1250,7 @@ static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
     return launch_halo_cfg_impl<TN, 0, false, true>(a, s);
   }
   if (a.Cs == 64 && ABL == 0 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true>(a, s);   // one slab: single patch buffer
+  if (ABL == 0 && g_halo_stag) return launch_halo_cfg_impl<TN, 0, false, false, true>(a, s);
   return launch_halo_cfg_impl<TN, ABL, false>(a, s);
 }
 
@@ -2527,7 +2529,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
-  g_halo_mf16 = enable == 19;         // 19: halo kernel on 16x16x32 MFMAs (A/B)
+  g_halo_mf16 = enable == 19;
+  g_halo_stag = enable == 23;         // 19: halo kernel on 16x16x32 MFMAs (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_head_fwd_enabled = enable != 14 && enable != 6;   // 14: heads on the Toeplitz GEMM (A/B); 6 keeps the generic order
   g_thin_fwd_enabled = enable != 18;  // 18: thin-input forward on the generic kernel (A/B)

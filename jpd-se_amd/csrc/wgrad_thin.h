@@ -144,19 +144,24 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_thin_kernel(const ThinWgAr
   const int a_lane_off = a_pl * a.Ks + a_slot_off;
   constexpr int CS = PITCH == 80 ? 40 : PITCH;        // channel storage when the pitch is a compile-time constant
   static_assert(A_PPU % 4 == 0 || A_ROWB >= 256, "swizzle must not depend on the unit index");
-  // strips are issued in order: their coordinates advance incrementally (wave-uniform, no division per strip)
-  int i_chunk = __builtin_amdgcn_readfirstlane(s_begin % a.chunks_per_row);
-  int i_row = __builtin_amdgcn_readfirstlane(s_begin / a.chunks_per_row);       // n*OH + oh
-  int i_oh = __builtin_amdgcn_readfirstlane(i_row % a.OH);
-  int i_n = __builtin_amdgcn_readfirstlane(i_row / a.OH);
+  // Strips are walked DOWN the image: strip index = (n * chunks_per_row + chunk column) * OH + oh.  The block of filter
+  // row r reads input row oh*st + r, which the block of row r - st (same pixel range, same XCD, see the launcher) reads
+  // one strip later: with the row-major order of round 1 that reuse was a whole image row of strips apart, further than
+  // the XCD's L2 reaches, and every filter row re-fetched the input (7x on the first 7x7 conv).
+  // Coordinates advance incrementally (wave-uniform, no division per strip).
+  int i_oh = __builtin_amdgcn_readfirstlane(s_begin % a.OH);
+  int i_chunk = __builtin_amdgcn_readfirstlane((s_begin / a.OH) % a.chunks_per_row);
+  int i_n = __builtin_amdgcn_readfirstlane((s_begin / a.OH) / a.chunks_per_row);
+  int i_row = __builtin_amdgcn_readfirstlane(i_n * a.OH + i_oh);                  // n*OH + oh
   auto issue = [&](int /*strip*/, int stage) {
     char* const st = smem + stage * stage_bytes;
     const int row = i_row, oh = i_oh, n = i_n;
     const int ow0 = i_chunk * 64;
-    if (++i_chunk == a.chunks_per_row) {
-      i_chunk = 0;
-      ++i_row;
-      if (++i_oh == a.OH) { i_oh = 0; ++i_n; }
+    ++i_row;
+    if (++i_oh == a.OH) {
+      i_oh = 0;
+      i_row -= a.OH;
+      if (++i_chunk == a.chunks_per_row) { i_chunk = 0; ++i_n; i_row += a.OH; }
     }
     const bf16_t* const dy_base = a.DY + ((long long)row * a.OW + ow0) * a.Ks;                       // uniform
     const long long x_base = (((long long)n * a.Hp + oh * a.st + r0) * a.Wp + (long long)ow0 * a.st) * a.Cs;
