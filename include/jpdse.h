@@ -59,18 +59,12 @@ int jpdse_arch_check(int device);
  * jpdse_prof_collect waits for them and returns the summed kernel time, the summed algorithmic
  * FLOPs (2*M*Ks*kdim per launch) and the number of launches, then resets the log.
  * Not thread safe; select with enable = 0 to switch it off. */
-/* Developer A/B switch for tests and benchmarks (kernel SELECTION only, results stay correct except for
- * the timing-only ablation codes >= 100): 0 = every convolution on the generic register-staged
- * kernels; 1 (default) = all specialised bf16 kernels; 3 = no halo kernel; 4 = no per-filter-row
- * weight gradient; 5 = heads without the Toeplitz GEMM; 6 = no split-K and no head kernel (same
- * summation order as the generic kernels: bit-comparable); 7 = reflect data gradient on the padded
- * domain; 8 = halo kernel always double buffered; 9 / 10 = long-K-only phase merging / no 128-row
- * tiles; 12 = no all-taps weight gradient; 13 = no tap-sum forward; 14 = no head kernel;
- * 15 / 16 = XCD-aware halo tile orders; 18 = no thin-input forward kernel; 19 = halo kernel on
- * 16x16x32 MFMA fragments.  Each call resets the others to their defaults. */
-int jpdse_debug_set_fast_path(int32_t enable);
 int jpdse_prof_select(int32_t enable, int32_t Ks, int64_t kdim, int32_t max_launches);
 int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
+/* The same sums for the other regions of the selected layer, WITHOUT resetting the log (call before jpdse_prof_collect):
+ * cls 1 = the ring-strip GEMMs + fold of the reflect-padded data gradient (time only, their FLOPs belong to the data
+ * gradient counted in class 0), cls 2 = the weight-gradient launches (K == Ks, 9 * CPAD(C) == kdim). */
+int jpdse_prof_collect_class(int32_t cls, double* total_ms, double* total_flops, int64_t* launches);
 
 /* ---- convolution family ------------------------------------------------------------- */
 /* One descriptor covers nn.Conv2d as used by:

@@ -19,6 +19,17 @@
 
 #include <vector>
 
+// Kernel-selection switches (which of two correct kernels runs) and timing-only ablations are DEVELOPER tools: in the
+// shipped library (libjpdse_hip.so) they are compile-time constants -- no mutable global state behind the ABI besides the
+// init-once launch attributes and the opt-in kernel timer -- and the ablation kernels are not even instantiated.  The
+// developer build (libjpdse_hip_dev.so, -DJPDSE_DEV, include/jpdse_dev.h) makes them run-time variables behind
+// jpdse_debug_set_fast_path for same-process A/B measurements and for the tests that compare two kernels of one layer.
+#ifdef JPDSE_DEV
+#define JPDSE_SWITCH(type, name, value) static type name = value
+#else
+#define JPDSE_SWITCH(type, name, value) static constexpr type name = value
+#endif
+
 namespace jpdse {
 
 // =========================================================================================
@@ -901,8 +912,9 @@ static void phase_axis(int st, int q, int Rf, int lo, int hi, int& U, int& i0, i
 
 // Split-K factor of the fast 256x128 kernel for a GEMM of M rows, Ks output channels and k_tiles
 // 64-wide K-tiles: only when the tiles alone would leave most of the 256 CUs idle.
-static int g_splitk_enabled = 1, g_toep_enabled = 1;   // A/B switches (jpdse_debug_set_fast_path 6 / 5)
-static int g_thin_out_fast = 1;
+JPDSE_SWITCH(int, g_splitk_enabled, 1);   // A/B switches (jpdse_debug_set_fast_path 6 / 5)
+JPDSE_SWITCH(int, g_toep_enabled, 1);
+JPDSE_SWITCH(int, g_thin_out_fast, 1);
 static int splitk_for(int M, int Ks, int k_tiles) {
   if (!g_splitk_enabled) return 1;
   // narrow outputs (Ks <= 32: the 512 -> 1 PatchGAN map) only with long reductions
@@ -1014,8 +1026,22 @@ struct GemmProf {
   int used = 0;
   std::vector<hipEvent_t> ev;   // 2 per launch
   std::vector<double> flops;
+  std::vector<int> cls;         // 0: forward / data-gradient GEMM; 1: reflect ring strips + fold; 2: weight gradient
 };
 static GemmProf g_prof;
+// regions other than the plain GEMM launches (which record in place): returns the slot or -1
+static int prof_begin(hipStream_t s) {
+  if (!g_prof.on || (size_t)(2 * g_prof.used + 2) > g_prof.ev.size()) return -1;
+  (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  return g_prof.used;
+}
+static void prof_end(int slot, int cls, double flops, hipStream_t s) {
+  if (slot < 0) return;
+  (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
+  g_prof.flops[slot] = flops;
+  g_prof.cls[slot] = cls;
+  g_prof.used = slot + 1;
+}
 
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_fwd_cfg(const GemmFwdArgs& a, hipStream_t s) {
@@ -1029,6 +1055,7 @@ static int launch_fwd_cfg(const GemmFwdArgs& a, hipStream_t s) {
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
+    g_prof.cls[g_prof.used] = 0;
     ++g_prof.used;
   }
   return check_launch("gemm_fwd_kernel");
@@ -1112,6 +1139,16 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
       return set_error(JPDSE_EINVAL, "gemm_fast: problem %d has no output buffer", i);
     if ((a.x_sh ? a.x_sh : (long long)a.IW * a.Cs) * a.IH >= (1LL << 31))
       return set_error(JPDSE_EINVAL, "gemm_fast: one image spans >= 2^31 elements (in-image offsets are 32-bit)");
+    if (a.x_extent > 0 && a.OH > 0 && a.OW > 0) {
+      // sub-image problems (the ring strips of the reflect data gradient address rows / columns of a larger tensor through
+      // x_sn / x_sh): the last element the loader can touch must lie inside the tensor -- a wrong stride or base here is
+      // a GPU memory fault, not a wrong number (the round-1 abort)
+      const long long n_img = a.M / ((long long)a.OH * a.OW);
+      const long long sn = a.x_sn ? a.x_sn : (long long)a.IH * a.IW * a.Cs, sh = a.x_sh ? a.x_sh : (long long)a.IW * a.Cs;
+      const long long last = (n_img - 1) * sn + (long long)(a.IH - 1) * sh + (long long)(a.IW - 1) * a.Cs + a.Cs;
+      if (n_img < 1 || last > a.x_extent)
+        return set_error(JPDSE_EINVAL, "gemm_fast: problem %d addresses element %lld of a %lld-element input", i, last, a.x_extent);
+    }
     b.first_tile[i] = total;
     total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN) * (a.splits > 1 ? a.splits : 1);
     const long long kdim = (long long)a.R * a.S * a.Cs;
@@ -1128,6 +1165,7 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = flops;
+    g_prof.cls[g_prof.used] = 0;
     ++g_prof.used;
   }
   return check_launch("gemm_fast_kernel");
@@ -1143,7 +1181,7 @@ static bool prefer_320(int M, int Ks) {
   return c320 < c256;
 }
 
-static int g_fast_small = 20;      // K-tile count up to which the 128-row / 2-stage fast configs are used
+JPDSE_SWITCH(int, g_fast_small, 20);      // K-tile count up to which the 128-row / 2-stage fast configs are used
 static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   if (b.n <= 0) return JPDSE_OK;
   const int Ks = b.p[0].Ks;
@@ -1179,7 +1217,7 @@ static int launch_fast(const FastArgs& a, hipStream_t s) {
   return launch_fast_batch(b, s);
 }
 
-static bool g_fast_enabled = true;   // jpdse_debug_set_fast_path(0) forces the generic kernels (A/B tests)
+JPDSE_SWITCH(bool, g_fast_enabled, true);   // jpdse_debug_set_fast_path(0) forces the generic kernels (A/B tests)
 
 // The fast kernel runs ONE 256-row tile per CU (144 KiB of LDS), so its grid should either cover
 // the 256 CUs many times over or be an exact multiple of them; in between (e.g. the 288 tiles of the
@@ -1205,11 +1243,11 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
   return tiles >= 448 || (tiles >= 256 && tiles % 256 == 0);
 }
 
-static int g_ring_enabled = 1;
-static int g_merge_min_kt = 4;
-static int g_halo_single = 1;
-static int g_halo_enabled = 1;
-static int g_halo_abl = 0;
+JPDSE_SWITCH(int, g_ring_enabled, 1);
+JPDSE_SWITCH(int, g_merge_min_kt, 4);
+JPDSE_SWITCH(int, g_halo_single, 1);
+JPDSE_SWITCH(int, g_halo_enabled, 1);
+JPDSE_SWITCH(int, g_halo_abl, 0);
 
 template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false>
 static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
@@ -1233,24 +1271,27 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
+    g_prof.cls[g_prof.used] = 0;
     ++g_prof.used;
   }
   return check_launch("gemm_halo_kernel");
 }
 
-static int g_halo_xcd = 0;
-static int g_halo_stag = 0;      // 23: waves 4..7 issue their DMA group after the MFMA cluster (A/B)
-static int g_halo_mf16 = 0;     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
+JPDSE_SWITCH(int, g_halo_xcd, 0);
+JPDSE_SWITCH(int, g_halo_stag, 0);      // 23: waves 4..7 issue their DMA group after the MFMA cluster (A/B)
+JPDSE_SWITCH(int, g_halo_mf16, 0);     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
 template <int TN, int ABL = 0>
 static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
   HaloArgs a = a0;
   a.xcd_mode = g_halo_xcd;
+#ifdef JPDSE_DEV
   if (ABL == 0 && g_halo_mf16) {
     if (a.Cs == 64 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, true>(a, s);
     return launch_halo_cfg_impl<TN, 0, false, true>(a, s);
   }
-  if (a.Cs == 64 && ABL == 0 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true>(a, s);   // one slab: single patch buffer
   if (ABL == 0 && g_halo_stag) return launch_halo_cfg_impl<TN, 0, false, false, true>(a, s);
+#endif
+  if (a.Cs == 64 && ABL == 0 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true>(a, s);   // one slab: single patch buffer
   return launch_halo_cfg_impl<TN, ABL, false>(a, s);
 }
 
@@ -1295,7 +1336,7 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ Z
   y[idx] = f2bf(v);
 }
 
-static int g_thin_fwd_enabled = 1;
+JPDSE_SWITCH(int, g_thin_fwd_enabled, 1);
 // geometry of the thin forward kernel for a layer: TH output rows per block (8, or 4 for stride 2 / when LDS is short)
 struct ThinFwdGeom { int TH, TW, strip_units, w_units, lds; };
 static bool thin_fwd_geom(const jpdse_conv_desc* d, const ConvPlan& p, ThinFwdGeom* g) {
@@ -1332,7 +1373,7 @@ static int launch_thin_fwd(const ThinFwdArgs& a, int lds, hipStream_t s) {
   return check_launch("thin_fwd_kernel");
 }
 
-static int g_head_fwd_enabled = 1;
+JPDSE_SWITCH(int, g_head_fwd_enabled, 1);
 static bool head_fwd_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
   const int ncols = d->K * d->R * d->S;
   return g_fast_enabled && g_head_fwd_enabled && p.ES == 2 && d->stride == 1 && d->K <= 3 && p.Ks == 8 &&
@@ -1353,7 +1394,7 @@ static int launch_head_fwd(const HeadFwdArgs& a, hipStream_t s) {
   return check_launch("head_fwd_kernel");
 }
 
-static int g_tapsum_enabled = 1;
+JPDSE_SWITCH(int, g_tapsum_enabled, 1);
 static bool tapsum_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
   return g_fast_enabled && g_tapsum_enabled && p.ES == 2 && d->stride == 1 && d->K * d->R * d->S <= 32 &&
          p.Cs % 64 == 0 && p.Cs >= 256 && p.Lk_fwd == d->S * p.Cs;
@@ -1470,6 +1511,7 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       h.out_base = 0;
       h.act = d->act;
       h.slope = d->slope;
+#ifdef JPDSE_DEV
       if (g_halo_abl && p.Ks > 64) {      // timing-only ablations (scripts/bench_conv.py --fast 11..)
         switch (g_halo_abl) {
           case 1: return launch_halo_cfg<2, 1>(h, s);
@@ -1484,6 +1526,7 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
           default: break;
         }
       }
+#endif
       return p.Ks > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
     }
     if (p.Cs % 64 == 0 && fast_pays(d->N * p.OH * p.OW, p.Ks, d->R * d->S * p.Cs / 64)) {
@@ -1770,6 +1813,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         g.X = dyb + (q == 1 ? (long long)(H - 1) * W * Ks : (q == 3 ? (long long)(W - 1) * Ks : 0));
         g.x_sn = (long long)H * W * Ks;
         g.x_sh = (long long)W * Ks;
+        g.x_extent = (long long)d->N * H * W * Ks - (g.X - dyb);
         g.IH = row_strip ? 1 : H;
         g.IW = row_strip ? W : 1;
         g.Cs = Ks;
@@ -1795,6 +1839,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         g.partial = slab + (q == 0 ? 0 : (q == 1 ? tb_elems : (q == 2 ? 2 * tb_elems : 2 * tb_elems + lr_elems)));
         rb.p[rb.n++] = g;
       }
+      const int pslot = (p.Cs == g_prof.Ks && 9LL * p.Ks == g_prof.kdim) ? prof_begin(s) : -1;
       if (int rc = launch_fast_batch(rb, s)) return rc;
       // (3) fold the ring into rows 1 / H-2 and columns 1 / W-2 of dx
       RingFoldArgs rf = {};
@@ -1817,6 +1862,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
                            reinterpret_cast<const T*>(mask), total_vec);
         rc = check_launch("relu_mask_kernel");
       }
+      prof_end(pslot, 1, 0.0, s);
       return rc;
     }
   }
@@ -2105,7 +2151,7 @@ static int launch_wgrad_thin(const ThinWgArgs& a, hipStream_t s) {
 
 // ---- all-taps weight gradient of the narrow high-resolution layers (wgrad_taps.h) -----------------
 // config id: 0 none; 1: 3x3 s2 K%128 C%64; 2: 3x3 s1 K%64 C%64; 3: 4x4 s2 K%128 C%64; 4: 3x3 s2 K%256 C%128
-static int g_wgrad_taps_enabled = 1;
+JPDSE_SWITCH(int, g_wgrad_taps_enabled, 1);
 static int wgrad_taps_cfg(const jpdse_conv_desc* d, const ConvPlan& p) {
   if (!g_fast_enabled || !g_wgrad_taps_enabled || p.ES != 2 || d->R != d->S) return 0;
   if ((long long)d->N * p.OH * ((p.OW + 63) / 64) < 32) return 0;
@@ -2205,7 +2251,7 @@ static int launch_wgrad_taps(const jpdse_conv_desc* d, const ConvPlan& p, int cf
 }
 
 // ---- all-nine-taps weight gradient of the wide 3x3 stride-1 layers (wgrad_nine.h): no atomics, no partial tiles ----
-static int g_wgrad_nine_enabled = 1;
+JPDSE_SWITCH(int, g_wgrad_nine_enabled, 1);
 static bool wgrad_nine_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
   return g_fast_enabled && g_wgrad_nine_enabled && p.ES == 2 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
          p.OW % 64 == 0 && p.Ks % 64 == 0 && p.Cs % 64 == 0 && d->H >= 2 && d->W >= 8 &&
@@ -2238,7 +2284,7 @@ static size_t wgrad_nine_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
   return a.splits > 1 ? (size_t)a.splits * d->K * 9 * d->C * sizeof(float) : 0;
 }
 
-static int g_nine_sched = 2;
+JPDSE_SWITCH(int, g_nine_sched, 2);
 template <bool REFLECT, int SCHED>
 static int launch_wgrad_nine_cfg(const NineWgArgs& a, hipStream_t s) {
   static bool configured = false;
@@ -2249,13 +2295,15 @@ static int launch_wgrad_nine_cfg(const NineWgArgs& a, hipStream_t s) {
     configured = true;
   }
   const int blocks = a.k_tiles * a.c_tiles * a.splits;
+  const int pslot = (a.Ks == g_prof.Ks && 9LL * a.Cs == g_prof.kdim) ? prof_begin(s) : -1;
   hipLaunchKernelGGL((wgrad_nine_kernel<REFLECT, SCHED, 0>), dim3(blocks), dim3(512), kNineLds, s, a);
   if (int rc = check_launch("wgrad_nine_kernel")) return rc;
   if (a.splits > 1) {
     const long long n4 = (long long)a.K * 9 * a.C / 4;
     hipLaunchKernelGGL(wgrad_nine_reduce_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, a.partial, a.DW, n4, a.splits);
-    return check_launch("wgrad_nine_reduce_kernel");
+    if (int rc = check_launch("wgrad_nine_reduce_kernel")) return rc;
   }
+  prof_end(pslot, 2, 2.0 * (double)a.N * a.H * a.W * (double)a.Ks * 9.0 * (double)a.Cs, s);
   return JPDSE_OK;
 }
 
@@ -2277,8 +2325,10 @@ static int launch_wgrad_nine(const jpdse_conv_desc* d, const ConvPlan& p, const 
   if (a.splits > 1 && ((long long)d->K * 9 * d->C) % 4 != 0)
     return set_error(JPDSE_EINVAL, "wgrad_nine: K*9*C = %lld is not a multiple of 4", (long long)d->K * 9 * d->C);
   if (d->pad_mode != JPDSE_PAD_REFLECT) return launch_wgrad_nine_cfg<false, 2>(a, s);
+#ifdef JPDSE_DEV
   if (g_nine_sched == 0) return launch_wgrad_nine_cfg<true, 0>(a, s);
   if (g_nine_sched == 1) return launch_wgrad_nine_cfg<true, 1>(a, s);
+#endif
   return launch_wgrad_nine_cfg<true, 2>(a, s);
 }
 
@@ -2517,6 +2567,7 @@ int jpdse_conv_out_shape(const jpdse_conv_desc* d, int32_t* OH, int32_t* OW) {
   return JPDSE_OK;
 }
 
+#ifdef JPDSE_DEV
 int jpdse_debug_set_fast_path(int32_t enable) {
   // 0: generic kernels only; 1: fast kernels (default schedule 0); 2: fast kernels, alternative schedule 1
   g_fast_enabled = enable != 0;
@@ -2540,6 +2591,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
   return JPDSE_OK;
 }
+#endif
 
 int jpdse_prof_select(int32_t enable, int32_t Ks, int64_t kdim, int32_t max_launches) {
   g_prof.on = false;
@@ -2552,16 +2604,18 @@ int jpdse_prof_select(int32_t enable, int32_t Ks, int64_t kdim, int32_t max_laun
     g_prof.ev.push_back(e);
   }
   g_prof.flops.assign(max_launches, 0.0);
+  g_prof.cls.assign(max_launches, 0);
   g_prof.Ks = Ks;
   g_prof.kdim = kdim;
   g_prof.on = true;
   return JPDSE_OK;
 }
 
-int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
-  JPDSE_REQUIRE(total_ms && total_flops && launches, "prof_collect: null output");
+static int prof_sum(int cls, double* total_ms, double* total_flops, int64_t* launches) {
   double ms = 0.0, fl = 0.0;
+  int64_t n = 0;
   for (int i = 0; i < g_prof.used; ++i) {
+    if (g_prof.cls[i] != cls) continue;
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess)
       return set_error(JPDSE_ELAUNCH, "prof_collect: hipEventSynchronize failed");
     float t = 0.f;
@@ -2569,12 +2623,24 @@ int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches)
       return set_error(JPDSE_ELAUNCH, "prof_collect: hipEventElapsedTime failed");
     ms += t;
     fl += g_prof.flops[i];
+    ++n;
   }
   *total_ms = ms;
   *total_flops = fl;
-  *launches = g_prof.used;
-  g_prof.used = 0;
+  *launches = n;
   return JPDSE_OK;
+}
+
+int jpdse_prof_collect_class(int32_t cls, double* total_ms, double* total_flops, int64_t* launches) {
+  JPDSE_REQUIRE(total_ms && total_flops && launches && cls >= 0 && cls <= 2, "prof_collect_class: bad argument");
+  return prof_sum(cls, total_ms, total_flops, launches);
+}
+
+int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
+  JPDSE_REQUIRE(total_ms && total_flops && launches, "prof_collect: null output");
+  const int rc = prof_sum(0, total_ms, total_flops, launches);
+  g_prof.used = 0;
+  return rc;
 }
 
 int jpdse_conv_plan_query(const jpdse_conv_desc* d, int32_t* out, int32_t n) {

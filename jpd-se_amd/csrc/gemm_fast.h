@@ -48,6 +48,7 @@ struct FastArgs {
   long long b_stride;
   int b_tap_r, b_tap_s;
   int no_finish;       // split-K: leave the slabs to the caller (no splitk_finish_kernel)
+  long long x_extent;  // elements readable from X (0 = not given): the launcher refuses a problem whose last pixel lies beyond
 };
 
 // Up to 4 independent problems in one launch (the stride-2 sub-pixel phases of a data gradient /

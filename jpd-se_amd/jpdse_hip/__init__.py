@@ -54,9 +54,9 @@ SIGNATURES = {
     'jpdse_version': (_I32, []),
     'jpdse_last_error': (ctypes.c_char_p, []),
     'jpdse_arch_check': (_I32, [_I32]),
-    'jpdse_debug_set_fast_path': (_I32, [_I32]),
     'jpdse_prof_select': (_I32, [_I32, _I32, _I64, _I32]),
     'jpdse_prof_collect': (_I32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64)]),
+    'jpdse_prof_collect_class': (_I32, [_I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64)]),
     'jpdse_conv_out_shape': (_I32, [_CD, ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
     'jpdse_conv_plan_query': (_I32, [_CD, ctypes.POINTER(_I32), _I32]),
     'jpdse_conv_fwd_pack_size': (_SZ, [_CD]),
@@ -106,7 +106,55 @@ SIGNATURES = {
     'jpdse_adam_step': (_I32, [_P, _I32, _I64, _F, _F, _F, _F, _I32, _F, _P]),
 }
 
+# the developer build (same sources, -DJPDSE_DEV): the shipped ABI plus include/jpdse_dev.h
+DEV_LIB_PATH = os.path.join(_HERE, 'libjpdse_hip_dev.so')
+DEV_SIGNATURES = {'jpdse_debug_set_fast_path': (_I32, [_I32])}
+
 _lib = None
+_dev = None
+
+
+def _load(path, signatures):
+  handle = ctypes.CDLL(path)
+  for name, (res, args) in signatures.items():
+    fn = getattr(handle, name)   # AttributeError here == ABI/header drift: fail loudly
+    fn.restype, fn.argtypes = res, args
+  return handle
+
+
+class dev_mode(object):
+  """Developer / test tool: run the enclosed calls on libjpdse_hip_dev.so with kernel-selection mode `mode`
+  (include/jpdse_dev.h: e.g. 0 = generic kernels only, 6 = no split-K, 19 = 16x16x32 MFMA halo variant).  The shipped
+  library has no such switch; on exit the binding is back on it.  Not re-entrant, single threaded."""
+
+  def __init__(self, mode):
+    self.mode = int(mode)
+
+  def __enter__(self):
+    global _lib, _dev
+    import torch  # noqa: F401
+    lib()
+    if _dev is None:
+      if not os.path.isfile(DEV_LIB_PATH):
+        raise JpdseError('libjpdse_hip_dev.so not found at %s -- build it with `make -C jpd-se_amd/csrc`' % DEV_LIB_PATH)
+      sig = dict(SIGNATURES)
+      sig.update(DEV_SIGNATURES)
+      _dev = _load(DEV_LIB_PATH, sig)
+    self._saved = _lib
+    _lib = _dev
+    check(_dev.jpdse_debug_set_fast_path(self.mode), 'jpdse_debug_set_fast_path')
+    return _dev
+
+  def __exit__(self, *exc):
+    global _lib
+    _dev.jpdse_debug_set_fast_path(1)
+    _lib = self._saved
+    return False
+
+
+def set_dev_mode(mode):
+  """Scripts: switch the binding to the developer build for the rest of the process, in kernel-selection mode `mode`."""
+  dev_mode(mode).__enter__()
 
 
 def lib():
@@ -120,11 +168,7 @@ def lib():
       raise JpdseError(
           'libjpdse_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
           'g.build()"` or `make -C jpd-se_amd/csrc`.  There is no CPU/torch fallback.' % LIB_PATH)
-    handle = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-      fn = getattr(handle, name)   # AttributeError here == ABI/header drift: fail loudly
-      fn.restype, fn.argtypes = res, args
-    _lib = handle
+    _lib = _load(LIB_PATH, SIGNATURES)
   return _lib
 
 

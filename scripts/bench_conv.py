@@ -67,7 +67,7 @@ print('%-34s %10s %10s %10s   (TFLOP/s, ms)' % ('layer', 'fwd', 'dgrad', 'wgrad'
 for (name, H, W, C, K, k, st, pad, mode, tr) in LAYERS:
   if args.filter and args.filter not in name: continue
   for fm in modes:
-   lib().jpdse_debug_set_fast_path(fm)
+   jpdse_hip.set_dev_mode(fm)
    layer = HipConv2d(C, K, k, st, pad, mode, apply_bias=False, transposed=tr, dtype=BF16, device=dev)
    name_m = '%s [m%d]' % (name[:28], fm)
    _bench_one(name_m, layer, H, W, C, K, k, tr)

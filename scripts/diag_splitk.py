@@ -3,6 +3,7 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'jpd-se_amd'))
 import torch
+import jpdse_hip
 from jpdse_hip import lib, BF16, PAD_ZERO, PAD_REFLECT, ACT_NONE
 from jpdse_hip.layers import HipConv2d
 from jpdse_hip.ops import Act
@@ -14,12 +15,12 @@ for (N, H, W, C, K, k, st, pad, mode) in [(2, 8, 16, 1024, 1024, 3, 1, 1, PAD_RE
   x = Act(torch.randn(N, H, W, C, device=dev).bfloat16(), C)
   out = {}
   for m in (1, 6, 0):
-    lib().jpdse_debug_set_fast_path(m)
+    jpdse_hip.set_dev_mode(m)
     y, ctx = layer.fwd(x)
     dy = Act((torch.arange(y.t.numel(), device=dev).reshape(y.t.shape) % 7 - 3).bfloat16(), y.C)
     dx = layer.bwd(ctx, dy, True, False)
     out[m] = (y.t.float().clone(), dx.t.float().clone())
-  lib().jpdse_debug_set_fast_path(1)
+  jpdse_hip.set_dev_mode(1)
   for m in (1, 6):
     for i, nm in enumerate(('fwd', 'dgrad')):
       a, b = out[m][i], out[0][i]

@@ -24,7 +24,7 @@ from jpdse_hip import lib, ops
 from ctu.trainers import get_trainer
 from ctu.utils.synthetic import synthetic_batch, default_opt
 
-lib().jpdse_debug_set_fast_path(args.fast)
+jpdse_hip.set_dev_mode(args.fast)
 opt = default_opt(gpu_ids=[0], print_losses=False, compute_dtype=args.dtype, use_compressed=True,
                   netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch)
 torch.manual_seed(1234)

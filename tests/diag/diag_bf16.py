@@ -5,11 +5,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'jpd-se_amd')); 
 import torch
 from oracle.ctu_cpu import model as omodel
 from ctu.trainers import get_trainer
+import jpdse_hip
 from jpdse_hip import lib
 import test_hip_step as T
 
 def grads(dtype, fast):
-  lib().jpdse_debug_set_fast_path(fast)
+  jpdse_hip.set_dev_mode(fast)
   opt = T._opts(compute_dtype=dtype)
   tr = get_trainer(opt)(opt, 'train')
   tr.model.netG.load_state_dict({k: v.detach() for k, v in ora.G.items()})

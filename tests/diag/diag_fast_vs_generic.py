@@ -4,6 +4,7 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'jpd-se_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
+import jpdse_hip
 from jpdse_hip import lib
 from ctu.trainers import get_trainer
 from oracle.ctu_cpu import model as omodel
@@ -16,13 +17,13 @@ base = get_trainer(opt)(opt, 'train')
 sdG, sdD = base.model.netG.state_dict(), base.model.netD.state_dict()
 res = {}
 for m in modes:
-  lib().jpdse_debug_set_fast_path(m)
+  jpdse_hip.set_dev_mode(m)
   tr = get_trainer(opt)(opt, 'train')
   tr.model.netG.load_state_dict(sdG); tr.model.netD.load_state_dict(sdD)
   tr.step(xd)
   res[m] = ({k: p.grad.detach().cpu().double().flatten() for k, p in list(tr.model.netG.named_parameters()) + [('D.' + k, p) for k, p in tr.model.netD.named_parameters()]
              if k.endswith('.weight')}, dict(tr.last_losses))
-lib().jpdse_debug_set_fast_path(1)
+jpdse_hip.set_dev_mode(1)
 opt32 = omodel.default_opt(gpu_ids=[0], print_losses=False, compute_dtype='fp32')
 tr = get_trainer(opt32)(opt32, 'train')
 tr.model.netG.load_state_dict(sdG); tr.model.netD.load_state_dict(sdD)

@@ -177,14 +177,11 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, seed):
 
 @pytest.mark.parametrize('name', ['halo_vgg_64', 'halo_vgg_256', 'ring_dgrad_192'])
 def test_halo_kernel_mfma_16x16x32_variant(name):
-  # debug mode 19: the halo kernel built on v_mfma_f32_16x16x32_bf16 (other swizzle, fragment and epilogue layout)
-  from jpdse_hip import lib
+  # developer mode 19: the halo kernel built on v_mfma_f32_16x16x32_bf16 (other swizzle, fragment and epilogue layout)
+  import jpdse_hip
   case = [c for c in CONV_CASES if c[0] == name][0]
-  lib().jpdse_debug_set_fast_path(19)
-  try:
+  with jpdse_hip.dev_mode(19):          # developer build of the library (include/jpdse_dev.h)
     test_conv_fwd_dgrad_wgrad(case, BF16, 0)
-  finally:
-    lib().jpdse_debug_set_fast_path(1)
 
 
 # conv -> ReLU(inplace) -> conv chains (VGG19): the second conv's data gradient with the ReLU backward fused
@@ -527,3 +524,38 @@ def test_full_size_adjointness_bf16(case):
   assert abs(lhs - via_dx) <= 4e-6 * scale, '%s: <y,dy> %.6e vs <x,dx> %.6e (scale %.3e)' % (name, lhs, via_dx, scale)
   assert abs(lhs - via_dw) <= 4e-6 * scale, '%s: <y,dy> %.6e vs <w,dw> %.6e (scale %.3e)' % (name, lhs, via_dw, scale)
   assert scale > 0 and abs(lhs) < scale
+
+
+def test_conv_entry_points_refuse_short_workspace_before_launching():
+  """Every conv entry point checks the caller's workspace against jpdse_conv_workspace_size BEFORE anything is enqueued
+  (JPDSE_EWORKSPACE): the reflect data gradient puts its ring-strip slabs, the split weight gradients their partial
+  slabs there, and a short buffer would otherwise be a device memory fault."""
+  import ctypes
+  from jpdse_hip import lib, ConvDesc, last_error
+  d = ops.conv_desc(BF16, 2, 8, 64, 64, 128, 3, 3, 1, 1, PAD_REFLECT)           # ring path + nine-tap weight gradient
+  need = lib().jpdse_conv_workspace_size(ctypes.byref(d))
+  assert need > 0
+  layer = HipConv2d(64, 128, 3, 1, 1, PAD_REFLECT, apply_bias=False, dtype=BF16, device=DEV)
+  fwd_pack, dgrad_pack = layer.packs()
+  x = Act.empty(2, 8, 64, 64, BF16, DEV)
+  x.t.zero_()
+  dy = Act.empty(2, 8, 64, 128, BF16, DEV)
+  dy.t.zero_()
+  dx = x.empty_like()
+  dx.t.fill_(7.0)
+  dw = torch.full((128, 3, 3, 64), 7.0, device=DEV)
+  ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+  s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  p = lambda t: ctypes.c_void_p(t.data_ptr())
+  short = need // 2
+  assert lib().jpdse_conv_dgrad(ctypes.byref(d), p(dy.t), p(dgrad_pack), p(dx.t), p(ws), short, s) == -2
+  assert 'workspace' in last_error()
+  assert lib().jpdse_conv_wgrad(ctypes.byref(d), p(x.t), p(dy.t), p(dw), p(ws), short, s) == -2
+  assert lib().jpdse_conv_fwd(ctypes.byref(d), p(x.t), p(fwd_pack), None, p(dy.t), p(ws), short, s) == -2
+  assert lib().jpdse_conv_dgrad(ctypes.byref(d), p(dy.t), p(dgrad_pack), p(dx.t), None, need, s) == -2
+  torch.cuda.synchronize()
+  assert (dx.t == 7.0).all() and (dw == 7.0).all(), 'a refused call must not have launched anything'
+  assert lib().jpdse_conv_dgrad(ctypes.byref(d), p(dy.t), p(dgrad_pack), p(dx.t), p(ws), need, s) == 0
+  assert lib().jpdse_conv_wgrad(ctypes.byref(d), p(x.t), p(dy.t), p(dw), p(ws), need, s) == 0
+  torch.cuda.synchronize()
+  assert (dx.t == 0).all() and (dw == 0).all()

@@ -275,7 +275,6 @@ def test_bf16_full_width_fast_kernels_in_situ():
         layers at random init).  The oracle's bf16-storage emulation (oracle.ctu_cpu.nets.storage_bf16)
         reproduces that on the CPU; the HIP path must be at least as close to fp32 as the emulation,
         minus 0.03, and its gradient norms within 5 %."""
-  from jpdse_hip import lib
   from oracle.ctu_cpu import nets as onets
   tr32, ora, _ = _paired(dict())
   sdG, sdD = tr32.model.netG.state_dict(), tr32.model.netD.state_dict()
@@ -290,18 +289,18 @@ def test_bf16_full_width_fast_kernels_in_situ():
   ora.step(xd)
 
   def run(fast_mode):
-    lib().jpdse_debug_set_fast_path(fast_mode)
-    try:
+    # mode 1 = the shipped library; the other kernel selections exist only in the developer build (jpdse_dev.h)
+    import contextlib
+    with (jpdse_hip.dev_mode(fast_mode) if fast_mode != 1 else contextlib.nullcontext()):
       opt16 = _opts(compute_dtype='bf16')
       tr = get_trainer(opt16)(opt16, 'train')
       tr.model.netG.load_state_dict(sdG)
       tr.model.netD.load_state_dict(sdD)
       tr.step(xd)
+      torch.cuda.synchronize()
       grads = {k: p.grad.detach().cpu().double().flatten() for k, p in tr.model.netG.named_parameters()
                if k.endswith('.weight')}
       return grads, dict(tr.last_losses)
-    finally:
-      lib().jpdse_debug_set_fast_path(1)
 
   cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
   g_fast, L = run(1)

@@ -28,6 +28,13 @@ def test_library_loads_and_exports_header_symbols():
   for name in sorted(declared):
     assert hasattr(L, name), 'header declares %s but the library does not export it' % name
   assert declared == set(jpdse_hip.SIGNATURES.keys())
+  # the developer switch is NOT part of the shipped ABI: only libjpdse_hip_dev.so (include/jpdse_dev.h) has it
+  assert not hasattr(L, 'jpdse_debug_set_fast_path'), 'the shipped library must not export the developer switch'
+  dev_header = open(os.path.join(ROOT, 'include', 'jpdse_dev.h')).read()
+  assert set(re.findall(r'\b(jpdse_[a-zA-Z0-9_]+)\s*\(', dev_header)) == set(jpdse_hip.DEV_SIGNATURES.keys())
+  dev = ctypes.CDLL(jpdse_hip.DEV_LIB_PATH)
+  for name in sorted(declared | set(jpdse_hip.DEV_SIGNATURES.keys())):
+    assert hasattr(dev, name), 'developer build lacks %s' % name
 
 
 def test_descriptor_validation_errors_are_reported():
