@@ -256,8 +256,9 @@ def test_bf16_trajectory_tracks_fp32_and_oracle_over_50_steps():
   np.testing.assert_allclose(c32[0], co[0], rtol=1e-3)
   np.testing.assert_allclose(c16[0], co[0], rtol=2e-2)
   # end of the run: bands on the 10-step means (GAN losses fluctuate most: wider band)
-  band32 = dict(G_GAN=0.10, G_GAN_Feat=0.05, G_VGG=0.03, G_Distortion=0.03, D_real=0.10, D_fake=0.10)
-  band16 = dict(G_GAN=0.15, G_GAN_Feat=0.08, G_VGG=0.05, G_Distortion=0.05, D_real=0.15, D_fake=0.15)
+  # measured on MI355X (round 2): fp32 vs oracle <= 1.7 %, bf16 vs fp32 <= 2.9 % (the two GAN terms), <= 0.7 % (others)
+  band32 = dict(G_GAN=0.05, G_GAN_Feat=0.03, G_VGG=0.02, G_Distortion=0.02, D_real=0.05, D_fake=0.05)
+  band16 = dict(G_GAN=0.07, G_GAN_Feat=0.03, G_VGG=0.03, G_Distortion=0.03, D_real=0.07, D_fake=0.07)
   for j, k in enumerate(omodel.LOSS_NAMES):
     ref = tail(co)[j]
     assert abs(tail(c32)[j] - ref) <= band32[k] * abs(ref), 'fp32 HIP %s: %.4f vs oracle %.4f' % (k, tail(c32)[j], ref)
