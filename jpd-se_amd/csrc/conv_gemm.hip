@@ -1249,14 +1249,14 @@ JPDSE_SWITCH(int, g_halo_single, 1);
 JPDSE_SWITCH(int, g_halo_enabled, 1);
 JPDSE_SWITCH(int, g_halo_abl, 0);
 
-template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false>
+template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false>
 static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   constexpr int BN = 2 * TN * 32;
   constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
   constexpr int lds = (SINGLE ? 1 : 2) * UH * 1024 + 3 * BN * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -1267,7 +1267,7 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG>), dim3(tiles), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE>), dim3(tiles), dim3(512), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
@@ -1278,7 +1278,8 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
 }
 
 JPDSE_SWITCH(int, g_halo_xcd, 0);
-JPDSE_SWITCH(int, g_halo_stag, 0);      // 23: waves 4..7 issue their DMA group after the MFMA cluster (A/B)
+JPDSE_SWITCH(int, g_halo_stag, 0);
+JPDSE_SWITCH(int, g_halo_pipe, 0);      // 25: software-pipelined fragment reads (A/B)      // 23: waves 4..7 issue their DMA group after the MFMA cluster (A/B)
 JPDSE_SWITCH(int, g_halo_mf16, 0);     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
 template <int TN, int ABL = 0>
 static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
@@ -1290,6 +1291,8 @@ static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
     return launch_halo_cfg_impl<TN, 0, false, true>(a, s);
   }
   if (ABL == 0 && g_halo_stag) return launch_halo_cfg_impl<TN, 0, false, false, true>(a, s);
+  if (ABL == 0 && g_halo_pipe == 1 && a.Cs != 64) return launch_halo_cfg_impl<TN, 0, false, false, false, true>(a, s);
+  if (ABL == 0 && g_halo_pipe == 1 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, false, false, true>(a, s);
 #endif
   if (a.Cs == 64 && ABL == 0 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true>(a, s);   // one slab: single patch buffer
   return launch_halo_cfg_impl<TN, ABL, false>(a, s);
@@ -2284,7 +2287,7 @@ static size_t wgrad_nine_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
   return a.splits > 1 ? (size_t)a.splits * d->K * 9 * d->C * sizeof(float) : 0;
 }
 
-JPDSE_SWITCH(int, g_nine_sched, 2);
+JPDSE_SWITCH(int, g_nine_sched, 3);
 template <bool REFLECT, int SCHED>
 static int launch_wgrad_nine_cfg(const NineWgArgs& a, hipStream_t s) {
   static bool configured = false;
@@ -2324,12 +2327,13 @@ static int launch_wgrad_nine(const jpdse_conv_desc* d, const ConvPlan& p, const 
   nine_partition(d, p, &a);
   if (a.splits > 1 && ((long long)d->K * 9 * d->C) % 4 != 0)
     return set_error(JPDSE_EINVAL, "wgrad_nine: K*9*C = %lld is not a multiple of 4", (long long)d->K * 9 * d->C);
-  if (d->pad_mode != JPDSE_PAD_REFLECT) return launch_wgrad_nine_cfg<false, 2>(a, s);
+  if (d->pad_mode != JPDSE_PAD_REFLECT) return launch_wgrad_nine_cfg<false, 3>(a, s);
 #ifdef JPDSE_DEV
   if (g_nine_sched == 0) return launch_wgrad_nine_cfg<true, 0>(a, s);
   if (g_nine_sched == 1) return launch_wgrad_nine_cfg<true, 1>(a, s);
+  if (g_nine_sched == 2) return launch_wgrad_nine_cfg<true, 2>(a, s);
 #endif
-  return launch_wgrad_nine_cfg<true, 2>(a, s);
+  return launch_wgrad_nine_cfg<true, 3>(a, s);
 }
 
 // heads with <= 8 output channels on a 32- / 64-channel input, stride 1 (64->3, 32->3 7x7)
@@ -2573,7 +2577,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_fast_enabled = enable != 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
-  g_nine_sched = enable == 21 ? 0 : (enable == 22 ? 1 : 2);   // 21 / 22: DMA issue placement of the nine-tap weight gradient (A/B)
+  g_nine_sched = enable == 21 ? 0 : (enable == 22 ? 1 : (enable == 24 ? 2 : 3));   // 21 / 22 / 24: unpipelined loop forms of the nine-tap weight gradient (A/B); default 3 = software-pipelined fragment reads   // 21 / 22: DMA issue placement of the nine-tap weight gradient (A/B)
   g_wgrad_nine_enabled = enable != 4;    // 4: wide 3x3 layers on the per-tap fast weight gradient instead of the all-nine-taps one (A/B)
   g_wgrad_taps_enabled = enable != 12;   // 12: fast kernels without the all-taps weight gradient (A/B)
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
@@ -2581,7 +2585,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
   g_halo_mf16 = enable == 19;
-  g_halo_stag = enable == 23;         // 19: halo kernel on 16x16x32 MFMAs (A/B)
+  g_halo_stag = enable == 23;
+  g_halo_pipe = enable == 25 ? 1 : 0;         // 19: halo kernel on 16x16x32 MFMAs (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_head_fwd_enabled = enable != 14 && enable != 6;   // 14: heads on the Toeplitz GEMM (A/B); 6 keeps the generic order
   g_thin_fwd_enabled = enable != 18;  // 18: thin-input forward on the generic kernel (A/B)

@@ -59,6 +59,10 @@ struct FastBatch {
   int n;
 };
 
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {      // 32-bit LDS address of a generic pointer into LDS
+  return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+}
+
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

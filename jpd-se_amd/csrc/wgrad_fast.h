@@ -56,9 +56,6 @@ __device__ __forceinline__ s16x8 tr_frag(const char* p, int row4_bytes) {
 // drained before the current chunk's MFMAs started).  The asm form is invisible to that analysis; the
 // caller orders it by hand: counted vmcnt + raw barrier before, tr_wait() (lgkmcnt(0) tied to the
 // fragment registers) between the reads and the MFMAs that consume them.
-__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
-  return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
-}
 template <int OFF_LO, int OFF_HI>
 __device__ __forceinline__ s16x8 tr_frag_asm(uint32_t addr) {
   s16x4 lo, hi;

@@ -48,7 +48,7 @@ static constexpr int kNineRedLds = 4 * 9 * 16 * 64 * 4;                         
 static constexpr int kNineLds = kNineLoopLds > kNineRedLds ? kNineLoopLds : kNineRedLds;
 
 // SCHED: where the DMA issue of chunk t+2 sits in iteration t (see the loop).  ABL (timing-only): 1 = no epilogue
-template <bool REFLECT, int SCHED = 2, int ABL = 0>
+template <bool REFLECT, int SCHED = 3, int ABL = 0>
 __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
   constexpr int NW = 8, BKP = 64, ROWB = 128;
   constexpr int A_STAGE = kNineStage, B_SLOT = kNineSlot, NSLOT = kNineSlots;
@@ -219,6 +219,51 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
       acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[t9], acc[t9], 0, 0, 0);
   };
 
+  // SCHED 3: the six (k-step, filter-row) groups of a chunk as a software pipeline -- the transposed reads of group g+1
+  // are in flight while the three MFMAs of group g issue, with COUNTED lgkmcnt waits (LDS operations return in order; the
+  // loop holds no scalar-memory loads, which would share the counter -- checked in the .s).  The plain form waits for
+  // lgkmcnt(0) after each k-step's 20 reads: two exposed LDS round trips per chunk and wave.
+  auto lgkm_wait = [&]<int N>(s16x8& f0, s16x8& f1, s16x8& f2, s16x8& f3) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "n"(N));
+  };
+  auto chunk_pipelined = [&](uint32_t a_addr, const uint32_t (&boff)[3], auto&& mid) {
+    s16x8 a0, a1, b0[3], b1[3], b2[3];
+    constexpr int K1 = 16 * ROWB;
+    a0 = tr_frag_asm<0, 4 * ROWB>(a_addr);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) b0[s] = tr_frag_asm<0, 4 * ROWB>(b_rd[s] + boff[0]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) b1[s] = tr_frag_asm<0, 4 * ROWB>(b_rd[s] + boff[1]);
+    mid();                                                     // (half 1: DMA issue under the first reads' latency)
+    lgkm_wait.template operator()<6>(a0, b0[0], b0[1], b0[2]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[s], acc[s], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) b2[s] = tr_frag_asm<0, 4 * ROWB>(b_rd[s] + boff[2]);
+    lgkm_wait.template operator()<6>(a0, b1[0], b1[1], b1[2]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc[3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1[s], acc[3 + s], 0, 0, 0);
+    a1 = tr_frag_asm<K1, K1 + 4 * ROWB>(a_addr);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) b0[s] = tr_frag_asm<K1, K1 + 4 * ROWB>(b_rd[s] + boff[0]);
+    lgkm_wait.template operator()<8>(a0, b2[0], b2[1], b2[2]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc[6 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2[s], acc[6 + s], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) b1[s] = tr_frag_asm<K1, K1 + 4 * ROWB>(b_rd[s] + boff[1]);
+    lgkm_wait.template operator()<6>(a1, b0[0], b0[1], b0[2]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0[s], acc[s], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) b2[s] = tr_frag_asm<K1, K1 + 4 * ROWB>(b_rd[s] + boff[2]);
+    lgkm_wait.template operator()<6>(a1, b1[0], b1[1], b1[2]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc[3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[s], acc[3 + s], 0, 0, 0);
+    lgkm_wait.template operator()<0>(a1, b2[0], b2[1], b2[2]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc[6 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[s], acc[6 + s], 0, 0, 0);
+  };
+
   for (int t = t0; t < t1; ++t) {
     if (t + 1 < t1) wait_vmcnt<2>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -238,6 +283,16 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
     // SCHED 0: DMA issue right behind the barrier (all 8 waves do scalar / address work while the matrix pipes idle);
     // 1: between the two k-steps, under the first one's MFMAs; 2: the two waves of a SIMD (pixel halves) take turns --
     // half 0 computes first and issues last, half 1 issues first: one of them feeds the matrix pipe while the other loads
+    if constexpr (SCHED == 3) {
+      __builtin_amdgcn_s_setprio(1);
+      chunk_pipelined(a_addr, boff, [&]() { if (ph == 1 && more) { issue_dy(); issue_row(); } });
+      __builtin_amdgcn_s_setprio(0);
+      if (ph == 0 && more) { issue_dy(); issue_row(); }
+      c_stage = c_stage == 2 ? 0 : c_stage + 1;
+      c_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
+      c_h = c_h == Hm1 ? 0 : c_h + 1;
+      continue;
+    }
     if (SCHED == 0 || (SCHED == 2 && ph == 1)) {
       if (more) { issue_dy(); issue_row(); }
     }
