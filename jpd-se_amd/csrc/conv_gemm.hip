@@ -1245,6 +1245,7 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
 
 JPDSE_SWITCH(int, g_ring_enabled, 1);
 JPDSE_SWITCH(int, g_merge_min_kt, 4);
+JPDSE_SWITCH(int, g_merge_min_tiles, 384);   // merged stride-phase data gradient on the fast kernel from this many 256-row tiles on (26: 64, A/B)
 JPDSE_SWITCH(int, g_halo_single, 1);
 JPDSE_SWITCH(int, g_halo_enabled, 1);
 JPDSE_SWITCH(int, g_halo_abl, 0);
@@ -1913,7 +1914,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     }
     nlive_phases = nlive;
     if (nlive == 1) fast = fast && fast_pays(m_single, p.Cs, kt_max);
-    else fast = fast && g_fast_enabled && p.Cs > 32 && kt_max >= g_merge_min_kt && tiles >= 384;   // short K loops: generic wins
+    else fast = fast && g_fast_enabled && p.Cs > 32 && kt_max >= g_merge_min_kt && tiles >= g_merge_min_tiles;   // few tiles / short K loops: generic wins
   }
   FastBatch batch = {};
   int rc = JPDSE_OK;
@@ -2581,7 +2582,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_wgrad_nine_enabled = enable != 4;    // 4: wide 3x3 layers on the per-tap fast weight gradient instead of the all-nine-taps one (A/B)
   g_wgrad_taps_enabled = enable != 12;   // 12: fast kernels without the all-taps weight gradient (A/B)
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
-  g_merge_min_kt = enable == 9 ? 16 : 4;    // 9: merged stride-phase data gradient only for long K loops (A/B)
+  g_merge_min_kt = enable == 9 ? 16 : 4;
+  g_merge_min_tiles = enable == 26 ? 64 : 384;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
   g_halo_mf16 = enable == 19;
