@@ -23,6 +23,15 @@ static inline int cpad(int c) { return (c + 7) & ~7; }
 static inline size_t esize(int dtype) { return dtype == JPDSE_BF16 ? 2 : 4; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Kernel-selection switches: compile-time constants in the shipped library, run-time variables in the developer build
+// (libjpdse_hip_dev.so, -DJPDSE_DEV; set through include/jpdse_dev.h).
+#ifdef JPDSE_DEV
+#define JPDSE_SWITCH(type, name, value) static type name = value
+extern int g_norm_fused;     // norm.hip: InstanceNorm form, 1 = two register-held kernels (default), 0 = three kernels (mode 27), 2 = one kernel (mode 28)
+#else
+#define JPDSE_SWITCH(type, name, value) static constexpr type name = value
+#endif
+
 // ---- device scalar types ------------------------------------------------------------------
 typedef uint16_t bf16_t;  // raw bf16 bits
 
@@ -55,6 +64,16 @@ template <> struct ElemOps<bf16_t> {
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
   static constexpr int N = 4;
+  __device__ static __forceinline__ void unpack(u32x4 t, float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(t[i]);
+  }
+  __device__ static __forceinline__ u32x4 pack(const float (&v)[4]) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(v[i]);
+    return t;
+  }
   __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
     f32x4 t = *reinterpret_cast<const f32x4*>(p);
     v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
@@ -66,6 +85,20 @@ template <> struct Vec16<float> {
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
+  __device__ static __forceinline__ void unpack(u32x4 t, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(t[i] << 16);
+      v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ u32x4 pack(const float (&v)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      t[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    return t;
+  }
   __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     u32x4 t = *reinterpret_cast<const u32x4*>(p);
 #pragma unroll

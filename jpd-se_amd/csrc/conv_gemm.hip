@@ -24,11 +24,7 @@
 // init-once launch attributes and the opt-in kernel timer -- and the ablation kernels are not even instantiated.  The
 // developer build (libjpdse_hip_dev.so, -DJPDSE_DEV, include/jpdse_dev.h) makes them run-time variables behind
 // jpdse_debug_set_fast_path for same-process A/B measurements and for the tests that compare two kernels of one layer.
-#ifdef JPDSE_DEV
-#define JPDSE_SWITCH(type, name, value) static type name = value
-#else
-#define JPDSE_SWITCH(type, name, value) static constexpr type name = value
-#endif
+// (JPDSE_SWITCH itself lives in common.h.)
 
 namespace jpdse {
 
@@ -88,6 +84,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "wgrad_taps.h"
 #include "head_fwd.h"
 #include "thin_fwd.h"
+#include "conv_rows.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1299,6 +1296,58 @@ static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
   return launch_halo_cfg_impl<TN, ABL, false>(a, s);
 }
 
+
+// 3x3 convs over 64-channel inputs (stride 1 | 2, zero padding): filter in registers, input rows streamed once (conv_rows.h)
+JPDSE_SWITCH(int, g_rows_enabled, 1);       // 29: these layers on the halo / fast kernels (A/B)
+
+static bool rows_ok(int R, int S, int stride, int reflect, int act, int OH, int OW, int Cs_in, int Ks_out) {
+  return g_fast_enabled && g_rows_enabled && R == 3 && S == 3 && (stride == 1 || stride == 2) && !reflect && Cs_in == 64 &&
+         Ks_out % 64 == 0 && OW % 64 == 0 && OH % 4 == 0 &&
+         (act == JPDSE_ACT_NONE || act == JPDSE_ACT_RELU || act == JPDSE_ACT_LRELU);
+}
+
+template <int STRIDE, int WC, bool FUSED>
+static int launch_rows_cfg(RowsArgs a, hipStream_t s) {
+  typedef RowsGeom<STRIDE, WC> G;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_kernel<STRIDE, WC, FUSED>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "conv_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
+    configured = true;
+  }
+  a.n_tiles = a.Ks / (32 * WC);
+  a.strips = a.OW / 64;
+  // band height: as tall as possible (the filter load and the ring prologue are paid once per block) while the grid still
+  // fills the chip (two blocks per CU for the 64-output stride-1 layers, one otherwise: LDS / registers)
+  const long long want = 256LL * ((STRIDE == 1 && WC == 2) ? 2 : 1);
+  int th = 0;
+  for (int cand = 64; cand >= 4; cand >>= 1) {
+    if (a.OH % cand != 0) continue;
+    if ((long long)a.N * a.strips * (a.OH / cand) * a.n_tiles >= want) { th = cand; break; }
+  }
+  if (th == 0)                                   // small problem: the grid cannot fill the chip anyway
+    for (int cand = 16; cand >= 4; cand >>= 1)
+      if (a.OH % cand == 0) { th = cand; break; }
+  a.TH = th;
+  a.bands = a.OH / th;
+  const long long blocks = (long long)a.N * a.bands * a.strips * a.n_tiles;
+  if (blocks > 0x7fffffffLL) return set_error(JPDSE_EINVAL, "conv_rows: grid too large");
+  hipLaunchKernelGGL((conv_rows_kernel<STRIDE, WC, FUSED>), dim3((unsigned)blocks), dim3(256), G::LDS, s, a);
+  return check_launch("conv_rows_kernel");
+}
+
+static int launch_rows(const RowsArgs& a, int stride, hipStream_t s) {
+  const bool fused = a.mask != nullptr || a.addend != nullptr;
+  const bool wide = a.Ks % 128 == 0;
+  if (stride == 1) {
+    if (wide) return fused ? launch_rows_cfg<1, 4, true>(a, s) : launch_rows_cfg<1, 4, false>(a, s);
+    return fused ? launch_rows_cfg<1, 2, true>(a, s) : launch_rows_cfg<1, 2, false>(a, s);
+  }
+  if (wide) return fused ? launch_rows_cfg<2, 4, true>(a, s) : launch_rows_cfg<2, 4, false>(a, s);
+  return fused ? launch_rows_cfg<2, 2, true>(a, s) : launch_rows_cfg<2, 2, false>(a, s);
+}
+
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
 // gradient of the zero-padded ones): LDS-resident input halo, see gemm_halo.h
 static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_out) {
@@ -1491,6 +1540,29 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
                          reinterpret_cast<bf16_t*>(y), d->N, d->H, d->W, p.OH, p.OW, d->K, p.Ks, d->R, d->S, d->pad,
                          d->pad_mode == JPDSE_PAD_REFLECT ? 1 : 0, zs, d->act, d->slope, total);
       return check_launch("tapsum_kernel");
+    }
+    if (rows_ok(d->R, d->S, d->stride, d->pad_mode == JPDSE_PAD_REFLECT, d->act, p.OH, p.OW, p.Cs, p.Ks)) {
+      RowsArgs r = {};
+      r.X = reinterpret_cast<const bf16_t*>(x);
+      r.B = reinterpret_cast<const bf16_t*>(pack);
+      r.bias = bias;
+      r.Y = reinterpret_cast<bf16_t*>(y);
+      r.N = d->N;
+      r.OH = p.OH;
+      r.OW = p.OW;
+      r.IH = d->H;
+      r.IW = d->W;
+      r.py = r.px = d->pad;
+      r.Kout = d->K;
+      r.Ks = p.Ks;
+      r.b_rows = p.Ks;
+      r.out_sn = (long long)p.OH * p.OW * p.Ks;
+      r.out_sh = (long long)p.OW * p.Ks;
+      r.out_sw = p.Ks;
+      r.out_base = 0;
+      r.act = d->act;
+      r.slope = d->slope;
+      return launch_rows(r, d->stride, s);
     }
     if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks)) {
       HaloArgs h = {};
@@ -1741,6 +1813,34 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   void* dxp = wsb + p.dypad_bytes;
   const bool refl = d->pad_mode == JPDSE_PAD_REFLECT;
   const int st = d->stride;
+  if constexpr (sizeof(T) == 2) {
+    if (!refl && p.nph == 1 && st == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W &&
+        rows_ok(p.ph[0].Uh, p.ph[0].Uw, 1, 0, JPDSE_ACT_NONE, d->H, d->W, p.Ks, p.Cs) && p.ph[0].Lk == 3 * p.Ks) {
+      const Phase& f = p.ph[0];
+      RowsArgs r = {};
+      r.X = reinterpret_cast<const bf16_t*>(dy);
+      r.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
+      r.Y = reinterpret_cast<bf16_t*>(dx);
+      r.N = d->N;
+      r.OH = d->H;
+      r.OW = d->W;
+      r.IH = p.OH;
+      r.IW = p.OW;
+      r.py = (f.Uh - 1) - f.i0h;
+      r.px = (f.Uw - 1) - f.i0w;
+      r.Kout = d->C;
+      r.Ks = p.Cs;
+      r.b_rows = p.Cs;
+      r.out_sn = (long long)d->H * d->W * p.Cs;
+      r.out_sh = (long long)d->W * p.Cs;
+      r.out_sw = p.Cs;
+      r.out_base = 0;
+      r.act = JPDSE_ACT_NONE;
+      r.mask = reinterpret_cast<const bf16_t*>(mask);
+      r.addend = reinterpret_cast<const bf16_t*>(addend);
+      return launch_rows(r, 1, s);
+    }
+  }
   if constexpr (sizeof(T) == 2) {
     if (!refl && p.nph == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W &&
         halo_ok(p.ph[0].Uh, p.ph[0].Uw, st, d->H, d->W, p.Ks, p.Cs)) {
@@ -2577,12 +2677,14 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   // 0: generic kernels only; 1: fast kernels (default schedule 0); 2: fast kernels, alternative schedule 1
   g_fast_enabled = enable != 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
+  g_rows_enabled = enable != 29 && enable != 3;   // 29: 64-channel 3x3 layers on the halo / fast kernels instead of conv_rows (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_nine_sched = enable == 21 ? 0 : (enable == 22 ? 1 : (enable == 24 ? 2 : 3));   // 21 / 22 / 24: unpipelined loop forms of the nine-tap weight gradient (A/B); default 3 = software-pipelined fragment reads   // 21 / 22: DMA issue placement of the nine-tap weight gradient (A/B)
   g_wgrad_nine_enabled = enable != 4;    // 4: wide 3x3 layers on the per-tap fast weight gradient instead of the all-nine-taps one (A/B)
   g_wgrad_taps_enabled = enable != 12;   // 12: fast kernels without the all-taps weight gradient (A/B)
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
   g_merge_min_kt = enable == 9 ? 16 : 4;
+  g_norm_fused = enable == 27 ? 0 : (enable == 28 ? 2 : 1);   // 27: InstanceNorm always as three kernels; 28: one-kernel form with the in-launch exchange (A/B)
   g_merge_min_tiles = enable == 26 ? 64 : 384;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)

@@ -5,7 +5,13 @@
 // 16-byte channel vector column and walks pixels (coalesced: a pixel's channels are
 // contiguous), partial sums per pixel-split written to the workspace; (2) a tiny finalize
 // kernel (deterministic order, no atomics); (3) a fully parallel apply kernel.
+//
+// Tensors with few pixel splits per image (everything up to 67 MB in the bench step) take the register-held two-kernel
+// form further down: no finalize launch, its work folded into the apply kernel's prologue.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace jpdse {
 
@@ -293,6 +299,448 @@ __global__ __launch_bounds__(256) void inorm_apply_bwd_kernel(const T* __restric
   }
 }
 
+
+// ---- register-held forms ------------------------------------------------------------------
+// Geometry shared by the two forms below: a block owns `span` = TY * P pixels of TX 16-byte channel columns of one image and
+// holds them in registers; the `splits` blocks of one (image, channel block) = one GROUP are consecutive in the grid.
+//   TWO kernels (default, any tensor with <= 64 splits): PHASE 1 writes one row of partial sums per block, PHASE 2 loads
+//     its pixels, sums the group's rows itself (split order: deterministic; the rows are L2 hits and load under the
+//     pixel loads), and applies.  Against moment -> finalize -> apply this drops a launch and the finalize round trip.
+//   ONE kernel (PHASE 0; developer A/B mode 28, tensors that fit a resident grid): the blocks of a group exchange their rows
+//     inside the launch -- `sc1` stores and loads for every handed-off byte, one agent-scope add per storing workgroup
+//     behind that workgroup's vmcnt(0) + barrier (MI355X_MICROARCH.md, "inter-workgroup visibility") -- and x / dy are
+//     read once.  Measured on the ResnetBlock tensor (16.8 MB): each cross-XCD hop of the exchange costs ~2 us, which
+//     eats what the saved launch and re-read give (profiles/r02_norm_forms.txt), so it is not the shipped form.
+static inline int norm_form() {
+#ifdef JPDSE_DEV
+  return g_norm_fused;     // 1 = two kernels (shipped default), 0 = moment -> finalize -> apply, 2 = one kernel
+#else
+  return 1;
+#endif
+}
+#ifdef JPDSE_DEV
+int g_norm_fused = 1;
+#endif
+
+struct FusedGeom {
+  int N, HW, Cs, cv;
+  int TX, TY, tx_shift;          // threads across 16-byte channel columns / pixels (TX * TY = 256)
+  int col_blocks, splits, span;  // blocks per image across channels / pixels; pixels per block (TY * P)
+  int nv;                        // floats per partial row: TX * VE * 2
+};
+
+static FusedGeom fused_geom(int N, int HW, int Cs, int VE, int P) {
+  FusedGeom g;
+  g.N = N; g.HW = HW; g.Cs = Cs; g.cv = Cs / VE;
+  int tx = 1;
+  while (tx < g.cv && tx < 16) tx <<= 1;       // <= 256 contiguous bytes per pixel and block
+  g.TX = tx; g.TY = 256 / tx;
+  g.tx_shift = 0;
+  while ((1 << g.tx_shift) < tx) ++g.tx_shift;
+  g.col_blocks = (g.cv + g.TX - 1) / g.TX;
+  g.span = g.TY * P;
+  g.splits = (HW + g.span - 1) / g.span;
+  g.nv = g.TX * VE * 2;
+  return g;
+}
+
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Sum over the block's TY pixel rows: value j (< nv) of the block's partial row, returned in thread j.
+template <int VE>
+__device__ __forceinline__ float block_row(float* red, const float (&s1)[8], const float (&s2)[8], const FusedGeom& g) {
+  const int tid = threadIdx.x;
+  const int tx = tid & (g.TX - 1), ty = tid >> g.tx_shift;
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    red[ty * g.nv + (tx * VE + e) * 2] = s1[e];
+    red[ty * g.nv + (tx * VE + e) * 2 + 1] = s2[e];
+  }
+  __syncthreads();
+  float tsum = 0.f;
+  if (tid < g.nv)
+    for (int yy = 0; yy < g.TY; ++yy) tsum += red[yy * g.nv + tid];
+  __syncthreads();                                    // red[] is free again
+  return tsum;
+}
+
+// Sum of the group's rows in split order (sixteen loads in flight, added in order); COHERENT: rows written inside this launch.
+template <bool COHERENT>
+__device__ __forceinline__ float sum_rows(const float* rows, int splits, int nv) {
+  float total = 0.f;
+  for (int s0 = 0; s0 < splits; s0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float* q = rows + (long long)(s0 + k) * nv;
+      v[k] = 0.f;
+      if (s0 + k < splits) v[k] = COHERENT ? ld_sc1(q) : *q;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) total += v[k];       // + 0.f for the absent rows changes nothing
+  }
+  return total;
+}
+
+// PHASE 0: on return red[j] holds the group total of value j.  `count`: one zeroed word per group, used once.
+template <int VE>
+__device__ __forceinline__ void exchange_totals(float* red, int* s_ctl, float tsum, float* partial, unsigned* count, int grp,
+                                                int split, const FusedGeom& g) {
+  const int tid = threadIdx.x;
+  float total = tsum;
+  if (g.splits > 1) {
+    float* const rows = partial + (long long)grp * g.splits * g.nv;
+    if (tid < g.nv) st_sc1(rows + (long long)split * g.nv + tid, tsum);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(count + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned it = 0;
+      int gave_up = 0;
+      while (ld_sc1(count + grp) < (unsigned)g.splits) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++it > (1u << 22)) { gave_up = 1; break; }   // every wave reaches an exit; the result is then NaN (loud)
+      }
+      s_ctl[0] = gave_up;
+    }
+    __syncthreads();
+    if (tid < g.nv) total = s_ctl[0] ? __builtin_nanf("") : sum_rows<true>(rows + tid, g.splits, g.nv);
+  }
+  if (tid < g.nv) red[tid] = total;
+  __syncthreads();
+}
+
+template <typename T, int P, int PHASE>
+__global__ __launch_bounds__(256, 4) void inorm_reg_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                             T* __restrict__ y, float* __restrict__ stats, float* partial,
+                                                             unsigned* count, int act, float slope, float eps, FusedGeom g) {
+  constexpr int VE = Vec16<T>::N;
+  __shared__ float red[256 * VE * 2];
+  __shared__ int s_ctl[2];
+  const int tid = threadIdx.x;
+  const int tx = tid & (g.TX - 1), ty = tid >> g.tx_shift;
+  const int split = blockIdx.x % g.splits, grp = blockIdx.x / g.splits;
+  const int cb = grp % g.col_blocks, n = grp / g.col_blocks;
+  const int col = cb * g.TX + tx;
+  const bool on = col < g.cv;
+  const int c0 = (on ? col : 0) * VE;
+  const long long base = (long long)n * g.HW * g.Cs + c0;
+  const int p0 = split * g.span + ty;
+  u32x4 xv[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int p = p0 + i * g.TY;
+    if (on && p < g.HW) xv[i] = *reinterpret_cast<const u32x4*>(x + base + (long long)p * g.Cs);
+  }
+  float aux[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { aux[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+  if (on) {
+    float v[VE];
+    Vec16<T>::load(x + base, v);                      // shift = the image's first pixel, as in the three-kernel form
+#pragma unroll
+    for (int e = 0; e < VE; ++e) aux[e] = v[e];
+  }
+  if constexpr (PHASE == 2) {
+    const float* rows = partial + (long long)grp * g.splits * g.nv;
+    const float total = tid < g.nv ? sum_rows<false>(rows + tid, g.splits, g.nv) : 0.f;
+    if (tid < g.nv) red[tid] = total;
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int p = p0 + i * g.TY;
+      if (on && p < g.HW) {
+        float v[VE];
+        Vec16<T>::unpack(xv[i], v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float d = v[e] - aux[e];
+          s1[e] += d;
+          s2[e] += d * d;
+        }
+      }
+    }
+    const float tsum = block_row<VE>(red, s1, s2, g);
+    if constexpr (PHASE == 1) {
+      if (tid < g.nv) partial[((long long)grp * g.splits + split) * g.nv + tid] = tsum;
+      return;
+    } else {
+      exchange_totals<VE>(red, s_ctl, tsum, partial, count, grp, split, g);
+    }
+  }
+  float mean[VE], rstd[VE];
+  const float inv = 1.f / (float)g.HW;
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    const float dm = red[(tx * VE + e) * 2] * inv;
+    float var = red[(tx * VE + e) * 2 + 1] * inv - dm * dm;
+    var = var > 0.f ? var : 0.f;
+    mean[e] = aux[e] + dm;
+    rstd[e] = rsqrtf(var + eps);
+  }
+  if (on && split == 0 && ty == 0) {
+    float* st = stats + ((long long)n * g.Cs + c0) * 2;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { st[2 * e] = mean[e]; st[2 * e + 1] = rstd[e]; }
+  }
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int p = p0 + i * g.TY;
+    if (on && p < g.HW) {
+      const long long off = base + (long long)p * g.Cs;
+      float v[VE], r[VE];
+      Vec16<T>::unpack(xv[i], v);
+      if (res != nullptr) Vec16<T>::load(res + off, r);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        float t = (v[e] - mean[e]) * rstd[e];
+        if (act == JPDSE_ACT_RELU) t = t > 0.f ? t : 0.f;
+        else if (act == JPDSE_ACT_LRELU) t = t > 0.f ? t : t * slope;
+        if (res != nullptr) t += r[e];
+        v[e] = t;
+      }
+      Vec16<T>::store(y + off, v);
+    }
+  }
+}
+
+template <typename T, int P, int PHASE>
+__global__ __launch_bounds__(256, (P == 8 ? 3 : 2)) void inorm_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                             T* __restrict__ dx,
+                                                                             const float* __restrict__ stats, float* partial,
+                                                                             unsigned* count, int act, float slope,
+                                                                             FusedGeom g) {
+  constexpr int VE = Vec16<T>::N;
+  __shared__ float red[256 * VE * 2];
+  __shared__ int s_ctl[2];
+  const int tid = threadIdx.x;
+  const int tx = tid & (g.TX - 1), ty = tid >> g.tx_shift;
+  const int split = blockIdx.x % g.splits, grp = blockIdx.x / g.splits;
+  const int cb = grp % g.col_blocks, n = grp / g.col_blocks;
+  const int col = cb * g.TX + tx;
+  const bool on = col < g.cv;
+  const int c0 = (on ? col : 0) * VE;
+  const long long base = (long long)n * g.HW * g.Cs + c0;
+  const int p0 = split * g.span + ty;
+  u32x4 xv[P], gv[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int p = p0 + i * g.TY;
+    if (on && p < g.HW) {
+      xv[i] = *reinterpret_cast<const u32x4*>(x + base + (long long)p * g.Cs);
+      gv[i] = *reinterpret_cast<const u32x4*>(dy + base + (long long)p * g.Cs);
+    }
+  }
+  float mean[VE], rstd[VE], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  {
+    const float* st = stats + ((long long)n * g.Cs + c0) * 2;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { mean[e] = st[2 * e]; rstd[e] = st[2 * e + 1]; }
+  }
+  if constexpr (PHASE == 2) {
+    const float* rows = partial + (long long)grp * g.splits * g.nv;
+    const float total = tid < g.nv ? sum_rows<false>(rows + tid, g.splits, g.nv) : 0.f;
+    if (tid < g.nv) red[tid] = total;
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const int p = p0 + i * g.TY;
+      if (on && p < g.HW) {
+        float v[VE], gr[VE];
+        Vec16<T>::unpack(xv[i], v);
+        Vec16<T>::unpack(gv[i], gr);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const float yh = (v[e] - mean[e]) * rstd[e];
+          const float dz = gr[e] * act_grad(yh, act, slope);
+          s1[e] += dz;
+          s2[e] += dz * yh;
+        }
+      }
+    }
+    const float tsum = block_row<VE>(red, s1, s2, g);
+    if constexpr (PHASE == 1) {
+      if (tid < g.nv) partial[((long long)grp * g.splits + split) * g.nv + tid] = tsum;
+      return;
+    } else {
+      exchange_totals<VE>(red, s_ctl, tsum, partial, count, grp, split, g);
+    }
+  }
+  float m1[VE], m2[VE];
+  const float inv = 1.f / (float)g.HW;
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    m1[e] = red[(tx * VE + e) * 2] * inv;
+    m2[e] = red[(tx * VE + e) * 2 + 1] * inv;
+  }
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int p = p0 + i * g.TY;
+    if (on && p < g.HW) {
+      float v[VE], gr[VE];
+      Vec16<T>::unpack(xv[i], v);
+      Vec16<T>::unpack(gv[i], gr);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float yh = (v[e] - mean[e]) * rstd[e];
+        const float dz = gr[e] * act_grad(yh, act, slope);
+        v[e] = rstd[e] * (dz - m1[e] - yh * m2[e]);
+      }
+      Vec16<T>::store(dx + base + (long long)p * g.Cs, v);
+    }
+  }
+}
+
+// One-kernel form only: zeroed count words, each used by one group of one launch; a (device, stream) ring that a
+// stream-ordered memset refills when it runs out (every ~2000 launches).
+constexpr int kCountSlots = 1 << 16;
+struct SyncState { unsigned* dev = nullptr; int cursor = 0; };
+static unsigned* count_slots(hipStream_t s, int groups) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SyncState> table;
+  int dev = 0;
+  if (groups > kCountSlots || hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  SyncState& st = table[std::make_pair(dev, s)];
+  if (st.dev == nullptr) {
+    if (hipMalloc(reinterpret_cast<void**>(&st.dev), kCountSlots * sizeof(unsigned)) != hipSuccess) return nullptr;
+    st.cursor = kCountSlots;     // forces the first fill
+  }
+  if (st.cursor + groups > kCountSlots) {
+    if (hipMemsetAsync(st.dev, 0, kCountSlots * sizeof(unsigned), s) != hipSuccess) return nullptr;
+    st.cursor = 0;
+  }
+  unsigned* p = st.dev + st.cursor;
+  st.cursor += groups;
+  return p;
+}
+
+// blocks of `kernel` that are resident at once (the exchange must never wait for a block that cannot start)
+template <typename K> static int resident_blocks(K kernel) {
+  int occ = 0, cus = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return occ * cus;
+}
+
+// Pixels held per thread for the register-held forms (0: moment -> finalize -> apply).  `one`: the one-kernel form is wanted.
+template <typename T, bool BWD> static int reg_pick(const jpdse_inorm_desc* d, bool one, FusedGeom* out) {
+  constexpr int VE = Vec16<T>::N;
+  static int cap8 = -1, cap16 = -1;
+  if (one && cap8 < 0) {
+    if (BWD) {
+      cap8 = resident_blocks(inorm_reg_bwd_kernel<T, 8, 0>);
+      cap16 = resident_blocks(inorm_reg_bwd_kernel<T, 16, 0>);
+    } else {
+      cap8 = resident_blocks(inorm_reg_fwd_kernel<T, 8, 0>);
+      cap16 = resident_blocks(inorm_reg_fwd_kernel<T, 16, 0>);
+    }
+  }
+  for (int P = 8; P <= 16; P *= 2) {
+    const FusedGeom g = fused_geom(d->N, d->H * d->W, cpad(d->C), VE, P);
+    const long long groups = (long long)d->N * g.col_blocks, blocks = groups * g.splits;
+    if (g.splits > 64 || blocks > (1ll << 30)) continue;
+    if (one && (groups > kCountSlots || blocks > (P == 8 ? cap8 : cap16))) continue;
+    *out = g;
+    return P;
+  }
+  return 0;
+}
+
+static size_t reg_ws_bytes(const jpdse_inorm_desc* d) {
+  // sized for either P (P = 8 has the larger split count); 0 when the register-held forms do not apply
+  const int VE = d->dtype == JPDSE_BF16 ? 8 : 4;
+  const FusedGeom g = fused_geom(d->N, d->H * d->W, cpad(d->C), VE, 8);
+  if (g.splits > 128) return 0;
+  return align_up((size_t)d->N * g.col_blocks * g.splits * g.nv * sizeof(float), 256);
+}
+
+template <typename T, int P>
+static int launch_reg_fwd(int form, const FusedGeom& fg, const jpdse_inorm_desc* d, const void* x, const void* res, void* y,
+                          float* stats, float* part, unsigned* count, hipStream_t s) {
+  const dim3 grid((unsigned)((size_t)d->N * fg.col_blocks * fg.splits));
+  const T* xp = reinterpret_cast<const T*>(x);
+  const T* rp = reinterpret_cast<const T*>(res);
+  T* yp = reinterpret_cast<T*>(y);
+  if (form == 2) {
+    hipLaunchKernelGGL((inorm_reg_fwd_kernel<T, P, 0>), grid, dim3(256), 0, s, xp, rp, yp, stats, part, count, d->act, d->slope,
+                       d->eps, fg);
+    return check_launch("inorm one-kernel fwd");
+  }
+  hipLaunchKernelGGL((inorm_reg_fwd_kernel<T, P, 1>), grid, dim3(256), 0, s, xp, rp, yp, stats, part, count, d->act, d->slope,
+                     d->eps, fg);
+  if (int rc = check_launch("inorm rows fwd")) return rc;
+  hipLaunchKernelGGL((inorm_reg_fwd_kernel<T, P, 2>), grid, dim3(256), 0, s, xp, rp, yp, stats, part, count, d->act, d->slope,
+                     d->eps, fg);
+  return check_launch("inorm apply-from-rows fwd");
+}
+
+template <typename T, int P>
+static int launch_reg_bwd(int form, const FusedGeom& fg, const jpdse_inorm_desc* d, const void* x, const float* stats,
+                          const void* dy, void* dx, float* part, unsigned* count, hipStream_t s) {
+  const dim3 grid((unsigned)((size_t)d->N * fg.col_blocks * fg.splits));
+  const T* xp = reinterpret_cast<const T*>(x);
+  const T* gp = reinterpret_cast<const T*>(dy);
+  T* dp = reinterpret_cast<T*>(dx);
+  if (form == 2) {
+    hipLaunchKernelGGL((inorm_reg_bwd_kernel<T, P, 0>), grid, dim3(256), 0, s, xp, gp, dp, stats, part, count, d->act, d->slope,
+                       fg);
+    return check_launch("inorm one-kernel bwd");
+  }
+  hipLaunchKernelGGL((inorm_reg_bwd_kernel<T, P, 1>), grid, dim3(256), 0, s, xp, gp, dp, stats, part, count, d->act, d->slope, fg);
+  if (int rc = check_launch("inorm rows bwd")) return rc;
+  hipLaunchKernelGGL((inorm_reg_bwd_kernel<T, P, 2>), grid, dim3(256), 0, s, xp, gp, dp, stats, part, count, d->act, d->slope, fg);
+  return check_launch("inorm apply-from-rows bwd");
+}
+
+// 1 = handled by a register-held form, 0 = not applicable, < 0 = error
+template <typename T>
+static int try_reg_fwd(const jpdse_inorm_desc* d, const void* x, const void* res, void* y, float* stats, void* ws,
+                       hipStream_t s) {
+  int form = norm_form();
+  if (form == 0) return 0;
+  FusedGeom fg;
+  int P = reg_pick<T, false>(d, form == 2, &fg);
+  if (P == 0 && form == 2) { form = 1; P = reg_pick<T, false>(d, false, &fg); }
+  if (P == 0) return 0;
+  unsigned* count = nullptr;
+  if (form == 2 && fg.splits > 1) {
+    count = count_slots(s, d->N * fg.col_blocks);
+    if (count == nullptr) form = 1;
+  }
+  float* part = reinterpret_cast<float*>(ws);
+  const int rc = P == 8 ? launch_reg_fwd<T, 8>(form, fg, d, x, res, y, stats, part, count, s)
+                        : launch_reg_fwd<T, 16>(form, fg, d, x, res, y, stats, part, count, s);
+  return rc == JPDSE_OK ? 1 : -1;
+}
+
+template <typename T>
+static int try_reg_bwd(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy, void* dx, void* ws,
+                       hipStream_t s) {
+  int form = norm_form();
+  if (form == 0) return 0;
+  FusedGeom fg;
+  int P = reg_pick<T, true>(d, form == 2, &fg);
+  if (P == 0 && form == 2) { form = 1; P = reg_pick<T, true>(d, false, &fg); }
+  if (P == 0) return 0;
+  unsigned* count = nullptr;
+  if (form == 2 && fg.splits > 1) {
+    count = count_slots(s, d->N * fg.col_blocks);
+    if (count == nullptr) form = 1;
+  }
+  float* part = reinterpret_cast<float*>(ws);
+  const int rc = P == 8 ? launch_reg_bwd<T, 8>(form, fg, d, x, stats, dy, dx, part, count, s)
+                        : launch_reg_bwd<T, 16>(form, fg, d, x, stats, dy, dx, part, count, s);
+  return rc == JPDSE_OK ? 1 : -1;
+}
+
 static int validate(const jpdse_inorm_desc* d) {
   JPDSE_REQUIRE(d != nullptr, "inorm: null descriptor");
   JPDSE_REQUIRE(d->dtype == JPDSE_F32 || d->dtype == JPDSE_BF16, "inorm: bad dtype");
@@ -307,7 +755,8 @@ static size_t ws_bytes_for(const jpdse_inorm_desc* d) {
   MomentGeom g = moment_geom(d->N, d->H * d->W, cpad(d->C), VE);
   const size_t partial = (size_t)d->N * g.splits * g.Cs * 2 * sizeof(float);
   const size_t sums = (size_t)d->N * g.Cs * 2 * sizeof(float);
-  return align_up(partial, 256) + align_up(sums, 256);
+  const size_t three = align_up(partial, 256) + align_up(sums, 256), one = reg_ws_bytes(d);
+  return three > one ? three : one;
 }
 
 template <typename T>
@@ -315,6 +764,10 @@ static int inorm_fwd_t(const jpdse_inorm_desc* d, const void* x, const void* res
                        hipStream_t s) {
   constexpr int VE = Vec16<T>::N;
   const int HW = d->H * d->W, Cs = cpad(d->C);
+  {
+    const int r = try_reg_fwd<T>(d, x, res, y, stats, ws, s);
+    if (r != 0) return r > 0 ? JPDSE_OK : JPDSE_ELAUNCH;
+  }
   MomentGeom g = moment_geom(d->N, HW, Cs, VE);
   float* partial = reinterpret_cast<float*>(ws);
   const int col_blocks = (g.cv + g.TX - 1) / g.TX;
@@ -335,6 +788,10 @@ static int inorm_bwd_t(const jpdse_inorm_desc* d, const void* x, const float* st
                        void* ws, hipStream_t s) {
   constexpr int VE = Vec16<T>::N;
   const int HW = d->H * d->W, Cs = cpad(d->C);
+  {
+    const int r = try_reg_bwd<T>(d, x, stats, dy, dx, ws, s);
+    if (r != 0) return r > 0 ? JPDSE_OK : JPDSE_ELAUNCH;
+  }
   MomentGeom g = moment_geom(d->N, HW, Cs, VE);
   float* partial = reinterpret_cast<float*>(ws);
   float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +

@@ -30,6 +30,7 @@ LAYERS = [
   ('G last 7x7 64->3',             512, 1024, 64, 3, 7, 1, 3, PAD_REFLECT, False),
   ('VGG conv1_1 3->64',            512, 1024, 3, 64, 3, 1, 1, PAD_ZERO, False),
   ('VGG conv1_2 64->64',           512, 1024, 64, 64, 3, 1, 1, PAD_ZERO, False),
+  ('VGG conv2_1 64->128',          256, 512, 64, 128, 3, 1, 1, PAD_ZERO, False),
   ('VGG conv2_2 128->128',         256, 512, 128, 128, 3, 1, 1, PAD_ZERO, False),
   ('VGG conv3_x 256->256',         128, 256, 256, 256, 3, 1, 1, PAD_ZERO, False),
   ('VGG conv4_x 512->512',         64, 128, 512, 512, 3, 1, 1, PAD_ZERO, False),

@@ -101,6 +101,14 @@ CONV_CASES = [
     ('taps_3x3s1_refl', 2, 36, 100, 64, 64,  3, 1, 1,  PAD_REFLECT, ACT_NONE),
     ('taps_4x4s2',     2, 38, 140, 64,  128, 4, 2, 2,  PAD_ZERO,    ACT_LRELU),
     ('taps_3x3s2_256', 1, 80, 136, 128, 256, 3, 2, 1,  PAD_ZERO,    ACT_NONE),
+    # filter-in-registers row-streaming kernel (conv_rows.h: 64-channel inputs, 3x3, zero pad): stride 2 with 128 / 64
+    # outputs (4 x 1 / 2 x 2 waves), stride 1 likewise; several strips, several bands, bands of 16 rows (steady-state
+    # look-ahead), borders on every side; the data gradient of the 64-output cases runs on it too
+    ('rows_s2_128',    2, 16, 128, 64,  128, 3, 2, 1,  PAD_ZERO,    ACT_NONE),
+    ('rows_s2_64',     1, 24, 256, 64,  64,  3, 2, 1,  PAD_ZERO,    ACT_LRELU),
+    ('rows_s2_tall',   1, 64, 128, 64,  128, 3, 2, 1,  PAD_ZERO,    ACT_RELU),
+    ('rows_s1_64',     2, 12, 128, 64,  64,  3, 1, 1,  PAD_ZERO,    ACT_RELU),
+    ('rows_s1_128',    1, 32, 192, 64,  128, 3, 1, 1,  PAD_ZERO,    ACT_NONE),
 ]
 
 
@@ -189,6 +197,7 @@ def test_halo_kernel_mfma_16x16x32_variant(name):
 FUSED_RELU_CASES = [
     ('halo_64to128',  1, 8,  64, 64,  128, 3, 1, 1, PAD_ZERO),
     ('halo_128to64',  2, 4,  64, 128, 64,  3, 1, 1, PAD_ZERO),
+    ('rows_64to64',   2, 16, 128, 64, 64,  3, 1, 1, PAD_ZERO),
     ('fast_s2',       1, 24, 40, 64,  128, 3, 2, 1, PAD_ZERO),
     ('splitk',        1, 10, 24, 256, 256, 3, 1, 1, PAD_ZERO),
     ('generic_small', 2, 9,  11, 16,  24,  3, 1, 1, PAD_ZERO),
@@ -310,6 +319,65 @@ def test_instance_norm_act(shape, act, dtype):
   dx = layer.bwd(ctx, to_act(gy, dtype))
   assert_close(to_nchw(dx), xr.grad, 3 * tol, 'inorm bwd')
 
+
+
+# register-held InstanceNorm forms (norm.hip, inorm_reg_*): shapes with several pixel splits per (image, channel block), a
+# ragged last split, a ragged channel block, both register depths (8 / 16 pixels per thread), and one tensor with too many
+# splits (three-kernel form).  Checked against torch, against the three-kernel form and the one-kernel form (in-launch
+# exchange) of the developer build, and for run-to-run bit equality (partial rows are summed in split order).
+FUSED_NORM_SHAPES = [
+    ('resblock_real', (4, 1024, 32, 64), True),    # the 36 ResnetBlock norms of the bench step: 512 blocks, 16 splits
+    ('ragged_cols',   (2, 72, 40, 50), False),     # 9 channel vectors in a 16-wide block, 16 splits of 128 pixels
+    ('d_scale2_p16',  (8, 128, 65, 129), False),   # 8385 pixels: 33 splits of 256 (16 pixels per thread), ragged tail
+    ('down3_p16',     (2, 512, 64, 128), False),
+    ('too_large',     (1, 64, 512, 512), False),   # 512 splits: stays on moment -> finalize -> apply
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('name,shape,with_res', FUSED_NORM_SHAPES, ids=[c[0] for c in FUSED_NORM_SHAPES])
+def test_instance_norm_exchange(name, shape, with_res, dtype):
+  N, C, H, W = shape
+  g = G(zlib.crc32(name.encode()) & 0xffff)
+  x = quantize_like(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.7, dtype)
+  res = quantize_like(torch.randn(N, C, H, W, generator=g), dtype) if with_res else None
+  gy = quantize_like(torch.randn(N, C, H, W, generator=g), dtype)
+  act = ACT_NONE if with_res else ACT_RELU
+  xr = x.clone().requires_grad_(True)
+  y_ref = F.instance_norm(xr, eps=1e-5)
+  y_ref = y_ref + res if with_res else F.relu(y_ref)
+  y_ref.backward(gy)
+  xa, ga = to_act(x, dtype), to_act(gy, dtype)
+  ra = to_act(res, dtype) if with_res else None
+
+  def run():
+    y, stats = ops.inorm_fwd(xa, act, 0.2, 1e-5, ra)
+    dx = ops.inorm_bwd(xa, stats, ga, act, 0.2, 1e-5)
+    torch.cuda.synchronize()
+    return y, stats, dx
+
+  y, stats, dx = run()
+  tol = RTOL[dtype]
+  assert_close(to_nchw(y), y_ref.detach(), tol, 'inorm fwd')
+  assert_close(to_nchw(dx), xr.grad, 3 * tol, 'inorm bwd')
+  for rep in range(3):                      # every launch uses a fresh epoch of the exchange flags
+    y2, stats2, dx2 = run()
+    assert torch.equal(y2.t, y.t) and torch.equal(stats2, stats) and torch.equal(dx2.t, dx.t), 'not reproducible'
+  with jpdse_hip.dev_mode(27):              # developer build: always the three-kernel form
+    y3, stats3, dx3 = run()
+  # same math, different summation order: fp32 sums of <= 8385 terms
+  st_tol = 2e-5
+  assert_close(stats3.cpu()[:, :C], stats.cpu()[:, :C], st_tol, 'stats vs three-kernel form')
+  assert_close(to_nchw(y3), to_nchw(y), tol, 'fwd vs three-kernel form')
+  assert_close(to_nchw(dx3), to_nchw(dx), 3 * tol, 'bwd vs three-kernel form')
+  with jpdse_hip.dev_mode(28):              # one kernel, rows exchanged inside the launch: the same sums in the same order
+    y4, stats4, dx4 = run()                 # (the epilogue arithmetic is compiled per kernel: equal to an ulp, not bitwise)
+    assert_close(stats4.cpu()[:, :C], stats.cpu()[:, :C], 1e-6, 'stats vs one-kernel form')
+    assert_close(to_nchw(y4), to_nchw(y), tol, 'fwd vs one-kernel form')
+    assert_close(to_nchw(dx4), to_nchw(dx), 3 * tol, 'bwd vs one-kernel form')
+    for rep in range(3):
+      y5, stats5, dx5 = run()
+      assert torch.equal(y5.t, y4.t) and torch.equal(stats5, stats4) and torch.equal(dx5.t, dx4.t), 'one-kernel form not reproducible'
 
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_resnet_block(dtype):
