@@ -643,7 +643,9 @@ template <typename T, bool BWD> static int reg_pick(const jpdse_inorm_desc* d, b
       cap16 = resident_blocks(inorm_reg_fwd_kernel<T, 16, 0>);
     }
   }
-  for (int P = 8; P <= 16; P *= 2) {
+  // two-kernel form: 8 pixels per thread only -- with 16 (tensors of 17-34 MB) it measured equal or slower than the
+  // three-kernel form (profiles/r02_norm_forms.txt)
+  for (int P = 8; P <= (one ? 16 : 8); P *= 2) {
     const FusedGeom g = fused_geom(d->N, d->H * d->W, cpad(d->C), VE, P);
     const long long groups = (long long)d->N * g.col_blocks, blocks = groups * g.splits;
     if (g.splits > 64 || blocks > (1ll << 30)) continue;
