@@ -85,6 +85,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "head_fwd.h"
 #include "thin_fwd.h"
 #include "conv_rows.h"
+#include "dgrad2_rows.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1348,6 +1349,32 @@ static int launch_rows(const RowsArgs& a, int stride, hipStream_t s) {
   return fused ? launch_rows_cfg<2, 2, true>(a, s) : launch_rows_cfg<2, 2, false>(a, s);
 }
 
+
+// data gradient of the 64 -> 128 3x3 stride-2 conv / forward of the 128 -> 64 ConvTranspose2d at full resolution (dgrad2_rows.h)
+static int launch_dgrad2_rows(Dgrad2Args a, hipStream_t s) {
+  typedef Dgrad2Geom G;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "dgrad2_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
+    configured = true;
+  }
+  a.strips = a.OW / 64;
+  int th = 0;
+  for (int cand = 64; cand >= 4; cand >>= 1) {
+    if (a.OH % cand != 0) continue;
+    if ((long long)a.N * a.strips * (a.OH / cand) >= 256) { th = cand; break; }
+  }
+  if (th == 0)
+    for (int cand = 16; cand >= 4; cand >>= 1)
+      if (a.OH % cand == 0) { th = cand; break; }
+  a.TH = th;
+  a.bands = a.OH / th;
+  hipLaunchKernelGGL(dgrad2_rows_kernel, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
+  return check_launch("dgrad2_rows_kernel");
+}
+
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
 // gradient of the zero-padded ones): LDS-resident input halo, see gemm_halo.h
 static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_out) {
@@ -1993,6 +2020,20 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.tiles_w = (d->W + 63) / 64;
       h.tiles_h = (d->H + kHeadTH - 1) / kHeadTH;
       return launch_head_fwd<64, 3, 3, 3>(h, s);
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (g_fast_enabled && g_rows_enabled && !refl && st == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && p.Ks == 128 && p.Cs == 64 &&
+        d->C == 64 && d->H == 2 * p.OH && d->W == 2 * p.OW && p.OW % 64 == 0 && p.OH % 4 == 0 && p.nph == 4 &&
+        mask == nullptr && addend == nullptr) {
+      Dgrad2Args g = {};
+      g.DY = reinterpret_cast<const bf16_t*>(dy);
+      for (int i = 0; i < 4; ++i) g.P[i] = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + p.ph[i].pack_off);
+      g.DX = reinterpret_cast<bf16_t*>(dx);
+      g.N = d->N;
+      g.OH = p.OH;
+      g.OW = p.OW;
+      return launch_dgrad2_rows(g, s);
     }
   }
   bool fast = false;

@@ -90,19 +90,20 @@ template <int STRIDE, int WC> struct RowsGeom {
   static constexpr int LDS = NR * ROWB + 4 * WTILE;
 };
 
-// s_waitcnt vmcnt(BASE + k * STEP), k = 0 .. 8 chosen at run time (the immediate must be a constant)
-template <int BASE, int STEP> __device__ __forceinline__ void wait_vmcnt_sel(int k) {
-  static_assert(BASE + 8 * STEP <= 63, "vmcnt is a 6-bit counter");
+// s_waitcnt vmcnt(BASE + k * STEP), k = 0 .. MAXK chosen at run time (the immediate must be a constant)
+template <int BASE, int STEP, int MAXK = 8> __device__ __forceinline__ void wait_vmcnt_sel(int k) {
+  static_assert(MAXK <= 8 && BASE + MAXK * STEP <= 63, "vmcnt is a 6-bit counter");
+  constexpr auto at = [](int j) constexpr { return BASE + (j < MAXK ? j : MAXK) * STEP; };
   switch (k) {
-    case 0: wait_vmcnt<BASE>(); break;
-    case 1: wait_vmcnt<BASE + STEP>(); break;
-    case 2: wait_vmcnt<BASE + 2 * STEP>(); break;
-    case 3: wait_vmcnt<BASE + 3 * STEP>(); break;
-    case 4: wait_vmcnt<BASE + 4 * STEP>(); break;
-    case 5: wait_vmcnt<BASE + 5 * STEP>(); break;
-    case 6: wait_vmcnt<BASE + 6 * STEP>(); break;
-    case 7: wait_vmcnt<BASE + 7 * STEP>(); break;
-    default: wait_vmcnt<BASE + 8 * STEP>(); break;
+    case 0: wait_vmcnt<at(0)>(); break;
+    case 1: wait_vmcnt<at(1)>(); break;
+    case 2: wait_vmcnt<at(2)>(); break;
+    case 3: wait_vmcnt<at(3)>(); break;
+    case 4: wait_vmcnt<at(4)>(); break;
+    case 5: wait_vmcnt<at(5)>(); break;
+    case 6: wait_vmcnt<at(6)>(); break;
+    case 7: wait_vmcnt<at(7)>(); break;
+    default: wait_vmcnt<at(8)>(); break;
   }
 }
 
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && WC == 2) ? 2 : 1)) void conv_
         if (i == 0) { if (wid < EXTRA) wait_vmcnt<B1>(); else wait_vmcnt<B0>(); }
       } else {
         const int k = i < G::LA ? i : G::LA;                  // iterations whose NST stores may still be in flight
-        if (wid < EXTRA) wait_vmcnt_sel<B1, NST>(k); else wait_vmcnt_sel<B0, NST>(k);
+        if (wid < EXTRA) wait_vmcnt_sel<B1, NST, G::LA>(k); else wait_vmcnt_sel<B0, NST, G::LA>(k);
       }
     }
     __builtin_amdgcn_s_barrier();     // every wave's pieces of these rows landed; the slots issued below were last read in i-1

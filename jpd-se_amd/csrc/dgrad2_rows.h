@@ -1,0 +1,226 @@
+// Data gradient of the 3x3 stride-2 pad-1 convolution 64 -> 128 at full resolution (G's first down-sampling conv, and --
+// the same operator -- the forward of the last ConvTranspose2d 128 -> 64, networks.py:215,244): dy has 128 channels at
+// 256x512, dx 64 channels at 512x1024.  As four stride-phase GEMMs on the tiled kernel it runs at 310 TFLOP/s: K-dims
+// of 128..512 (2..8 K-tiles) never fill a pipeline, dy is re-staged once per phase and tap, the filter once per tile.
+//
+// conv_rows.h's scheme, transposed: the FILTER LIVES IN REGISTERS, dy streams through LDS once, and one pass over a dy
+// row produces BOTH output rows it feeds, all four phases at once:
+//   dx[2a  ][2b  ] = dy[a][b] W11                                   (phase qh=1,qw=1: one tap)
+//   dx[2a  ][2b+1] = dy[a][b] W10' + dy[a][b+1] W10''               (two taps)
+//   dx[2a+1][2b  ] = dy[a][b] W01' + dy[a+1][b] W01''               (two taps)
+//   dx[2a+1][2b+1] = dy[a][b] W00' + dy[a][b+1] .. + dy[a+1][b] .. + dy[a+1][b+1] ..   (four taps)
+// (W.. = the stride-phase panels of the packed data-gradient filter, taps already flipped by the packer.)
+// A block owns 64 dy columns x TH dy rows; wave w owns output channels [16w, 16w+16) for all phases: 9 taps x 4 k-steps of
+// v_mfma_f32_16x16x32_bf16 B fragments = 144 VGPRs, loaded once.  Per dy row and 16-pixel m-tile the four A fragments
+// (dy[a|a+1][b|b+1]) feed 9 MFMAs per k-step; reads are inline asm, two (m-tile, k-step) units ahead, counted lgkmcnt.
+// The 2 x 128 output pixels of a dy row go through one LDS tile and leave as full 128-byte pixels (8 lanes x 16 B).
+#pragma once
+#include "common.h"
+#include "gemm_fast.h"
+#include "gemm_halo.h"
+#include "head_fwd.h"
+#include "conv_rows.h"
+
+namespace jpdse {
+
+struct Dgrad2Args {
+  const bf16_t* DY;      // [N][OH][OW][128]
+  const bf16_t* P[4];    // phase panels, plan order (qh, qw) = (0,0), (0,1), (1,0), (1,1); rows = 64 output channels
+  bf16_t* DX;            // [N][2 OH][2 OW][64]
+  int N, OH, OW;
+  int TH, bands, strips;
+};
+
+struct Dgrad2Geom {
+  static constexpr int PIX = 65;                       // staged dy pixels per row (64 + the right neighbour)
+  static constexpr int UNITS = (PIX * 256 + 1023) / 1024;   // 1 KiB DMA units: 4 pixels x 256 B
+  static constexpr int ROWB = UNITS * 1024;
+  static constexpr int LA = 5, NR = LA + 2;            // rows in flight ahead of the two in use
+  static constexpr int PITCH = 128 + 16;               // output tile: [2][128 pixels] x (64 channels bf16 + pad)
+  static constexpr int TILE = 2 * 128 * PITCH;
+  static constexpr int LDS = NR * ROWB + TILE;
+};
+
+__global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
+  typedef Dgrad2Geom G;
+  constexpr int U0 = G::UNITS / 4, U1 = U0 + 1, EXTRA = G::UNITS % 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int strip = b % a.strips; b /= a.strips;
+  const int band = b % a.bands;
+  const int n = b / a.bands;
+  const int a0 = band * a.TH, b0 = strip * 64;
+  const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const uint32_t smem0 = lds_addr32(smem);
+  const uint32_t tile0 = smem0 + G::NR * G::ROWB;
+
+  // ---- loader: this wave's units of a dy row (u = wid, wid + 4, ...): 4 pixels x 16 chunks of 16 B per unit
+  int col_off[U1];
+#pragma unroll
+  for (int k = 0; k < U1; ++k) {
+    const int u = wid + 4 * k;
+    const int lp = u * 4 + (lane >> 4);                // LDS pixel = dy column b0 + lp
+    const int bw = b0 + lp;
+    const bool ok = u < G::UNITS && lp < G::PIX && bw < a.OW;
+    const int chunk = ((lane & 15) ^ lp) & 15;         // conflict-free for the 16x16x32 A fragment reads (see below)
+    col_off[k] = ok ? bw * 128 + chunk * 8 : -1;
+  }
+  const bf16_t* const img = a.DY + (long long)n * a.OH * a.OW * 128;
+  const int row_elems = a.OW * 128;
+  auto issue_row = [&](int jr, int slot) {             // dy row a0 + jr -> ring slot
+    const int ih = a0 + jr;
+    const bool row_ok = ih < a.OH;
+    const bf16_t* const xrow = img + (row_ok ? ih : 0) * (long long)row_elems;
+    char* const dst = smem + slot * G::ROWB;
+#pragma unroll
+    for (int k = 0; k < U1; ++k) {
+      if (k < U0 || wid < EXTRA) {
+        const bf16_t* src = (row_ok && col_off[k] >= 0) ? xrow + col_off[k] : zero;
+        glds16(src, dst + (wid + 4 * k) * 1024);
+      }
+    }
+  };
+#pragma unroll
+  for (int jr = 0; jr <= G::LA; ++jr) issue_row(jr, jr);
+
+  // ---- filter slice: B[t][ks], t = 0: ee | 1, 2: eo | 3, 4: oe | 5..8: oo (order of use below)
+  s16x8 breg[36];
+  {
+    const int c = wid * 16 + (lane & 15);              // output channel (row of the panels)
+    const int kq = (lane >> 4) * 8;
+    // phase (qh, qw): Uh = qh ? 1 : 2, Uw = qw ? 1 : 2; element [c][up][wp][k] at c * Uh * Uw * 128 + (up * Uw + wp) * 128 + k
+    const bf16_t* const p00 = a.P[0] + (long long)c * 512 + kq;   // (0,0): 2 x 2 taps
+    const bf16_t* const p01 = a.P[1] + (long long)c * 256 + kq;   // (0,1): 2 x 1
+    const bf16_t* const p10 = a.P[2] + (long long)c * 256 + kq;   // (1,0): 1 x 2
+    const bf16_t* const p11 = a.P[3] + (long long)c * 128 + kq;   // (1,1): 1 x 1
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      breg[0 * 4 + ks] = *reinterpret_cast<const s16x8*>(p11 + ks * 32);
+      breg[1 * 4 + ks] = *reinterpret_cast<const s16x8*>(p10 + 0 * 128 + ks * 32);     // wp = 0: dy[a][b]
+      breg[2 * 4 + ks] = *reinterpret_cast<const s16x8*>(p10 + 1 * 128 + ks * 32);     // wp = 1: dy[a][b+1]
+      breg[3 * 4 + ks] = *reinterpret_cast<const s16x8*>(p01 + 0 * 128 + ks * 32);     // up = 0: dy[a][b]
+      breg[4 * 4 + ks] = *reinterpret_cast<const s16x8*>(p01 + 1 * 128 + ks * 32);     // up = 1: dy[a+1][b]
+      breg[5 * 4 + ks] = *reinterpret_cast<const s16x8*>(p00 + 0 * 128 + ks * 32);     // (0,0): dy[a][b]
+      breg[6 * 4 + ks] = *reinterpret_cast<const s16x8*>(p00 + 1 * 128 + ks * 32);     // (0,1): dy[a][b+1]
+      breg[7 * 4 + ks] = *reinterpret_cast<const s16x8*>(p00 + 2 * 128 + ks * 32);     // (1,0): dy[a+1][b]
+      breg[8 * 4 + ks] = *reinterpret_cast<const s16x8*>(p00 + 3 * 128 + ks * 32);     // (1,1): dy[a+1][b+1]
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 36; ++t) asm volatile("" : "+v"(breg[t]));
+
+  // A fragment addressing (16x16x32: lane -> pixel lane & 15, 8 k-values at 8 * (lane >> 4)): byte offset inside a ring row
+  // of pixel px, k-step ks: px * 256 + ((ks * 4 + (lane >> 4)) ^ (px & 15)) * 16
+  int a_px[4][2];                                       // [m-tile][column shift]
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) a_px[mt][sh] = mt * 16 + (lane & 15) + sh;
+  const int kc = lane >> 4;
+  const int odd = lane & 1;
+  const long long img_out = (long long)n * (2 * a.OH) * (2 * a.OW) * 64;
+
+  int base = 0;                                         // ring slot of dy row a0 + i
+  int nslot = (G::LA + 1) % G::NR, njr = G::LA + 1;
+  for (int i = 0; i < a.TH; ++i) {
+    // row i+1 landed (row i landed an iteration earlier); behind it: LA-1 rows and the tile stores of up to LA-1 iterations
+    {
+      int k = i - 1;
+      k = k < 0 ? 0 : (k > G::LA - 1 ? G::LA - 1 : k);
+      if (wid < EXTRA) wait_vmcnt_sel<(G::LA - 1) * U1, 8, G::LA - 1>(k); else wait_vmcnt_sel<(G::LA - 1) * U0, 8, G::LA - 1>(k);
+    }
+    __builtin_amdgcn_s_barrier();       // A: rows i, i+1 complete for every wave; the tile of iteration i-1 is written
+    asm volatile("" ::: "memory");
+    if (i > 0) {
+      // ---- tile of dy row i-1 -> dx rows 2(a0+i-1), +1: 256 pixels x 128 B, 8 x 16 B per thread
+      const long long orow = img_out + (long long)(2 * (a0 + i - 1)) * (2 * a.OW) * 64 + (long long)(2 * b0) * 64;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = tid + 256 * k;
+        const int pxl = idx >> 3, part = idx & 7;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + pxl * G::PITCH + part * 16);
+        *reinterpret_cast<u32x4*>(a.DX + orow + (long long)(pxl >> 7) * (2 * a.OW) * 64 + (pxl & 127) * 64 + part * 8) = val;
+      }
+    }
+    issue_row(njr, nslot);
+    ++njr;
+    nslot = nslot + 1 == G::NR ? 0 : nslot + 1;
+
+    f32x4 acc[4][4];                                    // [m-tile][ee, eo, oe, oo]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) acc[mt][ph] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t r0 = smem0 + base * G::ROWB;
+    const uint32_t r1 = smem0 + (base + 1 == G::NR ? 0 : base + 1) * G::ROWB;
+    s16x8 fr[3][4];                                     // [unit in flight][dy[a][b], dy[a][b+1], dy[a+1][b], dy[a+1][b+1]]
+    auto rd = [&](int u, s16x8 (&f)[4]) {               // unit u = mt * 4 + ks
+      const int mt = u >> 2, ks = u & 3;
+      const int c = ks * 4 + kc;
+      const uint32_t o0 = (a_px[mt][0] << 8) + (((c ^ a_px[mt][0]) & 15) << 4);
+      const uint32_t o1 = (a_px[mt][1] << 8) + (((c ^ a_px[mt][1]) & 15) << 4);
+      f[0] = lds_read128_asm(r0 + o0);
+      f[1] = lds_read128_asm(r0 + o1);
+      f[2] = lds_read128_asm(r1 + o0);
+      f[3] = lds_read128_asm(r1 + o1);
+    };
+    rd(0, fr[0]);
+    rd(1, fr[1]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (u + 2 < 16) rd(u + 2, fr[(u + 2) % 3]);
+      s16x8 (&f)[4] = fr[u % 3];
+      if (u + 2 < 16) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+      else if (u + 1 < 16) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+      const int mt = u >> 2, ks = u & 3;
+      acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], breg[0 * 4 + ks], acc[mt][0], 0, 0, 0);
+      acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], breg[1 * 4 + ks], acc[mt][1], 0, 0, 0);
+      acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], breg[3 * 4 + ks], acc[mt][2], 0, 0, 0);
+      acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[0], breg[5 * 4 + ks], acc[mt][3], 0, 0, 0);
+      acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], breg[2 * 4 + ks], acc[mt][1], 0, 0, 0);
+      acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[1], breg[6 * 4 + ks], acc[mt][3], 0, 0, 0);
+      acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], breg[4 * 4 + ks], acc[mt][2], 0, 0, 0);
+      acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[2], breg[7 * 4 + ks], acc[mt][3], 0, 0, 0);
+      acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[3], breg[8 * 4 + ks], acc[mt][3], 0, 0, 0);
+    }
+    base = base + 1 == G::NR ? 0 : base + 1;
+    __builtin_amdgcn_s_barrier();       // B: every thread has read the previous tile (right after barrier A)
+    asm volatile("" ::: "memory");
+    // ---- accumulators -> tile[pr][2 * bl + pc][channel]: lane pairs exchange so that each writes a (c, c+1) dword
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int pr = ph >> 1, pc = ph & 1;
+#pragma unroll
+        for (int ep = 0; ep < 2; ++ep) {
+          const float v0 = acc[mt][ph][2 * ep], v1 = acc[mt][ph][2 * ep + 1];
+          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? v0 : v1), 0xB1, 0xF, 0xF, false));
+          const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
+          const uint32_t word = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+          const int bl = mt * 16 + 4 * (lane >> 4) + 2 * ep + odd;       // dy column inside the strip
+          const int ch = wid * 16 + (lane & 15) - odd;
+          lds_store32u(tile0 + (pr * 128 + 2 * bl + pc) * G::PITCH + ch * 2, word);
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // ---- last tile
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    const long long orow = img_out + (long long)(2 * (a0 + a.TH - 1)) * (2 * a.OW) * 64 + (long long)(2 * b0) * 64;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = tid + 256 * k;
+      const int pxl = idx >> 3, part = idx & 7;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + pxl * G::PITCH + part * 16);
+      *reinterpret_cast<u32x4*>(a.DX + orow + (long long)(pxl >> 7) * (2 * a.OW) * 64 + (pxl & 127) * 64 + part * 8) = val;
+    }
+  }
+}
+
+}  // namespace jpdse

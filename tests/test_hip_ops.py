@@ -273,7 +273,8 @@ def test_l1_bwd_relu_mask(dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(2, 128, 64, 5, 7), (1, 1024, 512, 2, 4), (1, 24, 12, 3, 5)])
+# (2, 128, 64, 12, 64) and (1, 128, 64, 32, 128): the all-phases row-streaming kernel (dgrad2_rows.h), bands of 4 / 16 dy rows, 1 / 2 strips
+@pytest.mark.parametrize('shape', [(2, 128, 64, 5, 7), (1, 1024, 512, 2, 4), (1, 24, 12, 3, 5), (2, 128, 64, 12, 64), (1, 128, 64, 32, 128)])
 def test_conv_transpose(shape, dtype):
   N, Cin, Cout, H, W = shape
   g = G(Cin + H)
