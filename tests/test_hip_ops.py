@@ -371,9 +371,9 @@ def test_instance_norm_exchange(name, shape, with_res, dtype):
   assert_close(stats3.cpu()[:, :C], stats.cpu()[:, :C], st_tol, 'stats vs three-kernel form')
   assert_close(to_nchw(y3), to_nchw(y), tol, 'fwd vs three-kernel form')
   assert_close(to_nchw(dx3), to_nchw(dx), 3 * tol, 'bwd vs three-kernel form')
-  with jpdse_hip.dev_mode(28):              # one kernel, rows exchanged inside the launch: the same sums in the same order
-    y4, stats4, dx4 = run()                 # (the epilogue arithmetic is compiled per kernel: equal to an ulp, not bitwise)
-    assert_close(stats4.cpu()[:, :C], stats.cpu()[:, :C], 1e-6, 'stats vs one-kernel form')
+  with jpdse_hip.dev_mode(28):              # one kernel, rows exchanged inside the launch (8 or 16 pixels per thread: its own
+    y4, stats4, dx4 = run()                 # split count, so another summation order than the shipped form)
+    assert_close(stats4.cpu()[:, :C], stats.cpu()[:, :C], st_tol, 'stats vs one-kernel form')
     assert_close(to_nchw(y4), to_nchw(y), tol, 'fwd vs one-kernel form')
     assert_close(to_nchw(dx4), to_nchw(dx), 3 * tol, 'bwd vs one-kernel form')
     for rep in range(3):
