@@ -27,3 +27,14 @@ if len(sys.argv) > 3:
   print('--- by kernel and grid')
   for k, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[3])]:
     print('%-52s grid %8s x%3s  x%3d  %8.1f us  avg %7.1f' % (k[0], k[1], k[2], c, d / 1e3, d / 1e3 / c))
+# gaps between consecutive kernels of the step (launch latency the GPU could not hide)
+gaps = []
+for p, q in zip(step[:-1], step[1:]):
+  g = int(q['Start_Timestamp']) - int(p['End_Timestamp'])
+  gaps.append((g, p['Kernel_Name'].replace('void jpdse::', '').split('(')[0][:40], q['Kernel_Name'].replace('void jpdse::', '').split('(')[0][:40]))
+pos = [g for g in gaps if g[0] > 0]
+print('--- gaps: %d of %d boundaries idle, %.2f ms in all; > 5 us: %d (%.2f ms); > 20 us: %d (%.2f ms)' % (
+    len(pos), len(gaps), sum(g[0] for g in pos) / 1e6, sum(1 for g in pos if g[0] > 5000), sum(g[0] for g in pos if g[0] > 5000) / 1e6,
+    sum(1 for g in pos if g[0] > 20000), sum(g[0] for g in pos if g[0] > 20000) / 1e6))
+for g in sorted(pos, key=lambda t: -t[0])[:12]:
+  print('   %7.1f us  after %-40s before %s' % (g[0] / 1e3, g[1], g[2]))
