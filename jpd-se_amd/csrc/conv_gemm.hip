@@ -86,6 +86,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "thin_fwd.h"
 #include "conv_rows.h"
 #include "dgrad2_rows.h"
+#include "head_rows.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1375,6 +1376,35 @@ static int launch_dgrad2_rows(Dgrad2Args a, hipStream_t s) {
   return check_launch("dgrad2_rows_kernel");
 }
 
+
+// 64 -> <= 3 channel heads (7x7 reflect + Tanh; 3x3 zero-pad data gradient of VGG conv1_1) as a row-streaming pass (head_rows.h)
+static bool head_rows_ok(const HeadFwdArgs& a, int cin) {
+  return g_rows_enabled && cin == 64 && a.K <= 3 && a.Ks_out == 8 && a.OW % 128 == 0 && a.OH % 8 == 0 && a.OH == a.H && a.OW == a.W;
+}
+template <int R>
+static int launch_head_rows(const HeadFwdArgs& a, hipStream_t s) {
+  typedef HeadRowsGeom<R> G;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_rows_kernel<R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "head_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
+    configured = true;
+  }
+  const int strips = a.OW / 128;
+  int th = 0;
+  for (int cand = 64; cand >= 8; cand >>= 1) {
+    if (a.OH % cand != 0) continue;
+    if ((long long)a.N * strips * (a.OH / cand) >= 256) { th = cand; break; }
+  }
+  if (th == 0)
+    for (int cand = 16; cand >= 8; cand >>= 1)
+      if (a.OH % cand == 0) { th = cand; break; }
+  const int bands = a.OH / th;
+  hipLaunchKernelGGL((head_rows_kernel<R>), dim3((unsigned)(a.N * bands * strips)), dim3(256), G::LDS, s, a, th, bands, strips);
+  return check_launch("head_rows_kernel");
+}
+
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
 // gradient of the zero-padded ones): LDS-resident input halo, see gemm_halo.h
 static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_out) {
@@ -1539,6 +1569,7 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       h.slope = d->slope;
       h.tiles_w = (p.OW + 63) / 64;
       h.tiles_h = (p.OH + kHeadTH - 1) / kHeadTH;
+      if (head_rows_ok(h, p.Cs)) return launch_head_rows<7>(h, s);
       return p.Cs == 64 ? launch_head_fwd<64>(h, s) : launch_head_fwd<32>(h, s);
     }
     if (tapsum_ok(d, p)) {
@@ -2019,6 +2050,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.act = JPDSE_ACT_NONE;
       h.tiles_w = (d->W + 63) / 64;
       h.tiles_h = (d->H + kHeadTH - 1) / kHeadTH;
+      if (head_rows_ok(h, 64)) return launch_head_rows<3>(h, s);
       return launch_head_fwd<64, 3, 3, 3>(h, s);
     }
   }

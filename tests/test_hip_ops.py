@@ -109,6 +109,11 @@ CONV_CASES = [
     ('rows_s2_tall',   1, 64, 128, 64,  128, 3, 2, 1,  PAD_ZERO,    ACT_RELU),
     ('rows_s1_64',     2, 12, 128, 64,  64,  3, 1, 1,  PAD_ZERO,    ACT_RELU),
     ('rows_s1_128',    1, 32, 192, 64,  128, 3, 1, 1,  PAD_ZERO,    ACT_NONE),
+    # heads as a row-streaming pass (head_rows.h): 7x7 reflect + Tanh forward (bands of 16 rows, 2 strips of 128 pixels,
+    # reflected borders on all sides) and the 3x3 zero-pad data gradient of a 3-channel-input conv (VGG conv1_1)
+    ('head_rows_7',    2, 48, 256, 64,  3,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
+    ('head_rows_7b',   1, 16, 128, 64,  2,   7, 1, 3,  PAD_REFLECT, ACT_NONE),
+    ('vgg11_rows',     1, 24, 128, 3,   64,  3, 1, 1,  PAD_ZERO,    ACT_RELU),
 ]
 
 
