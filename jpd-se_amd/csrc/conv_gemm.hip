@@ -87,6 +87,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "conv_rows.h"
 #include "dgrad2_rows.h"
 #include "head_rows.h"
+#include "thin_dgrad2_rows.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1244,7 +1245,7 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
 
 JPDSE_SWITCH(int, g_ring_enabled, 1);
 JPDSE_SWITCH(int, g_merge_min_kt, 4);
-JPDSE_SWITCH(int, g_merge_min_tiles, 384);   // merged stride-phase data gradient on the fast kernel from this many 256-row tiles on (26: 64, A/B)
+JPDSE_SWITCH(int, g_merge_min_tiles, 64);    // merged stride-phase data gradient on the fast kernel from this many 256-row tiles on (26: 384 as in round 1, A/B)
 JPDSE_SWITCH(int, g_halo_single, 1);
 JPDSE_SWITCH(int, g_halo_enabled, 1);
 JPDSE_SWITCH(int, g_halo_abl, 0);
@@ -1403,6 +1404,32 @@ static int launch_head_rows(const HeadFwdArgs& a, hipStream_t s) {
   const int bands = a.OH / th;
   hipLaunchKernelGGL((head_rows_kernel<R>), dim3((unsigned)(a.N * bands * strips)), dim3(256), G::LDS, s, a, th, bands, strips);
   return check_launch("head_rows_kernel");
+}
+
+
+// data gradient of PatchGAN layer 0 with respect to the image channels (thin_dgrad2_rows.h)
+static int launch_thin_dgrad2_rows(ThinDgrad2Args a, hipStream_t s) {
+  typedef ThinDgrad2Geom G;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_dgrad2_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_dgrad2_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
+    configured = true;
+  }
+  a.strips = a.W / 256;
+  int th = 0;
+  for (int cand = 64; cand >= 8; cand >>= 1) {
+    if (a.H % cand != 0) continue;
+    if ((long long)a.N * a.strips * (a.H / cand) >= 256) { th = cand; break; }
+  }
+  if (th == 0)
+    for (int cand = 16; cand >= 8; cand >>= 1)
+      if (a.H % cand == 0) { th = cand; break; }
+  a.TH = th;
+  a.bands = a.H / th;
+  hipLaunchKernelGGL(thin_dgrad2_rows_kernel, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
+  return check_launch("thin_dgrad2_rows_kernel");
 }
 
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
@@ -2066,6 +2093,23 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       g.OH = p.OH;
       g.OW = p.OW;
       return launch_dgrad2_rows(g, s);
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (g_fast_enabled && g_rows_enabled && !refl && st == 2 && d->R == 4 && d->S == 4 && d->pad == 2 && p.Cs == 8 && d->C <= 3 &&
+        p.Ks == 64 && d->H % 8 == 0 && d->W % 256 == 0 && p.OH == d->H / 2 + 1 && p.OW == d->W / 2 + 1 && p.nph == 4 &&
+        p.ph[0].Lk == 128 && mask == nullptr && addend == nullptr) {
+      ThinDgrad2Args g = {};
+      g.DY = reinterpret_cast<const bf16_t*>(dy);
+      for (int i = 0; i < 4; ++i) g.P[i] = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + p.ph[i].pack_off);
+      g.DX = reinterpret_cast<bf16_t*>(dx);
+      g.N = d->N;
+      g.OH = p.OH;
+      g.OW = p.OW;
+      g.H = d->H;
+      g.W = d->W;
+      g.K = d->C;
+      return launch_thin_dgrad2_rows(g, s);
     }
   }
   bool fast = false;
@@ -2758,7 +2802,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
   g_merge_min_kt = enable == 9 ? 16 : 4;
   g_norm_fused = enable == 27 ? 0 : (enable == 28 ? 2 : 1);   // 27: InstanceNorm always as three kernels; 28: one-kernel form with the in-launch exchange (A/B)
-  g_merge_min_tiles = enable == 26 ? 64 : 384;    // 9: merged stride-phase data gradient only for long K loops (A/B)
+  g_merge_min_tiles = enable == 26 ? 384 : 64;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
   g_halo_mf16 = enable == 19;

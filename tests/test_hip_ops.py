@@ -302,6 +302,32 @@ def test_conv_transpose(shape, dtype):
   assert_close(layer.weight.grad.cpu(), wr.grad, 2 * tol, 'convT wgrad')
 
 
+# PatchGAN layer 0, data gradient with respect to the 3 image channels only (HipConv2d.bwd_input_slice): the row-streaming
+# kernel of thin_dgrad2_rows.h (dx width a multiple of 256) and the stride-phase path (any other width)
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 16, 256), (1, 24, 512), (1, 10, 36)])
+def test_conv_dgrad_input_slice(shape, dtype):
+  N, H, W = shape
+  g = G(N * H + W)
+  x = quantize_like(torch.randn(N, 39, H, W, generator=g), dtype)
+  w = torch.randn(64, 39, 4, 4, generator=g) * (1.0 / (39 * 16) ** 0.5)
+  layer = HipConv2d(39, 64, 4, 2, 2, PAD_ZERO, act=ACT_LRELU, apply_bias=True, dtype=dtype, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(w)
+  xr = x.clone().requires_grad_(True)
+  wq = quantize_like(w, dtype)
+  z_ref = F.conv2d(F.pad(xr, (2,) * 4), wq, layer.bias.detach().cpu(), stride=2)
+  y, ctx = layer.fwd(to_act(x, dtype))
+  y_dev = to_nchw(y)
+  gy = quantize_like(torch.randn(z_ref.shape, generator=g), dtype)
+  z_ref.backward(gy * _act_grad_from_output(y_dev, ACT_LRELU))      # through the device's activation mask (see above)
+  dx = layer.bwd_input_slice(ctx, to_act(gy, dtype), 36, 39)
+  torch.cuda.synchronize()
+  assert dx.C == 3 and dx.t.shape[1:3] == (H, W)
+  assert_close(to_nchw(dx), xr.grad[:, 36:39], 2 * RTOL[dtype], 'layer-0 data gradient, image channels')
+  assert (dx.t[..., 3:] == 0).all()
+
+
 # ---- instance norm -----------------------------------------------------------------------------
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('act', [ACT_NONE, ACT_RELU, ACT_LRELU])
