@@ -1119,6 +1119,7 @@ static int launch_wgrad(const GemmWgradArgs& a, float* slabs, hipStream_t s) {
   return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, slabs, s);
 }
 
+JPDSE_SWITCH(int, g_fast_xcd, 0);         // 30: N-tiles of an M-tile on one XCD (measured neutral: +5 % on the PatchGAN layer-3 data gradient, -4 % on the 1024 -> 512 ConvTranspose; memory-side fetch is not what bounds these layers)
 template <int WM, int WN, int TM, int TN, int VAR, int STAGES = 3>
 static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -1150,6 +1151,7 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
         return set_error(JPDSE_EINVAL, "gemm_fast: problem %d addresses element %lld of a %lld-element input", i, last, a.x_extent);
     }
     b.first_tile[i] = total;
+    b.p[i].xcd_map = (g_fast_xcd && a.splits <= 1 && (a.Ks + BN - 1) / BN >= 2 && (a.M + BM - 1) / BM >= 16) ? 1 : 0;
     total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN) * (a.splits > 1 ? a.splits : 1);
     const long long kdim = (long long)a.R * a.S * a.Cs;
     flops += 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
@@ -2794,6 +2796,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   // 0: generic kernels only; 1: fast kernels (default schedule 0); 2: fast kernels, alternative schedule 1
   g_fast_enabled = enable != 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
+  g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
   g_rows_enabled = enable != 29 && enable != 3;   // 29: 64-channel 3x3 layers on the halo / fast kernels instead of conv_rows (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_nine_sched = enable == 21 ? 0 : (enable == 22 ? 1 : (enable == 24 ? 2 : 3));   // 21 / 22 / 24: unpipelined loop forms of the nine-tap weight gradient (A/B); default 3 = software-pipelined fragment reads   // 21 / 22: DMA issue placement of the nine-tap weight gradient (A/B)

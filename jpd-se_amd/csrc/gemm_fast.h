@@ -49,6 +49,7 @@ struct FastArgs {
   int b_tap_r, b_tap_s;
   int no_finish;       // split-K: leave the slabs to the caller (no splitk_finish_kernel)
   long long x_extent;  // elements readable from X (0 = not given): the launcher refuses a problem whose last pixel lies beyond
+  int xcd_map;         // N-tiles of an M-tile on consecutive slots of one XCD (set by the launcher)
 };
 
 // Up to 4 independent problems in one launch (the stride-2 sub-pixel phases of a data gradient /
@@ -192,7 +193,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   const int ntiles = tiles_m * ((a.Ks + BN - 1) / BN);
   const int split = a.splits > 1 ? block_id / ntiles : 0;
   const int tile_id = a.splits > 1 ? block_id - split * ntiles : block_id;
-  const int tile_m = tile_id % tiles_m, tile_n = tile_id / tiles_m;
+  int tile_m = tile_id % tiles_m, tile_n = tile_id / tiles_m;
+  if (a.xcd_map) {
+    // The N-tiles of one M-tile read the same activation rows.  In the plain order they run tiles_m blocks apart, and the
+    // activation tensors of these layers (34-134 MB) do not live that long in a 4 MB L2: every N-tile re-fetches its rows
+    // from beyond L2 (PatchGAN layer 3: 1.49 GB per launch for a 34 MB input).  Blocks b, b + 8, ... share an XCD (speed only:
+    // MI355X_MICROARCH.md "XCD placement"), so deal each XCD whole M-tiles: consecutive slots of one XCD = the N-tiles of one
+    // M-tile.  The last tiles_m % 8 M-tiles keep the plain order.
+    const int tiles_n = ntiles / tiles_m;
+    const int m8 = tiles_m & ~7, head = m8 * tiles_n;
+    if (tile_id < head) {
+      const int x = tile_id & 7, j = tile_id >> 3;
+      tile_n = j % tiles_n;
+      tile_m = (j / tiles_n) * 8 + x;
+    } else {
+      const int rem = tiles_m - m8, t = tile_id - head;
+      tile_m = m8 + t % rem;
+      tile_n = t / rem;
+    }
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int lrow = lane >> 3, lslot = lane & 7;
 

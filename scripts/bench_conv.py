@@ -38,6 +38,7 @@ LAYERS = [
   ('D layer4 512->1 4x4 s1 @66x130 N8', 66, 130, 512, 1, 4, 1, 2, PAD_ZERO, False),
   ('D layer0 39->64 4x4 s2',       512, 1024, 39, 64, 4, 2, 2, PAD_ZERO, False),
   ('D layer1 64->128 4x4 s2',      257, 513, 64, 128, 4, 2, 2, PAD_ZERO, False),
+  ('D layer2 128->256 4x4 s2',     129, 257, 128, 256, 4, 2, 2, PAD_ZERO, False),
   ('D layer3 256->512 4x4 s1',     65, 129, 256, 512, 4, 1, 2, PAD_ZERO, False),
 ]
 
