@@ -109,6 +109,9 @@ class Pix2PixHDModel(BaseModel):
     a('--vgg19_state_dict', type=str, default=None,
       help='extension: local torchvision-format vgg19 state_dict (keys features.<i>.weight/bias) for the VGG loss; the '
            'reference downloads models.vgg19(pretrained=True) (networks.py:477), which needs network access')
+    a('--checkpoint_resblocks', action='store_true',
+      help='activation checkpointing of the ResnetBlocks (keep the block input, recompute in backward): the memory saver of '
+           'BASELINE config 5; not needed on a 288 GB part, bit-identical results either way')
     a('--vgg_random_init', action='store_true',
       help='extension: explicitly accept a seeded random-weight VGG19 for the VGG loss (tests, benchmarks); without '
            'this flag training with the VGG loss and no --vgg19_state_dict is refused')
@@ -148,6 +151,11 @@ class Pix2PixHDModel(BaseModel):
     self.netG = networks.define_G(netG_input_nc, opt.num_out_channels, opt.ngf, opt.netG,
                                   opt.n_downsample_global, opt.n_blocks_global, opt.n_local_enhancers,
                                   opt.n_blocks_local, opt.norm, gpu_ids=self.gpu_ids, compute_dtype=cd)
+    if g('checkpoint_resblocks', False):
+      from jpdse_hip.layers import HipResnetBlock
+      for m in self.netG.modules():
+        if isinstance(m, HipResnetBlock):
+          m.recompute = True
     if self.is_train:
       self.netD = networks.define_D(netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm, False, opt.num_D, True,
                                     gpu_ids=self.gpu_ids, compute_dtype=cd)

@@ -319,14 +319,25 @@ class HipResnetBlock(nn.Module):
     self.norm1 = InstNormAct(ACT_RELU)
     self.norm2 = InstNormAct(ACT_NONE)
 
-  def fwd(self, x):
+  # Activation checkpointing (BASELINE config 5): keep only the block's input and run the forward again
+  # inside backward.  Off by default -- 288 GB of HBM hold every activation of the 2048x1024 step -- and, the
+  # kernels being deterministic, bit-identical to the stored-activation path when on (tests/test_hip_configs.py).
+  recompute = False
+
+  def _fwd(self, x):
     h, c1 = self.conv_block[1].fwd(x)
     h, n1 = self.norm1.fwd(h)
     h, c2 = self.conv_block[5].fwd(h)
     y, n2 = self.norm2.fwd(h, residual=x)
     return y, Ctx(c1, n1, c2, n2)
 
+  def fwd(self, x):
+    y, ctx = self._fwd(x)
+    return (y, Ctx(x)) if self.recompute else (y, ctx)
+
   def bwd(self, ctx, dy, need_dx=True, need_dw=True):
+    if len(ctx.items) == 1:                     # checkpointed: rebuild the saved tensors from the block input
+      _, ctx = self._fwd(ctx.items[0])
     c1, n1, c2, n2 = ctx.items
     d = self.norm2.bwd(n2, dy)
     d = self.conv_block[5].bwd(c2, d, True, need_dw)

@@ -46,7 +46,7 @@ def default_opt(**over):
       no_d_gan_loss=False, no_g_gan_loss=False, no_vgg_loss=False, no_gan_feat_loss=False,
       no_distortion_loss=False, fp16=False, tf_log=False, schedule_lr=False,
       lr_decay_factor=0.1, lr_decay_patience=5, verbose=False, batch_size=1,
-      skip_unused_losses=False, vgg19_state_dict=None, vgg_random_init=True)
+      skip_unused_losses=False, vgg19_state_dict=None, vgg_random_init=True, checkpoint_resblocks=False)
   o.update(over)
   return types.SimpleNamespace(**o)
 
