@@ -88,6 +88,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "dgrad2_rows.h"
 #include "head_rows.h"
 #include "thin_dgrad2_rows.h"
+#include "thin_rows.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1434,6 +1435,31 @@ static int launch_thin_dgrad2_rows(ThinDgrad2Args a, hipStream_t s) {
   return check_launch("thin_dgrad2_rows_kernel");
 }
 
+
+// PatchGAN layer 0 forward (40-channel input, 4x4 stride 2, 64 outputs) as a row-streaming pass (thin_rows.h)
+static int launch_thin_rows(ThinFwdArgs a, hipStream_t s) {
+  typedef ThinRowsGeom G;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
+    configured = true;
+  }
+  a.tiles_w = (a.OW + 63) / 64;
+  // band height: fewest (rounds of 512 blocks: two per CU) x (rows per block + the ~4 rows a block pays for its filter load and prologue)
+  int th = 8;
+  long long best = -1;
+  for (int cand = 64; cand >= 8; cand >>= 1) {
+    const long long blocks = (long long)a.N * ((a.OH + cand - 1) / cand) * a.tiles_w;
+    const long long cost = ((blocks + 511) / 512) * (cand + 4);
+    if (best < 0 || cost < best) { best = cost; th = cand; }
+  }
+  const int bands = (a.OH + th - 1) / th;
+  hipLaunchKernelGGL(thin_rows_kernel, dim3((unsigned)(a.N * bands * a.tiles_w)), dim3(256), G::LDS, s, a, th, bands);
+  return check_launch("thin_rows_kernel");
+}
+
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
 // gradient of the zero-padded ones): LDS-resident input halo, see gemm_halo.h
 static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_out) {
@@ -1570,6 +1596,9 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       t.w_units = tg.w_units;
       t.tiles_w = (p.OW + tg.TW - 1) / tg.TW;
       t.tiles_h = (p.OH + tg.TH - 1) / tg.TH;
+      if (g_rows_enabled && d->stride == 2 && d->R == 4 && d->S == 4 && p.Cs == 40 && p.Ks == 64 && d->K == 64 && !t.reflect &&
+          p.KP_thin == 168 && (d->act == JPDSE_ACT_NONE || d->act == JPDSE_ACT_RELU || d->act == JPDSE_ACT_LRELU))
+        return launch_thin_rows(t, s);
       if (d->stride == 1) {
         if (tg.TH == 8) return p.Ks == 64 ? launch_thin_fwd<2, 8, 1, 64>(t, tg.lds, s) : launch_thin_fwd<1, 8, 1, 64>(t, tg.lds, s);
         return tg.TW == 64 ? launch_thin_fwd<1, 4, 1, 64>(t, tg.lds, s) : launch_thin_fwd<1, 4, 1, 32>(t, tg.lds, s);
