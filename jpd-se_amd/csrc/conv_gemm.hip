@@ -1399,7 +1399,7 @@ static int launch_head_rows(const HeadFwdArgs& a, hipStream_t s) {
   int th = 0;
   for (int cand = 64; cand >= 8; cand >>= 1) {
     if (a.OH % cand != 0) continue;
-    if ((long long)a.N * strips * (a.OH / cand) >= 256) { th = cand; break; }
+    if ((long long)a.N * strips * (a.OH / cand) >= 512) { th = cand; break; }
   }
   if (th == 0)
     for (int cand = 16; cand >= 8; cand >>= 1)
@@ -1424,7 +1424,7 @@ static int launch_thin_dgrad2_rows(ThinDgrad2Args a, hipStream_t s) {
   int th = 0;
   for (int cand = 64; cand >= 8; cand >>= 1) {
     if (a.H % cand != 0) continue;
-    if ((long long)a.N * a.strips * (a.H / cand) >= 256) { th = cand; break; }
+    if ((long long)a.N * a.strips * (a.H / cand) >= 512) { th = cand; break; }
   }
   if (th == 0)
     for (int cand = 16; cand >= 8; cand >>= 1)

@@ -26,7 +26,7 @@ template <int R> struct HeadRowsGeom {
   static constexpr int PIX = 128 + R - 1;
   static constexpr int UNITS = (PIX + 7) / 8;                 // 1 KiB DMA units per input row (8 pixels x 128 B)
   static constexpr int ROWB = UNITS * 1024;
-  static constexpr int LA = 4, NR = LA + 2;                   // one row in use, LA in flight
+  static constexpr int LA = 1, NR = LA + 2;                   // one row in use, LA in flight: 69 KB of LDS, two blocks per CU
   static constexpr int OROWS = R > 4 ? 8 : 4;                 // output rows under construction (power of two >= R)
   static constexpr int OPITCH = 32 * 16 + 16;                 // one output row of a wave: 32 pixels x 4 floats (+ bank skew)
   static constexpr int OTILE = OROWS * OPITCH;
@@ -38,7 +38,7 @@ __device__ __forceinline__ void lds_add_f32(uint32_t addr, float v) {
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void head_rows_kernel(const HeadFwdArgs a, int TH, int bands, int strips) {
+__global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadFwdArgs a, int TH, int bands, int strips) {
   typedef HeadRowsGeom<R> G;
   constexpr int S = R, T = S * 4;                             // k16-steps per input row
   constexpr int U0 = G::UNITS / 4, U1 = U0 + 1, EXTRA = G::UNITS % 4;

@@ -31,13 +31,13 @@ struct ThinDgrad2Geom {
   static constexpr int PIX = 129;
   static constexpr int UNITS = (PIX + 7) / 8;
   static constexpr int ROWB = UNITS * 1024;
-  static constexpr int LA = 4, NR = LA + 2;
+  static constexpr int LA = 1, NR = LA + 2;            // 69 KB of LDS: two blocks per CU
   static constexpr int OPITCH = 64 * 16 + 16;          // one dx row of a wave: 64 pixels x 4 floats (+ bank skew)
   static constexpr int OTILE = 4 * OPITCH;             // dx rows under construction
   static constexpr int LDS = NR * ROWB + 4 * OTILE;
 };
 
-__global__ __launch_bounds__(256) void thin_dgrad2_rows_kernel(const ThinDgrad2Args a) {
+__global__ __launch_bounds__(256, 2) void thin_dgrad2_rows_kernel(const ThinDgrad2Args a) {
   typedef ThinDgrad2Geom G;
   constexpr int T = 8;                                 // k16-steps per dy row: 2 column taps x 64 channels
   constexpr int U0 = G::UNITS / 4, U1 = U0 + 1, EXTRA = G::UNITS % 4;
