@@ -89,6 +89,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "head_rows.h"
 #include "thin_dgrad2_rows.h"
 #include "thin_rows.h"
+#include "thin_in_rows.h"
 namespace jpdse {
 
 // ---- MFMA over one 64-byte K chunk --------------------------------------------------------
@@ -1460,6 +1461,39 @@ static int launch_thin_rows(ThinFwdArgs a, hipStream_t s) {
   return check_launch("thin_rows_kernel");
 }
 
+
+// data gradient of the 64 -> 3 7x7 reflect-padded head (thin_in_rows.h): padded-domain conv with the interior written straight
+// into dx, then the ring fold
+static int launch_thin_in_rows(ThinInArgs a, hipStream_t s) {
+  typedef ThinInGeom G;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_in_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_in_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
+    configured = true;
+  }
+  const int HP = a.H + 2 * G::PAD, WP = a.W + 2 * G::PAD;
+  a.strips = (WP + 63) / 64;
+  int th = 8;
+  long long best = -1;
+  for (int cand = 64; cand >= 8; cand >>= 1) {
+    const long long blocks = (long long)a.N * ((HP + cand - 1) / cand) * a.strips;
+    const long long cost = ((blocks + 511) / 512) * (cand + 4);
+    if (best < 0 || cost < best) { best = cost; th = cand; }
+  }
+  a.TH = th;
+  a.bands = (HP + th - 1) / th;
+  hipLaunchKernelGGL(thin_in_rows_kernel, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
+  if (int rc = check_launch("thin_in_rows_kernel")) return rc;
+  const int band = G::PAD + 1;
+  const long long per_img = 2LL * band * a.W + (long long)(a.H - 2 * band) * 2 * band;
+  const long long total_vec = (long long)a.N * per_img * (64 / 8);
+  hipLaunchKernelGGL((reflect_ring_fold_kernel<bf16_t>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, a.DXP, a.DX, a.N, a.H, a.W, 64,
+                     G::PAD, total_vec);
+  return check_launch("reflect_ring_fold_kernel");
+}
+
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
 // gradient of the zero-padded ones): LDS-resident input halo, see gemm_halo.h
 static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_out) {
@@ -2141,6 +2175,20 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       g.W = d->W;
       g.K = d->C;
       return launch_thin_dgrad2_rows(g, s);
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (g_fast_enabled && g_rows_enabled && refl && st == 1 && d->R == 7 && d->S == 7 && d->pad == 3 && p.Ks == 8 && p.Cs == 64 &&
+        d->C == 64 && d->H >= 8 && d->W >= 8 && p.nph == 1 && p.ph[0].Lk == 64 && mask == nullptr && addend == nullptr) {
+      ThinInArgs g = {};
+      g.DY = reinterpret_cast<const bf16_t*>(dy);
+      g.P = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + p.ph[0].pack_off);
+      g.DX = reinterpret_cast<bf16_t*>(dx);
+      g.DXP = reinterpret_cast<bf16_t*>(dxp);
+      g.N = d->N;
+      g.H = d->H;
+      g.W = d->W;
+      return launch_thin_in_rows(g, s);
     }
   }
   bool fast = false;

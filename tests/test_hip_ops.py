@@ -114,6 +114,10 @@ CONV_CASES = [
     ('head_rows_7',    2, 48, 256, 64,  3,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
     ('head_rows_7b',   1, 16, 128, 64,  2,   7, 1, 3,  PAD_REFLECT, ACT_NONE),
     ('vgg11_rows',     1, 24, 128, 3,   64,  3, 1, 1,  PAD_ZERO,    ACT_RELU),
+    # head data gradient on the padded domain (thin_in_rows.h): interior written in place, ring folded back; several bands
+    # and strips (padded width 206 = 3 strips + 14 pixels), one image smaller than a strip
+    ('head_dgrad_rows', 2, 40, 200, 64, 3,   7, 1, 3,  PAD_REFLECT, ACT_NONE),
+    ('head_dgrad_small', 1, 9,  12,  64, 2,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
 ]
 
 
