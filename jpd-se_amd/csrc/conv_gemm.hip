@@ -1462,36 +1462,39 @@ static int launch_thin_rows(ThinFwdArgs a, hipStream_t s) {
 }
 
 
-// data gradient of the 64 -> 3 7x7 reflect-padded head (thin_in_rows.h): padded-domain conv with the interior written straight
-// into dx, then the ring fold
+// dense 8-channel inputs, 64 outputs, as a row-streaming pass (thin_in_rows.h): the data gradient of the 64 -> 3 7x7 reflect-padded
+// head (padded-domain conv with the interior written straight into dx, then the ring fold) and VGG conv1_1 forward (3x3, zero pad)
+template <int R, bool DUAL>
 static int launch_thin_in_rows(ThinInArgs a, hipStream_t s) {
-  typedef ThinInGeom G;
+  typedef ThinInGeom<R> G;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_in_rows_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_in_rows_kernel<R, DUAL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_in_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
     configured = true;
   }
-  const int HP = a.H + 2 * G::PAD, WP = a.W + 2 * G::PAD;
-  a.strips = (WP + 63) / 64;
+  a.strips = (a.OW + 63) / 64;
   int th = 8;
   long long best = -1;
   for (int cand = 64; cand >= 8; cand >>= 1) {
-    const long long blocks = (long long)a.N * ((HP + cand - 1) / cand) * a.strips;
+    const long long blocks = (long long)a.N * ((a.OH + cand - 1) / cand) * a.strips;
     const long long cost = ((blocks + 511) / 512) * (cand + 4);
     if (best < 0 || cost < best) { best = cost; th = cand; }
   }
   a.TH = th;
-  a.bands = (HP + th - 1) / th;
-  hipLaunchKernelGGL(thin_in_rows_kernel, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
+  a.bands = (a.OH + th - 1) / th;
+  hipLaunchKernelGGL((thin_in_rows_kernel<R, DUAL>), dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
   if (int rc = check_launch("thin_in_rows_kernel")) return rc;
-  const int band = G::PAD + 1;
-  const long long per_img = 2LL * band * a.W + (long long)(a.H - 2 * band) * 2 * band;
-  const long long total_vec = (long long)a.N * per_img * (64 / 8);
-  hipLaunchKernelGGL((reflect_ring_fold_kernel<bf16_t>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, a.DXP, a.DX, a.N, a.H, a.W, 64,
-                     G::PAD, total_vec);
-  return check_launch("reflect_ring_fold_kernel");
+  if (DUAL) {
+    const int band = G::PAD + 1;
+    const long long per_img = 2LL * band * a.W + (long long)(a.H - 2 * band) * 2 * band;
+    const long long total_vec = (long long)a.N * per_img * (64 / 8);
+    hipLaunchKernelGGL((reflect_ring_fold_kernel<bf16_t>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, a.DXP, a.DX, a.N, a.H, a.W,
+                       64, G::PAD, total_vec);
+    return check_launch("reflect_ring_fold_kernel");
+  }
+  return JPDSE_OK;
 }
 
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
@@ -1603,6 +1606,24 @@ template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
                       const float* bias, void* y, void* ws, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    if (g_fast_enabled && g_rows_enabled && p.Cs == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
+        d->pad_mode == JPDSE_PAD_ZERO && p.Ks == 64 && d->K == 64 && p.Lk_fwd == 32 &&
+        (d->act == JPDSE_ACT_NONE || d->act == JPDSE_ACT_RELU || d->act == JPDSE_ACT_LRELU)) {
+      ThinInArgs g = {};                       // VGG conv1_1: plain forward panel [k][r][(s, c8) 24 -> 32]
+      g.DY = reinterpret_cast<const bf16_t*>(x);
+      g.P = reinterpret_cast<const bf16_t*>(pack);
+      g.DX = reinterpret_cast<bf16_t*>(y);
+      g.bias = bias;
+      g.act = d->act;
+      g.slope = d->slope;
+      g.N = d->N;
+      g.H = d->H;
+      g.W = d->W;
+      g.OH = p.OH;
+      g.OW = p.OW;
+      g.py = g.px = 1;
+      return launch_thin_in_rows<3, false>(g, s);
+    }
     ThinFwdGeom tg;
     if (thin_fwd_geom(d, p, &tg)) {
       ThinFwdArgs t = {};
@@ -2188,7 +2209,11 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       g.N = d->N;
       g.H = d->H;
       g.W = d->W;
-      return launch_thin_in_rows(g, s);
+      g.OH = d->H + 6;
+      g.OW = d->W + 6;
+      g.py = g.px = 6;
+      g.act = JPDSE_ACT_NONE;
+      return launch_thin_in_rows<7, true>(g, s);
     }
   }
   bool fast = false;

@@ -21,31 +21,40 @@
 namespace jpdse {
 
 struct ThinInArgs {
-  const bf16_t* DY;      // [N][H][W][8]
-  const bf16_t* P;       // panel [64][7][64]
-  bf16_t* DX;            // [N][H][W][64]          interior of the padded domain
-  bf16_t* DXP;           // [N][H+6][W+6][64]      ring pixels only
-  int N, H, W;           // image size; the padded domain is (H + 6) x (W + 6)
+  const bf16_t* DY;      // [N][H][W][8]           (input of the conv that is computed: dy for the head, the image for VGG conv1_1)
+  const bf16_t* P;       // panel [64][R][32 KS]
+  bf16_t* DX;            // DUAL: [N][H][W][64], interior of the padded domain; otherwise the output [N][OH][OW][64]
+  bf16_t* DXP;           // DUAL: [N][H+6][W+6][64], ring pixels only
+  const float* bias;     // forward use: bias + ReLU / LeakyReLU epilogue
+  int act;
+  float slope;
+  int N, H, W;           // input size
+  int OH, OW;            // output domain (DUAL: H + 6, W + 6)
+  int py, px;            // input row = oh - py + r
   int TH, bands, strips;
 };
 
-struct ThinInGeom {
-  static constexpr int R = 7, PAD = 3;
-  static constexpr int PIX = 64 + 7;                    // staged dy pixels per row (the 8th pixel of the last run)
-  static constexpr int ROWB = 2048;                     // 71 x 16 B in two 1 KiB DMA units
-  static constexpr int LA = 2, NR = R + LA + 1;         // 7 rows in use, LA in flight
+// R x R filter over a dense 8-channel input, 64 outputs.  DUAL: the head data gradient (interior / ring destinations).
+template <int RR> struct ThinInGeom {
+  static constexpr int R = RR, PAD = 3;
+  static constexpr int KS = (RR * 8 + 31) / 32;         // k32-steps per filter row: a run of 4 KS pixels (the last ones meet zero weights)
+  static constexpr int PIX = 64 + 4 * KS - 1;           // staged pixels per row
+  static constexpr int ROWB = 2048;                     // <= 71 x 16 B in two 1 KiB DMA units
+  static constexpr int LA = 2, NR = R + LA + 1;         // R rows in use, LA in flight
   static constexpr int PITCH = 128 + 16;
   static constexpr int TILE = 64 * PITCH;
   static constexpr int LDS = NR * ROWB + TILE;
 };
 
+template <int RR, bool DUAL>
 __global__ __launch_bounds__(256, 2) void thin_in_rows_kernel(const ThinInArgs a) {
-  typedef ThinInGeom G;
+  typedef ThinInGeom<RR> G;
+  constexpr int KS = G::KS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wid & 1, wp = wid >> 1;
-  const int HP = a.H + 2 * G::PAD, WP = a.W + 2 * G::PAD;
+  const int HP = a.OH, WP = a.OW;
   int b = blockIdx.x;
   const int strip = b % a.strips; b /= a.strips;
   const int band = b % a.bands;
@@ -61,14 +70,14 @@ __global__ __launch_bounds__(256, 2) void thin_in_rows_kernel(const ThinInArgs a
   int col_off = -1;
   if (wid < 2) {
     const int p = wid * 64 + lane;
-    const int iw = ow0 - 2 * G::PAD + p;
+    const int iw = ow0 - a.px + p;
     if (p < G::PIX && (unsigned)iw < (unsigned)a.W) col_off = iw * 8;
   }
   const bf16_t* const img = a.DY + (long long)n * a.H * a.W * 8;
   const int row_elems = a.W * 8;
   auto issue_row = [&](int jr, int slot) {             // dy row oh0 - 6 + jr
     if (wid < 2) {
-      const int ih = oh0 - 2 * G::PAD + jr;
+      const int ih = oh0 - a.py + jr;
       const bool row_ok = (unsigned)ih < (unsigned)a.H;
       const bf16_t* src = (row_ok && col_off >= 0) ? img + ih * (long long)row_elems + col_off : zero;
       glds16(src, smem + slot * G::ROWB + wid * 1024);
@@ -79,21 +88,28 @@ __global__ __launch_bounds__(256, 2) void thin_in_rows_kernel(const ThinInArgs a
   for (int jr = 0; jr < PRO; ++jr) issue_row(jr, jr);
 
   // ---- filter: breg[(r * 2 + ks) * 2 + j] = P[c = 32 wc + 16 j + (lane & 15)][r][32 ks + 8 (lane >> 4) ..]
-  s16x8 breg[28];
+  s16x8 breg[G::R * KS * 2];
   {
     const int kq = (lane >> 4) * 8;
 #pragma unroll
-    for (int r = 0; r < 7; ++r)
+    for (int r = 0; r < G::R; ++r)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int c = wc * 32 + j * 16 + (lane & 15);
-          breg[(r * 2 + ks) * 2 + j] = *reinterpret_cast<const s16x8*>(a.P + ((long long)c * 7 + r) * 64 + ks * 32 + kq);
+          breg[(r * KS + ks) * 2 + j] = *reinterpret_cast<const s16x8*>(a.P + ((long long)c * G::R + r) * (32 * KS) + ks * 32 + kq);
         }
   }
 #pragma unroll
-  for (int t = 0; t < 28; ++t) asm volatile("" : "+v"(breg[t]));
+  for (int t = 0; t < G::R * KS * 2; ++t) asm volatile("" : "+v"(breg[t]));
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    bv[j] = a.bias != nullptr ? a.bias[wc * 32 + j * 16 + (lane & 15)] : 0.f;
+    asm volatile("" : "+v"(bv[j]));
+  }
+  const float nslope = a.act == JPDSE_ACT_RELU ? 0.f : (a.act == JPDSE_ACT_LRELU ? a.slope : 1.f);
   int a_off[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) a_off[i] = (wp * 32 + i * 16 + (lane & 15)) * 16 + (lane >> 4) * 16;
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void thin_in_rows_kernel(const ThinInArgs a
 
   int base = 0, nslot = PRO % G::NR, njr = PRO;
   auto store_tile = [&](int oh) {                       // padded row oh: interior pixels -> dx, ring pixels -> the scratch tensor
-    const bool row_in = oh >= G::PAD && oh < a.H + G::PAD;
+    const bool row_in = !DUAL || (oh >= G::PAD && oh < a.H + G::PAD);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int idx = tid + 256 * k;
@@ -109,9 +125,14 @@ __global__ __launch_bounds__(256, 2) void thin_in_rows_kernel(const ThinInArgs a
       const int ow = ow0 + px;
       if (ow < WP) {
         const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + px * G::PITCH + part * 16);
-        const bool inner = row_in && ow >= G::PAD && ow < a.W + G::PAD;
-        bf16_t* dst = inner ? a.DX + (((long long)n * a.H + (oh - G::PAD)) * a.W + (ow - G::PAD)) * 64
-                            : a.DXP + (((long long)n * HP + oh) * WP + ow) * 64;
+        bf16_t* dst;
+        if constexpr (DUAL) {
+          const bool inner = row_in && ow >= G::PAD && ow < a.W + G::PAD;
+          dst = inner ? a.DX + (((long long)n * a.H + (oh - G::PAD)) * a.W + (ow - G::PAD)) * 64
+                      : a.DXP + (((long long)n * HP + oh) * WP + ow) * 64;
+        } else {
+          dst = a.DX + (((long long)n * HP + oh) * WP + ow) * 64;
+        }
         *reinterpret_cast<u32x4*>(dst + part * 8) = val;
       }
     }
@@ -132,10 +153,10 @@ __global__ __launch_bounds__(256, 2) void thin_in_rows_kernel(const ThinInArgs a
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int T = 14, DEPTH = 3;
+    constexpr int T = G::R * KS, DEPTH = T > 3 ? 3 : T - 1;
     s16x8 fr[DEPTH + 1][2];
     auto rd = [&](int t, s16x8 (&f)[2]) {
-      const int r = t >> 1, ks = t & 1;
+      const int r = t / KS, ks = t - KS * r;
       int slot = base + r;
       slot = slot >= G::NR ? slot - G::NR : slot;
       const uint32_t rb = smem0 + slot * G::ROWB + ks * 64;
@@ -160,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void thin_in_rows_kernel(const ThinInArgs a
           acc[i2][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[i2], breg[t * 2 + j], acc[i2][j], 0, 0, 0);
     }
     base = base + 1 == G::NR ? 0 : base + 1;
-    __builtin_amdgcn_s_barrier();       // B: the previous tile has been read
+    __builtin_amdgcn_s_barrier();       // B: the previous tile has been read (THINB)
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
@@ -168,7 +189,9 @@ __global__ __launch_bounds__(256, 2) void thin_in_rows_kernel(const ThinInArgs a
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int ep = 0; ep < 2; ++ep) {
-          const float v0 = acc[i2][j][2 * ep], v1 = acc[i2][j][2 * ep + 1];
+          float v0 = acc[i2][j][2 * ep] + bv[j], v1 = acc[i2][j][2 * ep + 1] + bv[j];
+          v0 = v0 > 0.f ? v0 : v0 * nslope;
+          v1 = v1 > 0.f ? v1 : v1 * nslope;
           const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? v0 : v1), 0xB1, 0xF, 0xF, false));
           const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
           const uint32_t word = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
