@@ -1196,6 +1196,10 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   }
   for (int i = 0; i < b.n; ++i)
     if (b.n > 1 && !b.p[i].no_finish) b.p[i].splits = 1;
+  if (b.small_m) {
+    if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);
+    if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);
+  }
   int kt = 0;
   for (int i = 0; i < b.n; ++i) {
     const int k = b.p[i].R * b.p[i].S * (b.p[i].Cs / 64);
@@ -1248,6 +1252,7 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
 }
 
 JPDSE_SWITCH(int, g_ring_enabled, 1);
+JPDSE_SWITCH(int, g_ring_small, 0);       // 31: ring strips on 128-row tiles, two blocks per CU (measured slower: 873 vs 955 TFLOP/s for the whole data gradient)
 JPDSE_SWITCH(int, g_merge_min_kt, 4);
 JPDSE_SWITCH(int, g_merge_min_tiles, 64);    // merged stride-phase data gradient on the fast kernel from this many 256-row tiles on (26: 384 as in round 1, A/B)
 JPDSE_SWITCH(int, g_halo_single, 1);
@@ -2073,15 +2078,18 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       const bf16_t* pk = reinterpret_cast<const bf16_t*>(pack);
       const int Mtb = d->N * (W + 2), Mlr = d->N * H;
       const int nt = (p.Cs + 127) / 128;
-      const int tiles = 2 * ((Mtb + 255) / 256) * nt + 2 * ((Mlr + 255) / 256) * nt;
+      // the strips have few rows (N (W + 2) and N H); developer mode 31 tries 128-row tiles (two blocks per CU): slower
+      const int bm = g_ring_small ? 128 : 256;
+      const int tiles = 2 * ((Mtb + bm - 1) / bm) * nt + 2 * ((Mlr + bm - 1) / bm) * nt;
       const int kt = 3 * Ks / 64;
-      int sp = 256 / tiles;
+      int sp = (g_ring_small ? 512 : 256) / tiles;
       if (sp > kt / 8) sp = kt / 8;
       if (sp > 8) sp = 8;
       if (sp < 1) sp = 1;
       float* slab = reinterpret_cast<float*>(wsb);
       const size_t tb_elems = (size_t)sp * Mtb * p.Cs, lr_elems = (size_t)sp * Mlr * p.Cs;
       FastBatch rb = {};
+      rb.small_m = g_ring_small;
       for (int q = 0; q < 4; ++q) {
         FastArgs g = {};
         const bool row_strip = q < 2;         // 0 top, 1 bottom, 2 left, 3 right
@@ -2898,6 +2906,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   // 0: generic kernels only; 1: fast kernels (default schedule 0); 2: fast kernels, alternative schedule 1
   g_fast_enabled = enable != 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
+  g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
   g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
   g_rows_enabled = enable != 29 && enable != 3;   // 29: 64-channel 3x3 layers on the halo / fast kernels instead of conv_rows (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;

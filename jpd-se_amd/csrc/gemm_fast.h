@@ -58,6 +58,7 @@ struct FastBatch {
   FastArgs p[4];
   int first_tile[5];
   int n;
+  int small_m;         // host only: every problem has few rows (the ring strips): 128-row tiles, two blocks per CU
 };
 
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {      // 32-bit LDS address of a generic pointer into LDS
@@ -402,14 +403,41 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   acc_tile_to_lds<TM, TN>(tile, PITCH, wm * TM * 32, wn * TN * 32, n0, lane, acc, a.bias, a.Kout, a.act, a.slope);
   __syncthreads();
   constexpr int VPR = BN / 8;
+  constexpr int NV = BM * VPR / (64 * NW);
+  static_assert(BM * VPR % (64 * NW) == 0, "every thread owns the same number of output vectors");
+  if (a.addend != nullptr || a.mask != nullptr) {
+    // fused operands loaded for all of the thread's vectors before the first store (see gemm_halo.h): groups of 8 vectors
+    constexpr int G8 = NV < 8 ? NV : 8;
+    for (int it0 = 0; it0 < NV; it0 += G8) {
+      u32x4 addv[G8], mskv[G8];
+#pragma unroll
+      for (int g = 0; g < G8; ++g) {
+        const int idx = tid + 64 * NW * (it0 + g);
+        const int row = idx / VPR, v = idx - row * VPR;
+        const long long off = row_off[row];
+        const bool on = it0 + g < NV && off >= 0 && n0 + v * 8 < a.Ks;
+        if (on && a.addend != nullptr) addv[g] = *reinterpret_cast<const u32x4*>(a.addend + off + n0 + v * 8);
+        if (on && a.mask != nullptr) mskv[g] = *reinterpret_cast<const u32x4*>(a.mask + off + n0 + v * 8);
+      }
+#pragma unroll
+      for (int g = 0; g < G8; ++g) {
+        const int idx = tid + 64 * NW * (it0 + g);
+        const int row = idx / VPR, v = idx - row * VPR;
+        const long long off = row_off[row];
+        if (it0 + g >= NV || off < 0 || n0 + v * 8 >= a.Ks) continue;
+        u32x4 val = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
+        if (a.addend != nullptr) val = add_bf16x8(val, addv[g]);
+        if (a.mask != nullptr) val = relu_mask8(val, mskv[g]);
+        *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = val;
+      }
+    }
+    return;
+  }
   for (int idx = tid; idx < BM * VPR; idx += 64 * NW) {
     const int row = idx / VPR, v = idx - row * VPR;
     const long long off = row_off[row];
     if (off < 0 || n0 + v * 8 >= a.Ks) continue;
-    u32x4 val = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
-    if (a.addend != nullptr) val = add_bf16x8(val, *reinterpret_cast<const u32x4*>(a.addend + off + n0 + v * 8));
-    if (a.mask != nullptr) val = relu_mask8(val, *reinterpret_cast<const u32x4*>(a.mask + off + n0 + v * 8));
-    *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = val;
+    *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
   }
 }
 

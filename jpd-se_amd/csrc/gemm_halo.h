@@ -337,14 +337,40 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   __syncthreads();
   const long long blk_base = a.out_base + n * a.out_sn + (long long)oh0 * a.out_sh + (long long)ow0 * a.out_sw;
   constexpr int VPR = BN / 8;
+  // The fused operands (fan-in addend, ReLU mask) are loaded for ALL of the thread's vectors before the first store: written as
+  // one loop, each load sat behind the previous store (the compiler cannot rule out that Y aliases them) and the epilogue
+  // paid one memory round trip per vector -- 8 in a row with the block alone on its CU.
+  constexpr int NV = TH * 64 * VPR / 512;
+  static_assert(TH * 64 * VPR % 512 == 0, "every thread owns the same number of output vectors");
+  if (a.addend != nullptr || a.mask != nullptr) {
+    u32x4 addv[NV], mskv[NV];
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int idx = tid + 512 * it;
+      const int row = idx / VPR, v = idx - row * VPR;
+      const long long off = blk_base + (long long)(row >> 6) * a.out_sh + (long long)(row & 63) * a.out_sw + n0 + v * 8;
+      const bool on = n0 + v * 8 < a.Ks;
+      if (on && a.addend != nullptr) addv[it] = *reinterpret_cast<const u32x4*>(a.addend + off);
+      if (on && a.mask != nullptr) mskv[it] = *reinterpret_cast<const u32x4*>(a.mask + off);
+    }
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int idx = tid + 512 * it;
+      const int row = idx / VPR, v = idx - row * VPR;
+      if (n0 + v * 8 >= a.Ks) continue;
+      const long long off = blk_base + (long long)(row >> 6) * a.out_sh + (long long)(row & 63) * a.out_sw + n0 + v * 8;
+      u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);
+      if (a.addend != nullptr) val = add_bf16x8(val, addv[it]);
+      if (a.mask != nullptr) val = relu_mask8(val, mskv[it]);
+      *reinterpret_cast<u32x4*>(a.Y + off) = val;
+    }
+    return;
+  }
   for (int idx = tid; idx < TH * 64 * VPR; idx += 512) {
     const int row = idx / VPR, v = idx - row * VPR;
     if (n0 + v * 8 >= a.Ks) continue;
     const long long off = blk_base + (long long)(row >> 6) * a.out_sh + (long long)(row & 63) * a.out_sw;
-    u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);
-    if (a.addend != nullptr) val = add_bf16x8(val, *reinterpret_cast<const u32x4*>(a.addend + off + n0 + v * 8));
-    if (a.mask != nullptr) val = relu_mask8(val, *reinterpret_cast<const u32x4*>(a.mask + off + n0 + v * 8));
-    *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = val;
+    *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);
   }
 }
 
