@@ -86,7 +86,10 @@ template <int STRIDE, int WC> struct RowsGeom {
   static constexpr int LA = STRIDE == 2 ? 2 : (WC == 2 ? 3 : 8);
   static_assert(STRIDE * LA + 3 <= NR, "rows in use + rows in flight fit the ring");
   static constexpr int ODD0 = 65;                             // stride 2: LDS pixel index of the first odd padded column
-  static constexpr int WTILE = MT * 32 * 80;                  // per-wave epilogue tile: pixels x (64 + 16) bytes
+  static constexpr int WPITCH = 64;                           // per-wave epilogue tile: pixels x 64 bytes, unpadded: the packed dword
+                                                              // stores (even lanes row r, odd lanes row r+1) and the 16-byte reads (4 rows x
+                                                              // 4 quarters per lane group) are both conflict free; pitch 80 cost 16 % of the LDS cycles
+  static constexpr int WTILE = MT * 32 * WPITCH;
   static constexpr int LDS = NR * ROWB + 4 * WTILE;
 };
 
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && WC == 2) ? 2 : 1)) void conv_
     base += STRIDE;
     base = base >= G::NR ? base - G::NR : base;
     // ---- epilogue of this output row: per-wave LDS tile (LDS operations of one wave execute in order), 16-byte stores
-    acc_rows_to_lds<MT>(lds_addr32(wtile), 80, lane, acc, bv, nslope, keep);
+    acc_rows_to_lds<MT>(lds_addr32(wtile), G::WPITCH, lane, acc, bv, nslope, keep);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (FUSED) {                                    // addend / mask loads are older than this iteration's row DMA
       if (wid < EXTRA) wait_vmcnt<STRIDE * U1>(); else wait_vmcnt<STRIDE * U0>();
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && WC == 2) ? 2 : 1)) void conv_
 #pragma unroll
     for (int t = 0; t < NST; ++t) {
       const int v = lane + 64 * t;
-      u32x4 val = *reinterpret_cast<const u32x4*>(wtile + (v >> 2) * 80 + (v & 3) * 16);
+      u32x4 val = *reinterpret_cast<const u32x4*>(wtile + (v >> 2) * G::WPITCH + (v & 3) * 16);
       const long long off = orow + (long long)(v >> 2) * a.out_sw + (v & 3) * 8;
       if constexpr (FUSED) {
         if (a.addend != nullptr) val = add_bf16x8(val, addv[t]);
