@@ -123,6 +123,14 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d);
  * InstanceNorm: the bias is cancelled exactly by the mean subtraction). */
 int jpdse_conv_fwd(const jpdse_conv_desc* d, const void* x, const void* fwd_pack,
                    const float* bias, void* y, void* ws, size_t ws_bytes, void* stream);
+/* Forward of a conv that feeds an affine-less InstanceNorm, with the norm's moment pass fused into the conv's epilogue
+ * (networks.py:204,216,245: conv -> norm): also writes moments[n][c][slot] = (sum y, sum y^2) over the pixels of block `slot`
+ * of image n, fp32 [N][CPAD(K)][slots][2] with slots = jpdse_conv_moment_slots(d) (0: this layer's kernel has no such
+ * epilogue -- use jpdse_conv_fwd + jpdse_inorm_fwd).  No bias (the norm cancels it), d->act must be JPDSE_ACT_NONE.
+ * jpdse_inorm_fwd_from_moments then replaces jpdse_inorm_fwd's moment pass. */
+int32_t jpdse_conv_moment_slots(const jpdse_conv_desc* d);
+int jpdse_conv_fwd_moments(const jpdse_conv_desc* d, const void* x, const void* fwd_pack, void* y, float* moments,
+                           void* ws, size_t ws_bytes, void* stream);
 /* dx = d(loss)/d(x) given dy = d(loss)/d(pre-activation output) */
 int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, void* dx,
                      void* ws, size_t ws_bytes, void* stream);
@@ -147,6 +155,10 @@ int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, fl
  * transposed conv's OUTPUT: N,H,W,C = output geometry, K = transposed conv's Cin). */
 int jpdse_convT_fwd(const jpdse_conv_desc* d, const void* x, const void* dgrad_pack, void* y,
                     void* ws, size_t ws_bytes, void* stream);
+/* jpdse_convT_fwd with the moments of its output (see jpdse_conv_fwd_moments); slots for the UNDERLYING conv descriptor */
+int32_t jpdse_convT_moment_slots(const jpdse_conv_desc* d);
+int jpdse_convT_fwd_moments(const jpdse_conv_desc* d, const void* x, const void* dgrad_pack, void* y, float* moments,
+                            void* ws, size_t ws_bytes, void* stream);
 int jpdse_convT_dgrad(const jpdse_conv_desc* d, const void* dy, const void* fwd_pack, void* dx,
                       void* ws, size_t ws_bytes, void* stream);
 int jpdse_convT_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw,
@@ -167,6 +179,10 @@ size_t jpdse_inorm_workspace_size(const jpdse_inorm_desc* d);
 /* stats: fp32 [N][CPAD(C)][2] = (mean, rstd), kept for backward */
 int jpdse_inorm_fwd(const jpdse_inorm_desc* d, const void* x, const void* residual, void* y,
                     float* stats, void* ws, size_t ws_bytes, void* stream);
+/* jpdse_inorm_fwd with the moment pass replaced by the per-block moments a conv epilogue wrote (jpdse_conv_fwd_moments):
+ * a finalize over the `slots` blocks of each (image, channel), summed in a fixed order, then the apply pass. */
+int jpdse_inorm_fwd_from_moments(const jpdse_inorm_desc* d, const void* x, const float* moments, int32_t slots,
+                                 const void* residual, void* y, float* stats, void* stream);
 /* dx from (x, stats, dy); the residual branch's gradient is dy itself */
 int jpdse_inorm_bwd(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy,
                     void* dx, void* ws, size_t ws_bytes, void* stream);

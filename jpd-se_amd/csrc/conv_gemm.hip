@@ -1309,6 +1309,19 @@ static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
 }
 
 
+
+// band height of the row-streaming kernels: as tall as possible (the filter load and the ring prologue are paid once per block)
+// while the grid still fills the chip (`want` blocks); small problems take 16 / 8 / 4
+static int rows_band_height(int N, int OH, int strips, int n_tiles, long long want, int min_th = 4) {
+  for (int cand = 64; cand >= min_th; cand >>= 1) {
+    if (OH % cand != 0) continue;
+    if ((long long)N * strips * (OH / cand) * n_tiles >= want) return cand;
+  }
+  for (int cand = 16; cand >= min_th; cand >>= 1)
+    if (OH % cand == 0) return cand;
+  return min_th;
+}
+
 // 3x3 convs over 64-channel inputs (stride 1 | 2, zero padding): filter in registers, input rows streamed once (conv_rows.h)
 JPDSE_SWITCH(int, g_rows_enabled, 1);       // 29: these layers on the halo / fast kernels (A/B)
 
@@ -1330,19 +1343,10 @@ static int launch_rows_cfg(RowsArgs a, hipStream_t s) {
   }
   a.n_tiles = a.Ks / (32 * WC);
   a.strips = a.OW / 64;
-  // band height: as tall as possible (the filter load and the ring prologue are paid once per block) while the grid still
-  // fills the chip (two blocks per CU for the 64-output stride-1 layers, one otherwise: LDS / registers)
-  const long long want = 256LL * ((STRIDE == 1 && WC == 2) ? 2 : 1);
-  int th = 0;
-  for (int cand = 64; cand >= 4; cand >>= 1) {
-    if (a.OH % cand != 0) continue;
-    if ((long long)a.N * a.strips * (a.OH / cand) * a.n_tiles >= want) { th = cand; break; }
-  }
-  if (th == 0)                                   // small problem: the grid cannot fill the chip anyway
-    for (int cand = 16; cand >= 4; cand >>= 1)
-      if (a.OH % cand == 0) { th = cand; break; }
-  a.TH = th;
+  a.TH = rows_band_height(a.N, a.OH, a.strips, a.n_tiles, 256LL * ((STRIDE == 1 && WC == 2) ? 2 : 1));
+  const int th = a.TH;
   a.bands = a.OH / th;
+  a.mom_slots = a.bands * a.strips * (4 / WC);
   const long long blocks = (long long)a.N * a.bands * a.strips * a.n_tiles;
   if (blocks > 0x7fffffffLL) return set_error(JPDSE_EINVAL, "conv_rows: grid too large");
   hipLaunchKernelGGL((conv_rows_kernel<STRIDE, WC, FUSED>), dim3((unsigned)blocks), dim3(256), G::LDS, s, a);
@@ -1372,16 +1376,10 @@ static int launch_dgrad2_rows(Dgrad2Args a, hipStream_t s) {
     configured = true;
   }
   a.strips = a.OW / 64;
-  int th = 0;
-  for (int cand = 64; cand >= 4; cand >>= 1) {
-    if (a.OH % cand != 0) continue;
-    if ((long long)a.N * a.strips * (a.OH / cand) >= 256) { th = cand; break; }
-  }
-  if (th == 0)
-    for (int cand = 16; cand >= 4; cand >>= 1)
-      if (a.OH % cand == 0) { th = cand; break; }
+  const int th = rows_band_height(a.N, a.OH, a.strips, 1, 256);
   a.TH = th;
   a.bands = a.OH / th;
+  a.mom_slots = a.bands * a.strips;
   hipLaunchKernelGGL(dgrad2_rows_kernel, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
   return check_launch("dgrad2_rows_kernel");
 }
@@ -1607,9 +1605,48 @@ static bool tapsum_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
          p.Cs % 64 == 0 && p.Cs >= 256 && p.Lk_fwd == d->S * p.Cs;
 }
 
+
+// ---- forward moments for the InstanceNorm that follows a conv (jpdse_conv_fwd_moments): which layers write them, and how many
+// slots per image.  These mirror the dispatch order of conv_fwd_t / conv_dgrad_t.
+static bool thin_rows_takes(const jpdse_conv_desc* d, const ConvPlan& p) {
+  return g_rows_enabled && d->stride == 2 && d->R == 4 && d->S == 4 && p.Cs == 40 && p.Ks == 64 && d->K == 64 &&
+         d->pad_mode != JPDSE_PAD_REFLECT && p.KP_thin == 168;
+}
+static bool thin_in_rows_takes(const jpdse_conv_desc* d, const ConvPlan& p) {
+  return g_fast_enabled && g_rows_enabled && p.Cs == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
+         d->pad_mode == JPDSE_PAD_ZERO && p.Ks == 64 && d->K == 64 && p.Lk_fwd == 32;
+}
+static int conv_fwd_moment_slots(const jpdse_conv_desc* d, const ConvPlan& p) {
+  if (d->dtype != JPDSE_BF16 || d->act != JPDSE_ACT_NONE) return 0;
+  if (thin_in_rows_takes(d, p)) return 0;
+  ThinFwdGeom tg;
+  if (thin_fwd_geom(d, p, &tg)) {
+    if (thin_rows_takes(d, p)) return 0;
+    return (p.OH % tg.TH == 0 && p.OW % tg.TW == 0) ? (p.OH / tg.TH) * (p.OW / tg.TW) : 0;
+  }
+  if (head_fwd_ok(d, p) || tapsum_ok(d, p)) return 0;
+  if (rows_ok(d->R, d->S, d->stride, d->pad_mode == JPDSE_PAD_REFLECT, d->act, p.OH, p.OW, p.Cs, p.Ks)) {
+    const int WC = p.Ks % 128 == 0 ? 4 : 2, strips = p.OW / 64, n_tiles = p.Ks / (32 * WC);
+    const int th = rows_band_height(d->N, p.OH, strips, n_tiles, 256LL * ((d->stride == 1 && WC == 2) ? 2 : 1));
+    return (p.OH / th) * strips * (4 / WC);
+  }
+  return 0;
+}
+static bool dgrad2_rows_takes(const jpdse_conv_desc* d, const ConvPlan& p) {
+  return d->dtype == JPDSE_BF16 && g_fast_enabled && g_rows_enabled && d->pad_mode != JPDSE_PAD_REFLECT && d->stride == 2 && d->R == 3 &&
+         d->S == 3 && d->pad == 1 && p.Ks == 128 && p.Cs == 64 && d->C == 64 && d->H == 2 * p.OH && d->W == 2 * p.OW &&
+         p.OW % 64 == 0 && p.OH % 4 == 0 && p.nph == 4;
+}
+static int convT_fwd_moment_slots(const jpdse_conv_desc* d, const ConvPlan& p) {
+  if (!dgrad2_rows_takes(d, p)) return 0;
+  const int strips = p.OW / 64;
+  return (p.OH / rows_band_height(d->N, p.OH, strips, 1, 256)) * strips;
+}
+
 template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
-                      const float* bias, void* y, void* ws, hipStream_t s) {
+                      const float* bias, void* y, void* ws, hipStream_t s, float* mom = nullptr) {
+  // mom != nullptr: the caller asked jpdse_conv_moment_slots first, so the branch taken below is one that writes them
   if constexpr (sizeof(T) == 2) {
     if (g_fast_enabled && g_rows_enabled && p.Cs == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
         d->pad_mode == JPDSE_PAD_ZERO && p.Ks == 64 && d->K == 64 && p.Lk_fwd == 32 &&
@@ -1656,6 +1693,10 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       t.w_units = tg.w_units;
       t.tiles_w = (p.OW + tg.TW - 1) / tg.TW;
       t.tiles_h = (p.OH + tg.TH - 1) / tg.TH;
+      if (mom != nullptr && !thin_rows_takes(d, p)) {
+        t.mom = mom;
+        t.mom_slots = t.tiles_w * t.tiles_h;
+      }
       if (g_rows_enabled && d->stride == 2 && d->R == 4 && d->S == 4 && p.Cs == 40 && p.Ks == 64 && d->K == 64 && !t.reflect &&
           p.KP_thin == 168 && (d->act == JPDSE_ACT_NONE || d->act == JPDSE_ACT_RELU || d->act == JPDSE_ACT_LRELU))
         return launch_thin_rows(t, s);
@@ -1738,6 +1779,7 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       r.out_base = 0;
       r.act = d->act;
       r.slope = d->slope;
+      r.mom = mom;
       return launch_rows(r, d->stride, s);
     }
     if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks)) {
@@ -1983,7 +2025,7 @@ __global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask,
 
 template <typename T>
 static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx,
-                        void* ws, hipStream_t s, const void* mask = nullptr, const void* addend = nullptr) {
+                        void* ws, hipStream_t s, const void* mask = nullptr, const void* addend = nullptr, float* mom = nullptr) {
   char* wsb = reinterpret_cast<char*>(ws);
   void* dyp = wsb;
   void* dxp = wsb + p.dypad_bytes;
@@ -2186,6 +2228,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       g.N = d->N;
       g.OH = p.OH;
       g.OW = p.OW;
+      g.mom = mom;
       return launch_dgrad2_rows(g, s);
     }
   }
@@ -3160,6 +3203,46 @@ int jpdse_conv_fwd(const jpdse_conv_desc* d, const void* x, const void* fwd_pack
     return set_error(JPDSE_EWORKSPACE, "conv_fwd: workspace %zu < %zu", ws_bytes, need);
   return d->dtype == JPDSE_BF16 ? conv_fwd_t<bf16_t>(d, p, x, fwd_pack, bias, y, ws, as_stream(stream))
                                 : conv_fwd_t<float>(d, p, x, fwd_pack, bias, y, ws, as_stream(stream));
+}
+
+int32_t jpdse_conv_moment_slots(const jpdse_conv_desc* d) {
+  if (validate(d)) return 0;
+  ConvPlan p;
+  make_plan(d, &p);
+  return conv_fwd_moment_slots(d, p);
+}
+
+int32_t jpdse_convT_moment_slots(const jpdse_conv_desc* d) {
+  if (validate(d)) return 0;
+  ConvPlan p;
+  make_plan(d, &p);
+  return convT_fwd_moment_slots(d, p);
+}
+
+int jpdse_conv_fwd_moments(const jpdse_conv_desc* d, const void* x, const void* fwd_pack, void* y, float* moments, void* ws,
+                           size_t ws_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(x && fwd_pack && y && moments, "conv_fwd_moments: null pointer");
+  ConvPlan p;
+  make_plan(d, &p);
+  JPDSE_REQUIRE(conv_fwd_moment_slots(d, p) > 0, "conv_fwd_moments: this layer has no moment epilogue (jpdse_conv_moment_slots == 0)");
+  const size_t need = jpdse_conv_workspace_size(d);
+  if (ws == nullptr || ws_bytes < need)
+    return set_error(JPDSE_EWORKSPACE, "conv_fwd_moments: workspace %zu < %zu", ws_bytes, need);
+  return conv_fwd_t<bf16_t>(d, p, x, fwd_pack, nullptr, y, ws, as_stream(stream), moments);
+}
+
+int jpdse_convT_fwd_moments(const jpdse_conv_desc* d, const void* x, const void* dgrad_pack, void* y, float* moments, void* ws,
+                            size_t ws_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(x && dgrad_pack && y && moments, "convT_fwd_moments: null pointer");
+  ConvPlan p;
+  make_plan(d, &p);
+  JPDSE_REQUIRE(convT_fwd_moment_slots(d, p) > 0, "convT_fwd_moments: this layer has no moment epilogue (jpdse_convT_moment_slots == 0)");
+  const size_t need = jpdse_conv_workspace_size(d);
+  if (ws == nullptr || ws_bytes < need)
+    return set_error(JPDSE_EWORKSPACE, "convT_fwd_moments: workspace %zu < %zu", ws_bytes, need);
+  return conv_dgrad_t<bf16_t>(d, p, x, dgrad_pack, y, ws, as_stream(stream), nullptr, nullptr, moments);
 }
 
 int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, void* dx, void* ws,

@@ -72,6 +72,8 @@ struct RowsArgs {
   const bf16_t* addend;  // optional: Y = result + addend, before the mask
   int TH, bands, strips;
   int n_tiles;           // Ks / (32 * WC) column tiles (blockIdx fastest but one)
+  float* mom;            // optional: per-block sums of y and y^2 per channel for the InstanceNorm that follows,
+  int mom_slots;         //   [N][Ks][mom_slots][2], slot = (band * strips + strip) * WP + wp (bias NULL, no activation)
 };
 
 template <int STRIDE, int WC> struct RowsGeom {
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && WC == 2) ? 2 : 1)) void conv_
 #pragma unroll
   for (int t = 0; t < 36; ++t) asm volatile("" : "+v"(breg[t]));
 
+  float ms1 = 0.f, ms2 = 0.f;                                 // moments of this lane's column over the block's rows
   int base = 0;                                               // ring slot of input row STRIDE * i
   int nslot = PRO % G::NR;                                    // ring slot of the next row to issue
   int njr = PRO;
@@ -281,6 +284,16 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && WC == 2) ? 2 : 1)) void conv_
     __builtin_amdgcn_s_setprio(0);
     base += STRIDE;
     base = base >= G::NR ? base - G::NR : base;
+    if (a.mom != nullptr) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[mt][0][e];
+          ms1 += v;
+          ms2 += v * v;
+        }
+    }
     // ---- epilogue of this output row: per-wave LDS tile (LDS operations of one wave execute in order), 16-byte stores
     acc_rows_to_lds<MT>(lds_addr32(wtile), G::WPITCH, lane, acc, bv, nslope, keep);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -298,6 +311,17 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && WC == 2) ? 2 : 1)) void conv_
         if (a.mask != nullptr) val = relu_mask8(val, mskv[t]);
       }
       *reinterpret_cast<u32x4*>(a.Y + off) = val;
+    }
+  }
+  if (a.mom != nullptr) {
+    ms1 += __shfl_xor(ms1, 32, 64);                           // lanes l and l + 32 hold the same column (other pixel rows)
+    ms2 += __shfl_xor(ms2, 32, 64);
+    const int col = ncol0 + lane;
+    if (lane < 32 && col < a.Ks) {
+      const int slot = (band * a.strips + strip) * WP + wp;
+      float* const o = a.mom + (((long long)n * a.Ks + col) * a.mom_slots + slot) * 2;
+      o[0] = ms1;
+      o[1] = ms2;
     }
   }
 }

@@ -29,6 +29,8 @@ struct Dgrad2Args {
   bf16_t* DX;            // [N][2 OH][2 OW][64]
   int N, OH, OW;
   int TH, bands, strips;
+  float* mom;            // optional moments of dx for the InstanceNorm that follows: [N][64][mom_slots][2], slot = band * strips + strip
+  int mom_slots;
 };
 
 struct Dgrad2Geom {
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
   const int odd = lane & 1;
   const long long img_out = (long long)n * (2 * a.OH) * (2 * a.OW) * 64;
 
+  float ms1 = 0.f, ms2 = 0.f;
   int base = 0;                                         // ring slot of dy row a0 + i
   int nslot = (G::LA + 1) % G::NR, njr = G::LA + 1;
   for (int i = 0; i < a.TH; ++i) {
@@ -187,6 +190,18 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
       acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[3], breg[8 * 4 + ks], acc[mt][3], 0, 0, 0);
     }
     base = base + 1 == G::NR ? 0 : base + 1;
+    if (a.mom != nullptr) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = acc[mt][ph][e];
+            ms1 += v;
+            ms2 += v * v;
+          }
+    }
     __builtin_amdgcn_s_barrier();       // B: every thread has read the previous tile (right after barrier A)
     asm volatile("" ::: "memory");
     // ---- accumulators -> tile[pr][2 * bl + pc][channel]: lane pairs exchange so that each writes a (c, c+1) dword
@@ -219,6 +234,16 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
       const int pxl = idx >> 3, part = idx & 7;
       const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + pxl * G::PITCH + part * 16);
       *reinterpret_cast<u32x4*>(a.DX + orow + (long long)(pxl >> 7) * (2 * a.OW) * 64 + (pxl & 127) * 64 + part * 8) = val;
+    }
+  }
+  if (a.mom != nullptr) {
+    ms1 += __shfl_xor(ms1, 16, 64); ms2 += __shfl_xor(ms2, 16, 64);   // the four lane groups hold the same column
+    ms1 += __shfl_xor(ms1, 32, 64); ms2 += __shfl_xor(ms2, 32, 64);
+    if (lane < 16) {
+      const int col = wid * 16 + lane, slot = band * a.strips + strip;
+      float* const o = a.mom + (((long long)n * 64 + col) * a.mom_slots + slot) * 2;
+      o[0] = ms1;
+      o[1] = ms2;
     }
   }
 }

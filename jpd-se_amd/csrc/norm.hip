@@ -812,6 +812,56 @@ static int inorm_bwd_t(const jpdse_inorm_desc* d, const void* x, const float* st
   return check_launch("inorm apply bwd");
 }
 
+
+// Forward statistics from per-block moments written by a conv epilogue: moments[n][c][slot] = (sum y, sum y^2) over the
+// block's pixels.  One wave per (n, c): lane l adds slots l, l + 64, ... in order, then the fixed xor tree -- deterministic.
+__global__ __launch_bounds__(256) void finalize_slots_kernel(const float* __restrict__ mom, float* __restrict__ stats, int NC,
+                                                            int slots, int HW, float eps) {
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pair >= NC) return;
+  const float2* const src = reinterpret_cast<const float2*>(mom) + (long long)pair * slots;
+  float a = 0.f, b = 0.f;
+  int s = lane;
+  for (; s + 192 < slots; s += 256) {
+    const float2 v0 = src[s], v1 = src[s + 64], v2 = src[s + 128], v3 = src[s + 192];
+    a += v0.x; b += v0.y;
+    a += v1.x; b += v1.y;
+    a += v2.x; b += v2.y;
+    a += v3.x; b += v3.y;
+  }
+  for (; s < slots; s += 64) {
+    const float2 v = src[s];
+    a += v.x;
+    b += v.y;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (lane == 0) {
+    const float inv = 1.f / (float)HW;
+    const float mean = a * inv;
+    float var = b * inv - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    stats[2 * pair] = mean;
+    stats[2 * pair + 1] = rsqrtf(var + eps);
+  }
+}
+
+template <typename T>
+static int inorm_from_moments_t(const jpdse_inorm_desc* d, const void* x, const float* mom, int slots, const void* res, void* y,
+                                float* stats, hipStream_t s) {
+  constexpr int VE = Vec16<T>::N;
+  const int HW = d->H * d->W, Cs = cpad(d->C);
+  const int NC = d->N * Cs;
+  hipLaunchKernelGGL(finalize_slots_kernel, dim3((NC + 3) / 4), dim3(256), 0, s, mom, stats, NC, slots, HW, d->eps);
+  if (int rc = check_launch("inorm finalize from moments")) return rc;
+  MomentGeom g = moment_geom(d->N, HW, Cs, VE);
+  const int col_blocks = (g.cv + g.TX - 1) / g.TX;
+  hipLaunchKernelGGL((inorm_apply_fwd_kernel<T>), dim3(d->N * g.splits * col_blocks), dim3(256), 0, s,
+                     reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(res), reinterpret_cast<T*>(y), stats,
+                     d->act, d->slope, g);
+  return check_launch("inorm apply fwd");
+}
+
 }  // namespace jpdse
 
 using namespace jpdse;
@@ -843,6 +893,16 @@ int jpdse_inorm_bwd(const jpdse_inorm_desc* d, const void* x, const float* stats
     return set_error(JPDSE_EWORKSPACE, "inorm_bwd: workspace %zu < %zu", ws_bytes, ws_bytes_for(d));
   return d->dtype == JPDSE_BF16 ? inorm_bwd_t<bf16_t>(d, x, stats, dy, dx, ws, as_stream(stream))
                                 : inorm_bwd_t<float>(d, x, stats, dy, dx, ws, as_stream(stream));
+}
+
+int jpdse_inorm_fwd_from_moments(const jpdse_inorm_desc* d, const void* x, const float* moments, int32_t slots,
+                                 const void* residual, void* y, float* stats, void* stream) {
+  if (int rc = jpdse::validate(d)) return rc;
+  JPDSE_REQUIRE(x && y && stats && moments && slots > 0, "inorm_fwd_from_moments: null pointer / no slots");
+  JPDSE_REQUIRE(!d->has_residual || residual, "inorm_fwd_from_moments: has_residual set but residual is null");
+  const void* res = d->has_residual ? residual : nullptr;
+  return d->dtype == JPDSE_BF16 ? inorm_from_moments_t<bf16_t>(d, x, moments, slots, res, y, stats, as_stream(stream))
+                                : inorm_from_moments_t<float>(d, x, moments, slots, res, y, stats, as_stream(stream));
 }
 
 }  // extern "C"

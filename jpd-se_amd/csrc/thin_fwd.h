@@ -24,6 +24,8 @@ struct ThinFwdArgs {
   int strip_units;     // 1 KiB units per strip ((64 + S - 1) * Cs * 2 bytes rounded up)
   int w_units;         // 1 KiB units per filter row panel (K * KP * 2 bytes rounded up)
   int tiles_w, tiles_h;
+  float* mom;          // optional moments of y for the InstanceNorm that follows: [N][Ks][mom_slots][2], slot = tile (full tiles only,
+  int mom_slots;       //   no bias / activation: the launcher checks)
 };
 
 // TH output rows per block, 8 waves = TH rows x (8 / TH) column groups of TN 32-wide tiles (K = 32 * TN * 8 / TH);
@@ -108,6 +110,39 @@ __global__ __launch_bounds__(512) void thin_fwd_kernel(const ThinFwdArgs a) {
     __builtin_amdgcn_s_setprio(0);
   }
 
+  // ---- optional moments: per lane over its column's pixels, lane halves, then the TH row-waves of a column group through LDS
+  if (a.mom != nullptr) {
+    __syncthreads();                                   // the strips are dead
+    float* const red = reinterpret_cast<float*>(smem);  // [TH][WN * TN * 32][2]
+    constexpr int BNC = WN * TN * 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[i][j][e];
+          s1 += v;
+          s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 32) {
+        const int col = wcol * TN * 32 + j * 32 + lane;
+        red[(wrow * BNC + col) * 2] = s1;
+        red[(wrow * BNC + col) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BNC * 2) {
+      float t = 0.f;
+      for (int r = 0; r < TH; ++r) t += red[r * BNC * 2 + tid];
+      const int col = tid >> 1;
+      if (col < a.Ks)
+        a.mom[(((long long)n * a.Ks + col) * a.mom_slots + (th * a.tiles_w + tw)) * 2 + (tid & 1)] = t;
+    }
+  }
   // ---- epilogue: wave w = output row oh0 + w; bias + activation, 16-byte stores through LDS -----------------------
   __syncthreads();
   constexpr int BN = WN * TN * 32, PITCH = BN * 2 + 64;

@@ -71,6 +71,11 @@ SIGNATURES = {
     'jpdse_conv_dgrad_fused': (_I32, [_CD, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_wgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_convT_fwd': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_conv_moment_slots': (_I32, [_CD]),
+    'jpdse_convT_moment_slots': (_I32, [_CD]),
+    'jpdse_conv_fwd_moments': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_convT_fwd_moments': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_inorm_fwd_from_moments': (_I32, [_ND, _P, _P, _I32, _P, _P, _P, _P]),
     'jpdse_convT_dgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_convT_wgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_inorm_workspace_size': (_SZ, [_ND]),

@@ -176,6 +176,24 @@ class HipConv2d(nn.Module):
     y = ops.conv_fwd(d, x, fwd_pack, self.bias if self.apply_bias else None)
     return y, Ctx(x, y if self.act != ACT_NONE else None)
 
+  def fwd_moments(self, x):
+    """Forward for a conv whose output goes straight into an affine-less InstanceNorm: (y, ctx, moments, slots) with the
+    norm's moment pass fused into the conv epilogue (jpdse_conv_fwd_moments), or None when this layer's kernel has no such
+    epilogue (or the layer applies a bias / activation)."""
+    if self.apply_bias or self.act != ACT_NONE or self.cdtype != BF16:
+      return None
+    d = self._desc(x.N, 2 * x.H, 2 * x.W) if self.transposed else self._desc(x.N, x.H, x.W)
+    key = (x.N, x.H, x.W)
+    cache = self.__dict__.setdefault('_moment_slots', {})
+    if key not in cache:
+      cache[key] = ops.conv_moment_slots(d, self.transposed)
+    slots = cache[key]
+    if slots <= 0:
+      return None
+    fwd_pack, dgrad_pack = self.packs()
+    y, mom = ops.conv_fwd_moments(d, x, dgrad_pack if self.transposed else fwd_pack, slots, self.transposed)
+    return y, (Ctx(x) if self.transposed else Ctx(x, None)), mom, slots
+
   def bwd(self, ctx, dy, need_dx=True, need_dw=True, dy_is_dz=False, relu_input=False, addend=None):
     """dy_is_dz: dy is already the gradient w.r.t. the PRE-activation (the caller fused this layer's
     activation backward upstream); relu_input: the layer's input is a ReLU output and the returned dx
@@ -279,6 +297,10 @@ class InstNormAct(object):
     y, stats = ops.inorm_fwd(x, self.act, self.slope, self.eps, residual)
     return y, Ctx(x, stats)
 
+  def fwd_from_moments(self, x, mom, slots, residual=None):
+    y, stats = ops.inorm_fwd_from_moments(x, mom, slots, self.act, self.slope, self.eps, residual)
+    return y, Ctx(x, stats)
+
   def bwd(self, ctx, dy, need_dx=True, need_dw=True):
     x, stats = ctx.items
     return ops.inorm_bwd(x, stats, dy, self.act, self.slope, self.eps)
@@ -292,6 +314,11 @@ class ConvNormAct(object):
     self.conv, self.norm = conv, norm
 
   def fwd(self, x):
+    fused = self.conv.fwd_moments(x)
+    if fused is not None:                      # the norm's moment pass ran in the conv epilogue
+      h, c1, mom, slots = fused
+      y, c2 = self.norm.fwd_from_moments(h, mom, slots)
+      return y, Ctx(c1, c2)
     h, c1 = self.conv.fwd(x)
     y, c2 = self.norm.fwd(h)
     return y, Ctx(c1, c2)

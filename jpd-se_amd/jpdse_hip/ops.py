@@ -141,6 +141,38 @@ def conv_wgrad(d, x, dy, dw):
   check(lib().jpdse_conv_wgrad(ctypes.byref(d), _p(x.t), _p(dy.t), _p(dw), _p(ws), ws.numel(), _stream()), 'conv_wgrad')
 
 
+# ---- conv forward with the InstanceNorm moments fused into its epilogue -------------------------
+def conv_moment_slots(d, transposed=False):
+  """Blocks per image whose moments the layer's forward kernel writes (0: no such epilogue for this layer)."""
+  fn = lib().jpdse_convT_moment_slots if transposed else lib().jpdse_conv_moment_slots
+  return int(fn(ctypes.byref(d)))
+
+
+def conv_fwd_moments(d, x, pack, slots, transposed=False):
+  """y = conv(x) (no bias, no activation) and moments [N][CPAD(K)][slots][2] of y; for transposed=True `d` describes the
+  underlying conv (its input is the ConvTranspose output) and `pack` is the data-gradient panel."""
+  if transposed:
+    y = Act.empty(d.N, d.H, d.W, d.C, d.dtype, x.t.device)
+  else:
+    oh, ow = conv_out_shape(d)
+    y = Act.empty(d.N, oh, ow, d.K, d.dtype, x.t.device)
+  mom = torch.empty((d.N, y.Cs, slots, 2), dtype=torch.float32, device=x.t.device)
+  ws, n = _conv_ws(d, x.t.device)
+  fn = lib().jpdse_convT_fwd_moments if transposed else lib().jpdse_conv_fwd_moments
+  check(fn(ctypes.byref(d), _p(x.t), _p(pack), _p(y.t), _p(mom), _p(ws), ws.numel(), _stream()), 'conv_fwd_moments')
+  return y, mom
+
+
+def inorm_fwd_from_moments(x, mom, slots, act, slope=0.2, eps=1e-5, residual=None):
+  d = InormDesc(x.dtype, x.N, x.H, x.W, x.C, act, slope, eps, 1 if residual is not None else 0)
+  y = x.empty_like()
+  stats = torch.empty((x.N, x.Cs, 2), dtype=torch.float32, device=x.t.device)
+  check(lib().jpdse_inorm_fwd_from_moments(ctypes.byref(d), _p(x.t), _p(mom), slots,
+                                           _p(residual.t if residual is not None else None), _p(y.t), _p(stats), _stream()),
+        'inorm_fwd_from_moments')
+  return y, stats
+
+
 # ---- instance norm ----------------------------------------------------------------------------
 def inorm_fwd(x, act, slope=0.2, eps=1e-5, residual=None):
   d = InormDesc(x.dtype, x.N, x.H, x.W, x.C, act, slope, eps, 1 if residual is not None else 0)

@@ -332,6 +332,49 @@ def test_conv_dgrad_input_slice(shape, dtype):
   assert (dx.t[..., 3:] == 0).all()
 
 
+# conv -> InstanceNorm with the norm's moment pass fused into the conv epilogue (jpdse_conv_fwd_moments): the three producers
+# that have the epilogue -- thin_fwd (first 7x7 conv), conv_rows (64 -> 128 stride 2), dgrad2_rows (ConvTranspose 128 -> 64)
+# -- against the unfused sequence on the same layer (same kernels, moments from a separate pass) and against torch.
+from jpdse_hip.layers import ConvNormAct
+
+FUSED_MOMENT_CASES = [
+    ('first7x7',  lambda: HipConv2d(39, 64, 7, 1, 3, PAD_REFLECT, apply_bias=False, dtype=BF16, device=DEV), (2, 39, 16, 128)),
+    ('down_s2',   lambda: HipConv2d(64, 128, 3, 2, 1, PAD_ZERO, apply_bias=False, dtype=BF16, device=DEV), (2, 64, 32, 128)),
+    ('convT_up',  lambda: HipConv2d(128, 64, 3, 2, 1, transposed=True, apply_bias=False, dtype=BF16, device=DEV), (2, 128, 16, 64)),
+]
+
+
+@pytest.mark.parametrize('name,make,shape', FUSED_MOMENT_CASES, ids=[c[0] for c in FUSED_MOMENT_CASES])
+def test_conv_norm_fused_moments(name, make, shape):
+  g = G(zlib.crc32(name.encode()) & 0xfff)
+  conv = make()
+  with torch.no_grad():
+    conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (1.0 / (conv.weight[0].numel()) ** 0.5))
+  stage = ConvNormAct(conv, InstNormAct(ACT_RELU))
+  x = to_act(quantize_like(torch.randn(*shape, generator=g), BF16), BF16)
+  assert conv.fwd_moments(x) is not None, 'this layer is expected to take the fused epilogue'
+  y, ctx = stage.fwd(x)
+  gy = to_act(quantize_like(torch.randn(to_nchw(y).shape, generator=g), BF16), BF16)
+  dx = stage.bwd(ctx, gy, True, True)
+  dw = conv.weight.grad.clone()
+  stats = ctx.items[1].items[1].clone()
+  torch.cuda.synchronize()
+  # unfused reference on the same layer
+  conv.fwd_moments = lambda _x: None
+  y2, ctx2 = stage.fwd(x)
+  dx2 = stage.bwd(ctx2, gy, True, True)
+  torch.cuda.synchronize()
+  C = to_nchw(y).shape[1]
+  assert torch.equal(ctx.items[1].items[0].t, ctx2.items[1].items[0].t), 'the conv output itself must not change'
+  assert_close(stats.cpu()[:, :C], ctx2.items[1].items[1].cpu()[:, :C], 1e-3, name + ' stats (moments of the fp32 accumulators vs a pass over the bf16-rounded output)')
+  assert_close(to_nchw(y), to_nchw(y2), RTOL[BF16], name + ' norm output')
+  assert_close(to_nchw(dx), to_nchw(dx2), 3 * RTOL[BF16], name + ' dx')
+  assert_close(dw.cpu(), conv.weight.grad.cpu(), 3 * RTOL[BF16], name + ' dw')
+  # and against torch on the fp32 view of the same conv output
+  h = to_nchw(ctx.items[1].items[0])
+  assert_close(to_nchw(y), F.relu(F.instance_norm(h, eps=1e-5)), RTOL[BF16], name + ' vs torch')
+
+
 # ---- instance norm -----------------------------------------------------------------------------
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('act', [ACT_NONE, ACT_RELU, ACT_LRELU])
