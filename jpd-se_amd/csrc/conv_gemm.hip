@@ -1616,8 +1616,9 @@ static bool thin_in_rows_takes(const jpdse_conv_desc* d, const ConvPlan& p) {
   return g_fast_enabled && g_rows_enabled && p.Cs == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
          d->pad_mode == JPDSE_PAD_ZERO && p.Ks == 64 && d->K == 64 && p.Lk_fwd == 32;
 }
+JPDSE_SWITCH(int, g_moments_fused, 1);     // 32 (and 6: the rounding-point-preserving comparison mode): no moment epilogues
 static int conv_fwd_moment_slots(const jpdse_conv_desc* d, const ConvPlan& p) {
-  if (d->dtype != JPDSE_BF16 || d->act != JPDSE_ACT_NONE) return 0;
+  if (!g_moments_fused || d->dtype != JPDSE_BF16 || d->act != JPDSE_ACT_NONE) return 0;
   if (thin_in_rows_takes(d, p)) return 0;
   ThinFwdGeom tg;
   if (thin_fwd_geom(d, p, &tg)) {
@@ -1638,7 +1639,7 @@ static bool dgrad2_rows_takes(const jpdse_conv_desc* d, const ConvPlan& p) {
          p.OW % 64 == 0 && p.OH % 4 == 0 && p.nph == 4;
 }
 static int convT_fwd_moment_slots(const jpdse_conv_desc* d, const ConvPlan& p) {
-  if (!dgrad2_rows_takes(d, p)) return 0;
+  if (!g_moments_fused || !dgrad2_rows_takes(d, p)) return 0;
   const int strips = p.OW / 64;
   return (p.OH / rows_band_height(d->N, p.OH, strips, 1, 256)) * strips;
 }
@@ -2949,6 +2950,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   // 0: generic kernels only; 1: fast kernels (default schedule 0); 2: fast kernels, alternative schedule 1
   g_fast_enabled = enable != 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
+  g_moments_fused = enable != 32 && enable != 6;   // 32: InstanceNorm moments always in their own pass (A/B); 6 keeps the generic kernels' rounding points
   g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
   g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
   g_rows_enabled = enable != 29 && enable != 3;   // 29: 64-channel 3x3 layers on the halo / fast kernels instead of conv_rows (A/B)
