@@ -58,6 +58,18 @@ def _wrap(kind):
 
 
 ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = _wrap('fwd'), _wrap('dgrad'), _wrap('wgrad')
+# convs whose epilogue also writes the InstanceNorm moments (ConvTranspose forward = the data gradient of the underlying conv)
+_fm = ops.conv_fwd_moments
+def _fwd_moments(d, x, pack, slots, transposed=False):
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  c0 = time.perf_counter()
+  r = _fm(d, x, pack, slots, transposed)
+  c1 = time.perf_counter()
+  e1.record()
+  records.append((_key('dgrad' if transposed else 'fwd', d), e0, e1, c1 - c0))
+  return r
+ops.conv_fwd_moments = _fwd_moments
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record()
 for _ in range(args.steps):
