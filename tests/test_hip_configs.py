@@ -130,6 +130,43 @@ def test_checkpointed_resblocks_bit_identical_and_smaller():
   assert res[True][2] < res[False][2]
 
 
+# ---- BASELINE size (1024x512, batch 4): the thin-channel layers that the row-streaming kernels took over late in round 2 ---
+LAYERS_1024_THIN = [
+    ('vgg_conv1_1',        4, 512, 1024, 3,   64,  3, 1, 1, PAD_ZERO),      # thin_in_rows<3> fwd, head_rows<3> dgrad
+    ('vgg_conv2_1',        4, 256, 512,  64,  128, 3, 1, 1, PAD_ZERO),      # conv_rows<1,4>
+    ('g_up_convT_as_conv', 4, 512, 1024, 64,  128, 3, 2, 1, PAD_ZERO),      # conv_rows<2,4> fwd, dgrad2_rows dgrad
+    ('g_head_7x7',         4, 512, 1024, 64,  3,   7, 1, 3, PAD_REFLECT),   # head_rows<7> fwd, thin_in_rows<7> dgrad + ring fold
+    ('d_layer0',           8, 512, 1024, 39,  64,  4, 2, 2, PAD_ZERO),      # thin_rows fwd
+]
+
+
+@pytest.mark.parametrize('case', LAYERS_1024_THIN, ids=[c[0] for c in LAYERS_1024_THIN])
+def test_1024x512_adjointness_thin_layers_bf16(case):
+  assert _adjointness(*case), 'weight gradient not bit-reproducible'
+
+
+def test_1024x512_layer0_image_slice_gradient_is_the_adjoint_of_the_slice_bf16():
+  """PatchGAN layer 0 at the bench size: the data gradient w.r.t. the 3 image channels (thin_dgrad2_rows) is the adjoint of
+  the conv restricted to those channels: <conv(x with only channels 36..38 set), dy> = <x[36:39], dx_slice>."""
+  g = torch.Generator(device=DEV).manual_seed(5)
+  layer = HipConv2d(39, 64, 4, 2, 2, PAD_ZERO, act=ACT_NONE, apply_bias=False, dtype=BF16, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(torch.randn(layer.weight.shape, generator=g, device=DEV) * (1.0 / (39 * 16) ** 0.5))
+  x = Act.empty(4, 512, 1024, 39, BF16, DEV)
+  x.t.zero_()
+  x.t[..., 36:39] = torch.randn((4, 512, 1024, 3), generator=g, device=DEV).to(torch.bfloat16)
+  y, ctx = layer.fwd(x)
+  dy = y.empty_like()
+  dy.t.copy_(torch.randn(dy.t.shape, generator=g, device=DEV).to(torch.bfloat16))
+  dxs = layer.bwd_input_slice(ctx, dy, 36, 39)
+  torch.cuda.synchronize()
+  dot = lambda a, b: (a.double() * b.double()).sum().item()
+  lhs, rhs = dot(y.t, dy.t), dot(x.t[..., 36:39], dxs.t[..., :3])
+  scale = (dot(y.t, y.t) * dot(dy.t, dy.t)) ** 0.5
+  print('layer-0 slice: |<y,dy>-<x,dx>|/scale = %.2e' % (abs(lhs - rhs) / scale))
+  assert abs(lhs - rhs) <= 4e-6 * scale, (lhs, rhs, scale)
+
+
 # ---- config 3: LocalEnhancer ngf 32 at 1024x512, bf16 ---------------------------------------------------------------
 LAYERS_LOCAL = [
     ('local_first_7x7',    4, 512, 1024, 39, 32, 7, 1, 3, PAD_REFLECT),
