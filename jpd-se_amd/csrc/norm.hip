@@ -602,6 +602,10 @@ __global__ __launch_bounds__(256, (P == 8 ? 3 : 2)) void inorm_reg_bwd_kernel(co
 constexpr int kCountSlots = 1 << 16;
 struct SyncState { unsigned* dev = nullptr; int cursor = 0; };
 static unsigned* count_slots(hipStream_t s, int groups) {
+#ifndef JPDSE_DEV
+  (void)s; (void)groups;
+  return nullptr;            // the shipped library never allocates: the one-kernel form exists in the developer build only
+#else
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, SyncState> table;
   int dev = 0;
@@ -619,6 +623,7 @@ static unsigned* count_slots(hipStream_t s, int groups) {
   unsigned* p = st.dev + st.cursor;
   st.cursor += groups;
   return p;
+#endif
 }
 
 // blocks of `kernel` that are resident at once (the exchange must never wait for a block that cannot start)
@@ -634,6 +639,7 @@ template <typename K> static int resident_blocks(K kernel) {
 template <typename T, bool BWD> static int reg_pick(const jpdse_inorm_desc* d, bool one, FusedGeom* out) {
   constexpr int VE = Vec16<T>::N;
   static int cap8 = -1, cap16 = -1;
+#ifdef JPDSE_DEV
   if (one && cap8 < 0) {
     if (BWD) {
       cap8 = resident_blocks(inorm_reg_bwd_kernel<T, 8, 0>);
@@ -643,6 +649,7 @@ template <typename T, bool BWD> static int reg_pick(const jpdse_inorm_desc* d, b
       cap16 = resident_blocks(inorm_reg_fwd_kernel<T, 16, 0>);
     }
   }
+#endif
   // two-kernel form: 8 pixels per thread only -- with 16 (tensors of 17-34 MB) it measured equal or slower than the
   // three-kernel form (profiles/r02_norm_forms.txt)
   for (int P = 8; P <= (one ? 16 : 8); P *= 2) {
@@ -671,11 +678,13 @@ static int launch_reg_fwd(int form, const FusedGeom& fg, const jpdse_inorm_desc*
   const T* xp = reinterpret_cast<const T*>(x);
   const T* rp = reinterpret_cast<const T*>(res);
   T* yp = reinterpret_cast<T*>(y);
+#ifdef JPDSE_DEV
   if (form == 2) {
     hipLaunchKernelGGL((inorm_reg_fwd_kernel<T, P, 0>), grid, dim3(256), 0, s, xp, rp, yp, stats, part, count, d->act, d->slope,
                        d->eps, fg);
     return check_launch("inorm one-kernel fwd");
   }
+#endif
   hipLaunchKernelGGL((inorm_reg_fwd_kernel<T, P, 1>), grid, dim3(256), 0, s, xp, rp, yp, stats, part, count, d->act, d->slope,
                      d->eps, fg);
   if (int rc = check_launch("inorm rows fwd")) return rc;
@@ -691,11 +700,13 @@ static int launch_reg_bwd(int form, const FusedGeom& fg, const jpdse_inorm_desc*
   const T* xp = reinterpret_cast<const T*>(x);
   const T* gp = reinterpret_cast<const T*>(dy);
   T* dp = reinterpret_cast<T*>(dx);
+#ifdef JPDSE_DEV
   if (form == 2) {
     hipLaunchKernelGGL((inorm_reg_bwd_kernel<T, P, 0>), grid, dim3(256), 0, s, xp, gp, dp, stats, part, count, d->act, d->slope,
                        fg);
     return check_launch("inorm one-kernel bwd");
   }
+#endif
   hipLaunchKernelGGL((inorm_reg_bwd_kernel<T, P, 1>), grid, dim3(256), 0, s, xp, gp, dp, stats, part, count, d->act, d->slope, fg);
   if (int rc = check_launch("inorm rows bwd")) return rc;
   hipLaunchKernelGGL((inorm_reg_bwd_kernel<T, P, 2>), grid, dim3(256), 0, s, xp, gp, dp, stats, part, count, d->act, d->slope, fg);
