@@ -167,6 +167,44 @@ def test_1024x512_layer0_image_slice_gradient_is_the_adjoint_of_the_slice_bf16()
   assert abs(lhs - rhs) <= 4e-6 * scale, (lhs, rhs, scale)
 
 
+ROW_KERNEL_LAYERS = [
+    ('down 64->128 s2', 4, 512, 1024, 64,  128, 3, 2, 1, PAD_ZERO,    False),
+    ('vgg conv1_2',     4, 512, 1024, 64,  64,  3, 1, 1, PAD_ZERO,    False),
+    ('convT 128->64',   4, 256, 512,  128, 64,  3, 2, 1, PAD_ZERO,    True),
+    ('head 7x7',        4, 512, 1024, 64,  3,   7, 1, 3, PAD_REFLECT, False),
+    ('vgg conv1_1',     4, 512, 1024, 3,   64,  3, 1, 1, PAD_ZERO,    False),
+    ('D layer0',        8, 512, 1024, 39,  64,  4, 2, 2, PAD_ZERO,    False),
+]
+
+
+@pytest.mark.parametrize('case', ROW_KERNEL_LAYERS, ids=[c[0].replace(' ', '_') for c in ROW_KERNEL_LAYERS])
+def test_row_streaming_kernels_bit_reproducible_at_bench_size(case):
+  """Race check of the counted vmcnt / lgkmcnt pipelines and LDS rings of the row-streaming kernels: forward, data gradient and
+  weight gradient repeated at the bench size with the caches flushed in between must be bit-identical every time (a wait that
+  counts one operation too few shows up as a sporadic mismatch here; scripts/diag_rows_race.py is the long form)."""
+  name, N, H, W, C, K, k, st, pad, mode, tr = case
+  torch.manual_seed(5)
+  layer = HipConv2d(C, K, k, st, pad, mode, act=ACT_NONE, apply_bias=False, transposed=tr, dtype=BF16, device=DEV)
+  x = Act.empty(N, H, W, C, BF16, DEV)
+  x.t.zero_()
+  x.t[..., :C] = torch.randn((N, H, W, C), device=DEV).to(torch.bfloat16)
+  y0, ctx = layer.fwd(x)
+  dy = y0.empty_like()
+  dy.t.zero_()
+  dy.t[..., :y0.C] = torch.randn(dy.t[..., :y0.C].shape, device=DEV).to(torch.bfloat16)
+  dx0 = layer.bwd(ctx, dy, True, True).t.clone()
+  dw0 = layer.weight.grad.clone()
+  y0 = y0.t.clone()
+  for it in range(6):
+    junk = torch.full((64 << 20,), float('nan'), device=DEV)      # 256 MB: beyond the Infinity Cache
+    y, ctx = layer.fwd(x)
+    dx = layer.bwd(ctx, dy, True, True)
+    assert torch.equal(y.t, y0), '%s: forward differs in repetition %d' % (name, it)
+    assert torch.equal(dx.t, dx0), '%s: data gradient differs in repetition %d' % (name, it)
+    assert torch.equal(layer.weight.grad, dw0), '%s: weight gradient differs in repetition %d' % (name, it)
+    del junk
+
+
 # ---- config 3: LocalEnhancer ngf 32 at 1024x512, bf16 ---------------------------------------------------------------
 LAYERS_LOCAL = [
     ('local_first_7x7',    4, 512, 1024, 39, 32, 7, 1, 3, PAD_REFLECT),
