@@ -38,6 +38,7 @@ F_ALG_GFLOP = {('global', 1024, 512): 4592.5, ('local', 1024, 512): 2803.2,
                ('global', 512, 256): 1154.3, ('global', 256, 128): 291.7,
                ('global', 2048, 1024): 18322.1, ('local', 2048, 1024): 11164.5}
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}     # MI355X_MICROARCH.md, dense
+HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s measured on a copy)
 
 
 def parse():
@@ -54,6 +55,10 @@ def parse():
                   help='BASELINE config 2: GlobalGenerator + 2-scale PatchGAN step without the VGG loss '
                        '(no_vgg_loss + skip_unused_losses: VGG is not run at all)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-kernel-timers', action='store_true',
+                  help='A/B only: leave the in-library hipEvent timers off in the timed region (no roofline objects)')
+  ap.add_argument('--late-readback', action='store_true',
+                  help='A/B only: read the losses back after the optimizer steps, as round 2 did')
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                   help='collective backend for N > 1: nccl == RCCL over xGMI (the product path); gloo only to rehearse '
                        'the multi-rank schedule on a box with fewer GPUs than ranks (with --share-gpu)')
@@ -62,6 +67,9 @@ def parse():
   ap.add_argument('--bf16-reduce', action='store_true',
                   help='all-reduce the gradients in bf16 (half the xGMI bytes) instead of fp32; reported next to the fp32 '
                        'reduce (SURVEY.md 8d config 4)')
+  ap.add_argument('--ddp-overlap', default='d_backward', choices=['d_backward', 'layers'],
+                  help='N > 1: the generator gradient all-reduce overlaps the discriminator backward (default) or is fired '
+                       'layer by layer from the backward hooks (round 1-2 behaviour); same results')
   ap.add_argument('--master-port', type=int, default=0, help='self-launch only: rendezvous port (0 = pick a free one)')
   ap.add_argument('--debug-mode', type=int, default=None,
                   help='developer A/B runs: use libjpdse_hip_dev.so with this kernel-selection mode (include/jpdse_dev.h)')
@@ -72,52 +80,87 @@ def make_opt(args, device_index):
   from ctu.utils.synthetic import default_opt
   kw = dict(gpu_ids=[device_index], print_losses=False, compute_dtype=args.dtype, use_compressed=True,
             netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch,
-            bf16_grad_reduce=args.bf16_reduce)
+            bf16_grad_reduce=args.bf16_reduce, ddp_overlap=args.ddp_overlap)
   if args.no_vgg:
     kw.update(no_vgg_loss=True, skip_unused_losses=True)
   return default_opt(**kw)
 
 
-def cpu_baseline(args, budget_s=30.0):
-  """The oracle (a port: kind 'port') on this box's host cores, SURVEY.md 8(d): fp32, batch 1, all host cores, warm-up
-  then >= 3 timed steps at 512x256; when those are fast enough that three 1024x512 steps (4x the work) fit the budget
-  as well, one warm-up + 3 timed steps at the reported size, and that figure is the one quoted.  Bounded: about
-  `budget_s` seconds of CPU work."""
+def cpu_baseline(args, budget_s=60.0):
+  """The oracle (a port: kind 'port') on this box's host cores, SURVEY.md 8(d): fp32, batch 1.  A batch-1 conv graph does
+  not scale to every hardware thread of a large host (round 2 ran it on all 128 and got LESS than the survey's 8-core probe),
+  so the thread count is swept first -- one 512x256 step each at {8, 16, 32, 64, all} threads after a warm-up step -- and the
+  fastest is kept; with it, one 1024x512 step (the headline size) is timed when the projection fits the budget, else the
+  512x256 figure is quoted.  `sample` says which, and which thread count won.  Bounded: about `budget_s` seconds."""
   from oracle.ctu_cpu import model as omodel
-  cores = torch.get_num_threads()
+  ncpu = os.cpu_count() or torch.get_num_threads()
   opt = omodel.default_opt(netG=args.netG, ngf=64 if args.netG == 'global' else 32, use_compressed=True)
   torch.manual_seed(1234)
   ora = omodel.OracleTrainer(opt)
 
-  def timed(h, w, warm, steps, seed):
-    for i in range(warm):
-      ora.step(omodel.synthetic_batch(1, h, w, seed=seed + i))
-    ts = []
-    for i in range(steps):
-      xd = omodel.synthetic_batch(1, h, w, seed=seed + warm + i)
-      t0 = time.perf_counter()
-      ora.step(xd)
-      ts.append(time.perf_counter() - t0)
-    return ts
+  def one(h, w, seed):
+    xd = omodel.synthetic_batch(1, h, w, seed=seed)
+    t0 = time.perf_counter()
+    ora.step(xd)
+    return time.perf_counter() - t0
 
-  t0 = time.perf_counter()
-  small = timed(256, 512, 1, 3, 1)
-  spent = time.perf_counter() - t0
-  med = sorted(small)[1]
-  value, sample = 1.0 / med, '1 warm-up + 3 timed steps (median %.2f s), batch 1, 512x256, fp32 torch-CPU oracle' % med
-  if spent + 4 * 4.2 * med <= budget_s:       # warm-up + 3 steps at 4x the pixels
-    big = timed(512, 1024, 1, 3, 11)
-    med = sorted(big)[1]
-    value = 1.0 / med
-    sample = ('1 warm-up + 3 timed steps (median %.2f s), batch 1, 1024x512, fp32 torch-CPU oracle '
-              '(after 4 steps at 512x256)' % med)
-  return dict(value=round(value, 5), unit='images/sec', cores=cores, kind='port', sample=sample)
+  t_start = time.perf_counter()
+  saved = torch.get_num_threads()
+  cands = sorted({c for c in (8, 16, 32, 64, ncpu) if 0 < c <= ncpu})
+  torch.set_num_threads(cands[0])
+  one(256, 512, 1)                                    # warm-up (allocator, oneDNN primitive cache)
+  sweep = {}
+  for i, c in enumerate(cands):
+    if sweep and time.perf_counter() - t_start > 0.6 * budget_s:
+      break
+    torch.set_num_threads(c)
+    sweep[c] = one(256, 512, 2 + i)
+  best = min(sweep, key=sweep.get)
+  torch.set_num_threads(best)
+  sweep_txt = ', '.join('%d: %.2f s' % (c, t) for c, t in sorted(sweep.items()))
+  value = 1.0 / sweep[best]
+  sample = ('one step at 512x256 per thread count after a warm-up step {%s}; fastest: %d threads (%.2f s/step); batch 1, fp32 '
+            'torch-CPU oracle' % (sweep_txt, best, sweep[best]))
+  if (time.perf_counter() - t_start) + 4.3 * sweep[best] <= budget_s:
+    t_big = one(512, 1024, 11)
+    value = 1.0 / t_big
+    sample = ('one step at 1024x512 (%.2f s) on %d threads, the fastest of the sweep {%s} of one 512x256 step per thread '
+              'count; batch 1, fp32 torch-CPU oracle' % (t_big, best, sweep_txt))
+  torch.set_num_threads(saved)
+  return dict(value=round(value, 5), unit='images/sec', cores=best, kind='port', sample=sample)
 
 
-def self_launch(args):
+def visible_gpu_count():
+  """GPUs this process tree may use, WITHOUT a HIP / torch.cuda call in this (launcher) process: the GPU nodes of the KFD
+  topology (a node with simd_count > 0), cut down by the *_VISIBLE_DEVICES masks the children will inherit.  None when
+  neither source says anything (no readable topology, no mask): the ranks then find out for themselves."""
+  n = None
+  base = '/sys/class/kfd/kfd/topology/nodes'
+  try:
+    count = 0
+    for node in sorted(os.listdir(base)):
+      try:
+        with open(os.path.join(base, node, 'properties')) as fh:
+          props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+        if int(props.get('simd_count', '0')) > 0:
+          count += 1
+      except (OSError, ValueError):
+        continue
+    n = count
+  except OSError:
+    n = None
+  for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+    if var in os.environ:
+      ids = [t for t in os.environ[var].split(',') if t.strip() != '']
+      n = len(ids) if n is None else min(n, len(ids))
+  return n
+
+
+def self_launch(args, timeout_s=1500):
   """`python bench.py --gpus N` (N > 1) without a launcher: start `torch.distributed.run` with N ranks as a CHILD process
-  and relay its output.  Nothing in this process has touched the GPU at this point (argparse and `import torch` only;
-  `torch.cuda.device_count()` does not initialise HIP on this image), and it never execs."""
+  and relay its output.  This process never touches the GPU (argparse, `import torch`, sysfs only -- no torch.cuda call)
+  and never execs.  A child that hangs is killed with its process group after `timeout_s`."""
+  import signal
   import socket
   import subprocess
   port = args.master_port
@@ -125,8 +168,8 @@ def self_launch(args):
     with socket.socket() as sk:
       sk.bind(('127.0.0.1', 0))
       port = sk.getsockname()[1]
-  ndev = torch.cuda.device_count()
-  if ndev < args.gpus and not args.share_gpu:
+  ndev = visible_gpu_count()
+  if ndev is not None and ndev < args.gpus and not args.share_gpu:
     sys.stderr.write('bench.py: --gpus %d but %d GPU(s) visible (rehearse with --backend gloo --share-gpu)\n' % (args.gpus, ndev))
     return 2
   env = dict(os.environ)
@@ -134,8 +177,19 @@ def self_launch(args):
   env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-  proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-  sys.stdout.write(proc.stdout)
+  proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+  try:
+    out, _ = proc.communicate(timeout=timeout_s)
+  except subprocess.TimeoutExpired:
+    try:
+      os.killpg(proc.pid, signal.SIGKILL)      # the exact group this launcher started
+    except OSError:
+      pass
+    out, _ = proc.communicate()
+    sys.stdout.write(out or '')
+    sys.stderr.write('bench.py: the %d-rank child did not finish within %d s and was killed\n' % (args.gpus, timeout_s))
+    return 3
+  sys.stdout.write(out)
   sys.stdout.flush()
   return proc.returncode
 
@@ -196,7 +250,11 @@ def main():
     trainer.step(xd)
   # time the ResnetBlock 3x3 GEMM (forward and its data-gradient: same kernel, N=1024, K=9216)
   L = lib()
-  check(L.jpdse_prof_select(1, 1024, 9216, 96 * max(args.steps, 1)), 'prof_select')
+  if args.late_readback:
+    trainer.model.early_loss_readback = False
+  if not args.no_kernel_timers:
+    check(L.jpdse_prof_select(1, 1024, 9216, 96 * max(args.steps, 1)), 'prof_select')
+    check(L.jpdse_prof_hbm_select(1, 160 * max(args.steps, 1)), 'prof_hbm_select')   # ~72 norm calls + 2 Adams per step
   barrier()
   t0 = time.perf_counter()
   for _ in range(args.steps):
@@ -211,6 +269,12 @@ def main():
     extra[name] = (m2.value, f2.value, n2.value)
   check(L.jpdse_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), 'prof_collect')
   check(L.jpdse_prof_select(0, 0, 0, 0), 'prof_select off')
+  hbm = {}
+  for cls, name in ((0, 'inorm_fwd'), (1, 'inorm_bwd'), (2, 'adam')):
+    m2, b2, n2 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    check(L.jpdse_prof_hbm_collect(cls, ctypes.byref(m2), ctypes.byref(b2), ctypes.byref(n2)), 'prof_hbm_collect')
+    hbm[name] = (m2.value, b2.value, n2.value)
+  check(L.jpdse_prof_hbm_select(0, 0), 'prof_hbm_select off')
   if world > 1:
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -255,6 +319,30 @@ def main():
                                        wgrad=round(wg[0] / args.steps, 4)),
                       wgrad=dict(achieved=round(wg[1] / (wg[0] * 1e-3) / 1e12, 2), avg_launch_ms=round(wg[0] / wg[2], 4),
                                  launches_per_step=wg[2] / args.steps, frac=round(wg[1] / (wg[0] * 1e-3) / 1e12 / peak, 4)))
+    # third roofline entry, HBM-bound: the InstanceNorm + activation (+ residual) calls, forward and backward (north_star:
+    # "HBM GB/s on the norm/activation kernels against gfx950 peak"), and the fused Adam next to them
+    roof_hbm = None
+    nt = hbm['inorm_fwd'][0] + hbm['inorm_bwd'][0]
+    if nt > 0:
+      nb = hbm['inorm_fwd'][1] + hbm['inorm_bwd'][1]
+      gbs = lambda b, t: round(b / (t * 1e-3) / 1e9, 1) if t > 0 else None
+      roof_hbm = dict(bound='hbm', kernel='InstanceNorm + activation (+ residual): moment / finalize / apply and register-held kernels, '
+                                           'forward and backward (norm.hip)',
+                      achieved=gbs(nb, nt), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nb / (nt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      traffic=None, calls_per_step=(hbm['inorm_fwd'][2] + hbm['inorm_bwd'][2]) / args.steps,
+                      ms_per_step=round(nt / args.steps, 4), algorithmic_bytes_per_step=nb / args.steps,
+                      forward=dict(achieved=gbs(hbm['inorm_fwd'][1], hbm['inorm_fwd'][0]), ms_per_step=round(hbm['inorm_fwd'][0] / args.steps, 4)),
+                      backward=dict(achieved=gbs(hbm['inorm_bwd'][1], hbm['inorm_bwd'][0]), ms_per_step=round(hbm['inorm_bwd'][0] / args.steps, 4)),
+                      adam=dict(achieved=gbs(hbm['adam'][1], hbm['adam'][0]), ms_per_step=round(hbm['adam'][0] / args.steps, 4),
+                                frac=round(hbm['adam'][1] / (hbm['adam'][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hbm['adam'][0] > 0 else None))
+      tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+      if (os.path.exists(tpath) and (args.netG, args.width, args.height, args.batch, args.dtype) == ('global', 1024, 512, 4, 'bf16')):
+        with open(tpath) as fh:
+          tj = json.load(fh)
+        if 'norm_family_bytes_per_step' in tj:
+          roof_hbm['traffic'] = tj['norm_family_bytes_per_step']
+          roof_hbm['traffic_unit'] = 'bytes per step, all norm kernels (memory-side of L2, Infinity-Cache hits included)'
+          roof_hbm['traffic_source'] = tj['source']
     f_alg = F_ALG_GFLOP.get((args.netG, args.width, args.height))
     if args.no_vgg and f_alg:      # minus VGG's 3 passes (2 fwd + 1 dgrad), SURVEY.md 8d config 2
       f_alg = round(f_alg - 6 * 189.4 * (args.width * args.height) / (1024.0 * 512.0), 1)
@@ -274,6 +362,7 @@ def main():
                    'f_alg_gflop_per_image': f_alg},
         'roofline': roof,
         'roofline_resblock_all_passes': roof_all,
+        'roofline_hbm': roof_hbm,
     }
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args)

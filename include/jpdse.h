@@ -65,6 +65,19 @@ int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches)
  * cls 1 = the ring-strip GEMMs + fold of the reflect-padded data gradient (time only, their FLOPs belong to the data
  * gradient counted in class 0), cls 2 = the weight-gradient launches (K == Ks, 9 * CPAD(C) == kdim). */
 int jpdse_prof_collect_class(int32_t cls, double* total_ms, double* total_flops, int64_t* launches);
+/* The same for the HBM-bound calls (bench.py "roofline_hbm"; north_star: "HBM GB/s on the norm/activation kernels"): after
+ * jpdse_prof_hbm_select(1, max) every jpdse_inorm_fwd / jpdse_inorm_fwd_from_moments (class JPDSE_HBM_INORM_FWD),
+ * jpdse_inorm_bwd (JPDSE_HBM_INORM_BWD) and jpdse_adam_step (JPDSE_HBM_ADAM) call is bracketed by a hipEvent pair on its own
+ * stream (all kernels of the call: moments, finalize, apply) until `max` regions are used.  jpdse_prof_hbm_collect waits for
+ * the regions of one class and returns their summed time, their summed ALGORITHMIC bytes -- InstanceNorm forward 3 x the
+ * tensor (x read by the moment pass and by the apply pass, y written; + the residual when there is one; 2 x when the moments
+ * came from the conv epilogue), backward 5 x (x and dy read twice, dx written), Adam 28 B per parameter (+ 2 B when it also
+ * writes the bf16 forward panel) -- and their count.  jpdse_prof_hbm_select(0, 0) switches the timer off and clears the log. */
+#define JPDSE_HBM_INORM_FWD 0
+#define JPDSE_HBM_INORM_BWD 1
+#define JPDSE_HBM_ADAM 2
+int jpdse_prof_hbm_select(int32_t enable, int32_t max_regions);
+int jpdse_prof_hbm_collect(int32_t cls, double* total_ms, double* total_bytes, int64_t* regions);
 
 /* ---- convolution family ------------------------------------------------------------- */
 /* One descriptor covers nn.Conv2d as used by:
@@ -124,8 +137,9 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d);
 int jpdse_conv_fwd(const jpdse_conv_desc* d, const void* x, const void* fwd_pack,
                    const float* bias, void* y, void* ws, size_t ws_bytes, void* stream);
 /* Forward of a conv that feeds an affine-less InstanceNorm, with the norm's moment pass fused into the conv's epilogue
- * (networks.py:204,216,245: conv -> norm): also writes moments[n][c][slot] = (sum y, sum y^2) over the pixels of block `slot`
- * of image n, fp32 [N][CPAD(K)][slots][2] with slots = jpdse_conv_moment_slots(d) (0: this layer's kernel has no such
+ * (networks.py:204,216,245: conv -> norm): also writes moments[n][c][slot] = (mean, M2 = sum (y - mean)^2) of the STORED
+ * (rounded) values over the pixels of block `slot` of image n -- every slot covers H*W / slots pixels; taken about a per-block
+ * pilot value, so a channel with |mean| >> std keeps its variance --, fp32 [N][CPAD(K)][slots][2] with slots = jpdse_conv_moment_slots(d) (0: this layer's kernel has no such
  * epilogue -- use jpdse_conv_fwd + jpdse_inorm_fwd).  No bias (the norm cancels it), d->act must be JPDSE_ACT_NONE.
  * jpdse_inorm_fwd_from_moments then replaces jpdse_inorm_fwd's moment pass. */
 int32_t jpdse_conv_moment_slots(const jpdse_conv_desc* d);
@@ -180,7 +194,8 @@ size_t jpdse_inorm_workspace_size(const jpdse_inorm_desc* d);
 int jpdse_inorm_fwd(const jpdse_inorm_desc* d, const void* x, const void* residual, void* y,
                     float* stats, void* ws, size_t ws_bytes, void* stream);
 /* jpdse_inorm_fwd with the moment pass replaced by the per-block moments a conv epilogue wrote (jpdse_conv_fwd_moments):
- * a finalize over the `slots` blocks of each (image, channel), summed in a fixed order, then the apply pass. */
+ * a finalize over the `slots` blocks of each (image, channel) -- Chan's parallel-variance merge of the (mean, M2) slots in a
+ * fixed order --, then the apply pass. */
 int jpdse_inorm_fwd_from_moments(const jpdse_inorm_desc* d, const void* x, const float* moments, int32_t slots,
                                  const void* residual, void* y, float* stats, void* stream);
 /* dx from (x, stats, dy); the residual branch's gradient is dy itself */

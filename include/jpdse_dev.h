@@ -1,7 +1,7 @@
 /*
- * jpdse_dev.h -- the ONE extra entry point of the developer build libjpdse_hip_dev.so (compiled with -DJPDSE_DEV from
+ * jpdse_dev.h -- the extra entry points of the developer build libjpdse_hip_dev.so (compiled with -DJPDSE_DEV from
  * the same sources as libjpdse_hip.so).  Not part of the drop-in boundary: the shipped library neither exports this
- * symbol nor contains the run-time switches behind it (they are compile-time constants there) nor the timing-only
+ * symbols nor contains the run-time switches behind them (they are compile-time constants there) nor the timing-only
  * ablation kernels.  Used by scripts/ (same-process A/B measurements) and by the tests that compare two kernels of one
  * layer with each other; no reference counterpart.
  */
@@ -22,8 +22,21 @@ extern "C" {
  * domain; 8 = halo kernel always double buffered; 9 / 10 = long-K-only phase merging / no 128-row
  * tiles; 12 = no all-taps weight gradient; 13 = no tap-sum forward; 14 = no head kernel;
  * 15 / 16 = XCD-aware halo tile orders; 18 = no thin-input forward kernel; 19 = halo kernel on
- * 16x16x32 MFMA fragments.  Each call resets the others to their defaults. */
+ * 16x16x32 MFMA fragments; 21 / 22 / 24 = unpipelined loop forms of the nine-tap weight gradient (default:
+ * software-pipelined fragment reads); 23 = halo kernel with waves 4..7 issuing their DMA group after the MFMA
+ * cluster; 25 = halo kernel with software-pipelined fragment reads; 26 = merged stride-phase data gradient only
+ * from 384 tiles on; 27 = InstanceNorm always as three kernels; 28 = InstanceNorm as one kernel with the
+ * in-launch exchange; 29 = the 64-channel / thin-input layers on the halo / fast kernels instead of the
+ * row-streaming family; 30 = fast kernel with the XCD-aware tile order; 31 = reflect ring strips on 128-row
+ * tiles; 32 = no InstanceNorm moments in conv epilogues.  100 + bits = timing-only ablations of the halo loop.
+ * Each call resets the others to their defaults. */
 int jpdse_debug_set_fast_path(int32_t enable);
+
+/* CU occupier for the one-GPU rehearsal of "compute kernels share the chip with a collective" (scripts/cu_contention.py,
+ * profiles/r03_cu_contention.txt): launches `blocks` (1..128) workgroups on `stream`, each holding a whole CU's 160 KiB of LDS,
+ * that sleep until *release_flag (host-visible memory, e.g. pinned) becomes non-zero or max_ms (<= 20000) of wall clock have
+ * passed -- every wave exits by itself, the grid always drains.  No reference counterpart. */
+int jpdse_debug_occupy_cus(int32_t blocks, const int32_t* release_flag, int32_t max_ms, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,10 @@ int check_launch(const char* what);
   } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// opt-in timer of the HBM-bound calls (api.cpp; jpdse_prof_hbm_select / _collect): begin returns a slot or -1 (off / full)
+int hbm_prof_begin(hipStream_t s);
+void hbm_prof_end(int slot, int cls, double algorithmic_bytes, hipStream_t s);   // cls: JPDSE_HBM_INORM_FWD / _BWD / _ADAM
 static inline int cpad(int c) { return (c + 7) & ~7; }
 static inline size_t esize(int dtype) { return dtype == JPDSE_BF16 ? 2 : 4; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -115,6 +119,27 @@ template <> struct Vec16<bf16_t> {
     *reinterpret_cast<u32x4*>(p) = t;
   }
 };
+
+// ---- InstanceNorm moments written by conv epilogues (conv_rows.h, dgrad2_rows.h, thin_fwd.h -> norm.hip) ----------------
+// Every block writes, per (image, channel), ONE slot = (mean, M2) of the values it produced -- of the bf16-ROUNDED values,
+// the ones that are stored and that the norm's backward re-reads -- with M2 = sum (v - mean)^2.  Each lane sums about its own
+// pilot (its first value; no cross-lane operation inside the hand-scheduled loops), lanes that share a channel are merged
+// pairwise with Chan's formula after the loop, so neither the sums nor the merge of the slots
+// (finalize_slots_kernel: Chan's parallel-variance formula, all slots cover the same number of pixels) ever forms
+// E[v^2] - mean^2 of un-shifted values: a channel with |mean| >> std keeps its variance.
+__device__ __forceinline__ float bf16_round(float v) { return bf2f(f2bf(v)); }
+// Chan's merge of two (mean, M2) pairs that cover `n_each` values each: (mean, m2) <- merged over 2 n_each values
+__device__ __forceinline__ void chan_merge_equal(float& mean, float& m2, float mean_o, float m2_o, float n_each) {
+  const float d = mean_o - mean;
+  m2 = m2 + m2_o + d * d * (0.5f * n_each);
+  mean = mean + 0.5f * d;
+}
+// (sum, sum of squares) about `pilot` over `count` values -> (mean, M2)
+__device__ __forceinline__ void shifted_to_mean_m2(float s1, float s2, float pilot, float count, float& mean, float& m2) {
+  const float d = s1 / count;
+  mean = pilot + d;
+  m2 = fmaxf(s2 - s1 * d, 0.f);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

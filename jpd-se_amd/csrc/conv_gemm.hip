@@ -2946,6 +2946,37 @@ int jpdse_conv_out_shape(const jpdse_conv_desc* d, int32_t* OH, int32_t* OW) {
 }
 
 #ifdef JPDSE_DEV
+// CU occupier (developer build only; scripts/cu_contention.py): `blocks` workgroups that each hold a whole CU's LDS (no
+// LDS-using workgroup can share the CU) and sleep until *release != 0 or `max_ms` of wall clock have passed -- a stand-in for
+// the compute units a concurrent RCCL collective holds.  Every wave reaches its exit: the poll is bounded by s_memrealtime
+// (100 MHz), so the grid drains even if the host never sets the flag.
+__global__ __launch_bounds__(256) void occupy_cus_kernel(const int* __restrict__ release, unsigned long long max_ticks) {
+  extern __shared__ __attribute__((aligned(16))) char occ_smem[];
+  if (threadIdx.x == 0) reinterpret_cast<volatile int*>(occ_smem)[0] = (int)blockIdx.x;   // the allocation is live
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (true) {
+    const int r = __hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (r != 0) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;
+    __builtin_amdgcn_s_sleep(127);
+  }
+}
+
+int jpdse_debug_occupy_cus(int32_t blocks, const int32_t* release_flag, int32_t max_ms, void* stream) {
+  JPDSE_REQUIRE(blocks > 0 && blocks <= 128 && release_flag != nullptr && max_ms > 0 && max_ms <= 20000,
+                "debug_occupy_cus: blocks in 1..128, a flag, max_ms in 1..20000");
+  constexpr int lds = 160 * 1024;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "occupy_cus: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(occupy_cus_kernel, dim3(blocks), dim3(256), lds, as_stream(stream), release_flag,
+                     (unsigned long long)max_ms * 100000ULL);
+  return check_launch("occupy_cus_kernel");
+}
+
 int jpdse_debug_set_fast_path(int32_t enable) {
   // 0: generic kernels only; 1: fast kernels (default schedule 0); 2: fast kernels, alternative schedule 1
   g_fast_enabled = enable != 0;

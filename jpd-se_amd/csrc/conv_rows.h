@@ -72,7 +72,7 @@ struct RowsArgs {
   const bf16_t* addend;  // optional: Y = result + addend, before the mask
   int TH, bands, strips;
   int n_tiles;           // Ks / (32 * WC) column tiles (blockIdx fastest but one)
-  float* mom;            // optional: per-block sums of y and y^2 per channel for the InstanceNorm that follows,
+  float* mom;            // optional: per-block (mean, M2) of y per channel (common.h) for the InstanceNorm that follows,
   int mom_slots;         //   [N][Ks][mom_slots][2], slot = (band * strips + strip) * WP + wp (bias NULL, no activation)
 };
 
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && WC == 2) ? 2 : 1)) void conv_
 #pragma unroll
   for (int t = 0; t < 36; ++t) asm volatile("" : "+v"(breg[t]));
 
-  float ms1 = 0.f, ms2 = 0.f;                                 // moments of this lane's column over the block's rows
+  float ms1 = 0.f, ms2 = 0.f, mpilot = 0.f;                   // moments of this lane's column over the block's rows, about a pilot (common.h)
   int base = 0;                                               // ring slot of input row STRIDE * i
   int nslot = PRO % G::NR;                                    // ring slot of the next row to issue
   int njr = PRO;
@@ -285,11 +285,12 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && WC == 2) ? 2 : 1)) void conv_
     base += STRIDE;
     base = base >= G::NR ? base - G::NR : base;
     if (a.mom != nullptr) {
+      if (i == 0) mpilot = bf16_round(acc[0][0][0]);          // this lane's own pilot (no cross-lane traffic in this loop)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float v = acc[mt][0][e];
+          const float v = bf16_round(acc[mt][0][e]) - mpilot;
           ms1 += v;
           ms2 += v * v;
         }
@@ -314,14 +315,19 @@ __global__ __launch_bounds__(256, ((STRIDE == 1 && WC == 2) ? 2 : 1)) void conv_
     }
   }
   if (a.mom != nullptr) {
-    ms1 += __shfl_xor(ms1, 32, 64);                           // lanes l and l + 32 hold the same column (other pixel rows)
-    ms2 += __shfl_xor(ms2, 32, 64);
+    // lanes l and l + 32 hold the same column (the other half of the pixel rows): each turns its sums into (mean, M2) over
+    // its TH * MW / 2 values, then the pair is merged
+    const float half = 0.5f * (float)(a.TH * MW);
+    float mean, m2;
+    shifted_to_mean_m2(ms1, ms2, mpilot, half, mean, m2);
+    const float mean_o = __shfl_xor(mean, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
+    chan_merge_equal(mean, m2, mean_o, m2_o, half);
     const int col = ncol0 + lane;
     if (lane < 32 && col < a.Ks) {
       const int slot = (band * a.strips + strip) * WP + wp;
       float* const o = a.mom + (((long long)n * a.Ks + col) * a.mom_slots + slot) * 2;
-      o[0] = ms1;
-      o[1] = ms2;
+      o[0] = mean;
+      o[1] = m2;
     }
   }
 }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
   const int odd = lane & 1;
   const long long img_out = (long long)n * (2 * a.OH) * (2 * a.OW) * 64;
 
-  float ms1 = 0.f, ms2 = 0.f;
+  float ms1 = 0.f, ms2 = 0.f, mpilot = 0.f;             // moments about a pilot (common.h)
   int base = 0;                                         // ring slot of dy row a0 + i
   int nslot = (G::LA + 1) % G::NR, njr = G::LA + 1;
   for (int i = 0; i < a.TH; ++i) {
@@ -191,13 +191,14 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
     }
     base = base + 1 == G::NR ? 0 : base + 1;
     if (a.mom != nullptr) {
+      if (i == 0) mpilot = bf16_round(acc[0][0][0]);      // this lane's own pilot (no cross-lane traffic in this loop)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float v = acc[mt][ph][e];
+            const float v = bf16_round(acc[mt][ph][e]) - mpilot;
             ms1 += v;
             ms2 += v * v;
           }
@@ -237,13 +238,20 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
     }
   }
   if (a.mom != nullptr) {
-    ms1 += __shfl_xor(ms1, 16, 64); ms2 += __shfl_xor(ms2, 16, 64);   // the four lane groups hold the same column
-    ms1 += __shfl_xor(ms1, 32, 64); ms2 += __shfl_xor(ms2, 32, 64);
+    // the four lane groups hold the same column (a quarter of the values each): (mean, M2) per lane, then two pairwise merges
+    const float quarter = 64.f * (float)a.TH;             // TH dy rows x 64 columns x 4 phases / 4 lane groups
+    float mean, m2;
+    shifted_to_mean_m2(ms1, ms2, mpilot, quarter, mean, m2);
+    float mean_o = __shfl_xor(mean, 16, 64), m2_o = __shfl_xor(m2, 16, 64);
+    chan_merge_equal(mean, m2, mean_o, m2_o, quarter);
+    mean_o = __shfl_xor(mean, 32, 64);
+    m2_o = __shfl_xor(m2, 32, 64);
+    chan_merge_equal(mean, m2, mean_o, m2_o, 2.f * quarter);
     if (lane < 16) {
       const int col = wid * 16 + lane, slot = band * a.strips + strip;
       float* const o = a.mom + (((long long)n * 64 + col) * a.mom_slots + slot) * 2;
-      o[0] = ms1;
-      o[1] = ms2;
+      o[0] = mean;
+      o[1] = m2;
     }
   }
 }

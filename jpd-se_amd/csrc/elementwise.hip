@@ -893,8 +893,12 @@ int jpdse_adam_step(const jpdse_adam_entry* table, int32_t n_entries, int64_t to
   JPDSE_REQUIRE(table && n_entries > 0 && total_blocks > 0 && step >= 1, "adam_step: bad argument");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int pslot = hbm_prof_begin(as_stream(stream));
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), table, n_entries,
                      (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+  // algorithmic bytes: p, m, v read and written, g read = 28 B per parameter (blocks of 1024 parameters; the optional bf16
+  // panel copy adds 2 B per parameter of the layers that have one and is not counted)
+  hbm_prof_end(pslot, JPDSE_HBM_ADAM, 28.0 * 1024.0 * (double)total_blocks, as_stream(stream));
   return check_launch("adam_step");
 }
 

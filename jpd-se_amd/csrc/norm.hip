@@ -824,33 +824,38 @@ static int inorm_bwd_t(const jpdse_inorm_desc* d, const void* x, const float* st
 }
 
 
-// Forward statistics from per-block moments written by a conv epilogue: moments[n][c][slot] = (sum y, sum y^2) over the
-// block's pixels.  One wave per (n, c): lane l adds slots l, l + 64, ... in order, then the fixed xor tree -- deterministic.
+// Forward statistics from per-block moments written by a conv epilogue: moments[n][c][slot] = (mean, M2) of the block's
+// (bf16-rounded) values, every slot over the same number of pixels HW / slots (common.h).  One wave per (n, c) merges them with
+// Chan's parallel-variance formula in two passes over the slots (they are L2 hits): mean = average of the slot means, then
+// M2 = sum_slots [M2_s + n_s (mean_s - mean)^2] -- no E[y^2] - mean^2 of un-shifted sums anywhere (the stand-alone moment
+// kernels above shift by x[n,0,c] for the same reason).  Lane l takes slots l, l + 64, ... in order, then the fixed xor tree:
+// deterministic.
 __global__ __launch_bounds__(256) void finalize_slots_kernel(const float* __restrict__ mom, float* __restrict__ stats, int NC,
                                                             int slots, int HW, float eps) {
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (pair >= NC) return;
   const float2* const src = reinterpret_cast<const float2*>(mom) + (long long)pair * slots;
-  float a = 0.f, b = 0.f;
+  float a = 0.f;
   int s = lane;
   for (; s + 192 < slots; s += 256) {
     const float2 v0 = src[s], v1 = src[s + 64], v2 = src[s + 128], v3 = src[s + 192];
-    a += v0.x; b += v0.y;
-    a += v1.x; b += v1.y;
-    a += v2.x; b += v2.y;
-    a += v3.x; b += v3.y;
+    a += v0.x;
+    a += v1.x;
+    a += v2.x;
+    a += v3.x;
   }
-  for (; s < slots; s += 64) {
+  for (; s < slots; s += 64) a += src[s].x;
+  const float mean = wave_sum(a) / (float)slots;
+  const float ns = (float)HW / (float)slots;
+  float b = 0.f;
+  for (s = lane; s < slots; s += 64) {
     const float2 v = src[s];
-    a += v.x;
-    b += v.y;
+    const float dm = v.x - mean;
+    b += v.y + ns * dm * dm;
   }
-  a = wave_sum(a);
   b = wave_sum(b);
   if (lane == 0) {
-    const float inv = 1.f / (float)HW;
-    const float mean = a * inv;
-    float var = b * inv - mean * mean;
+    float var = b / (float)HW;
     var = var > 0.f ? var : 0.f;
     stats[2 * pair] = mean;
     stats[2 * pair + 1] = rsqrtf(var + eps);
@@ -877,6 +882,11 @@ static int inorm_from_moments_t(const jpdse_inorm_desc* d, const void* x, const 
 
 using namespace jpdse;
 
+// bytes of one [N][H][W][CPAD(C)] tensor of the descriptor's dtype (the unit of the algorithmic byte counts of jpdse_prof_hbm_*)
+static double tensor_bytes(const jpdse_inorm_desc* d) {
+  return (double)d->N * d->H * d->W * cpad(d->C) * (double)esize(d->dtype);
+}
+
 extern "C" {
 
 size_t jpdse_inorm_workspace_size(const jpdse_inorm_desc* d) {
@@ -892,8 +902,11 @@ int jpdse_inorm_fwd(const jpdse_inorm_desc* d, const void* x, const void* residu
   if (ws == nullptr || ws_bytes < ws_bytes_for(d))
     return set_error(JPDSE_EWORKSPACE, "inorm_fwd: workspace %zu < %zu", ws_bytes, ws_bytes_for(d));
   const void* res = d->has_residual ? residual : nullptr;
-  return d->dtype == JPDSE_BF16 ? inorm_fwd_t<bf16_t>(d, x, res, y, stats, ws, as_stream(stream))
-                                : inorm_fwd_t<float>(d, x, res, y, stats, ws, as_stream(stream));
+  const int pslot = hbm_prof_begin(as_stream(stream));
+  const int rc = d->dtype == JPDSE_BF16 ? inorm_fwd_t<bf16_t>(d, x, res, y, stats, ws, as_stream(stream))
+                                        : inorm_fwd_t<float>(d, x, res, y, stats, ws, as_stream(stream));
+  hbm_prof_end(pslot, JPDSE_HBM_INORM_FWD, tensor_bytes(d) * (d->has_residual ? 4.0 : 3.0), as_stream(stream));
+  return rc;
 }
 
 int jpdse_inorm_bwd(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy, void* dx, void* ws,
@@ -902,8 +915,11 @@ int jpdse_inorm_bwd(const jpdse_inorm_desc* d, const void* x, const float* stats
   JPDSE_REQUIRE(x && stats && dy && dx, "inorm_bwd: null pointer");
   if (ws == nullptr || ws_bytes < ws_bytes_for(d))
     return set_error(JPDSE_EWORKSPACE, "inorm_bwd: workspace %zu < %zu", ws_bytes, ws_bytes_for(d));
-  return d->dtype == JPDSE_BF16 ? inorm_bwd_t<bf16_t>(d, x, stats, dy, dx, ws, as_stream(stream))
-                                : inorm_bwd_t<float>(d, x, stats, dy, dx, ws, as_stream(stream));
+  const int pslot = hbm_prof_begin(as_stream(stream));
+  const int rc = d->dtype == JPDSE_BF16 ? inorm_bwd_t<bf16_t>(d, x, stats, dy, dx, ws, as_stream(stream))
+                                        : inorm_bwd_t<float>(d, x, stats, dy, dx, ws, as_stream(stream));
+  hbm_prof_end(pslot, JPDSE_HBM_INORM_BWD, tensor_bytes(d) * 5.0, as_stream(stream));
+  return rc;
 }
 
 int jpdse_inorm_fwd_from_moments(const jpdse_inorm_desc* d, const void* x, const float* moments, int32_t slots,
@@ -912,8 +928,11 @@ int jpdse_inorm_fwd_from_moments(const jpdse_inorm_desc* d, const void* x, const
   JPDSE_REQUIRE(x && y && stats && moments && slots > 0, "inorm_fwd_from_moments: null pointer / no slots");
   JPDSE_REQUIRE(!d->has_residual || residual, "inorm_fwd_from_moments: has_residual set but residual is null");
   const void* res = d->has_residual ? residual : nullptr;
-  return d->dtype == JPDSE_BF16 ? inorm_from_moments_t<bf16_t>(d, x, moments, slots, res, y, stats, as_stream(stream))
-                                : inorm_from_moments_t<float>(d, x, moments, slots, res, y, stats, as_stream(stream));
+  const int pslot = hbm_prof_begin(as_stream(stream));
+  const int rc = d->dtype == JPDSE_BF16 ? inorm_from_moments_t<bf16_t>(d, x, moments, slots, res, y, stats, as_stream(stream))
+                                        : inorm_from_moments_t<float>(d, x, moments, slots, res, y, stats, as_stream(stream));
+  hbm_prof_end(pslot, JPDSE_HBM_INORM_FWD, tensor_bytes(d) * (d->has_residual ? 3.0 : 2.0), as_stream(stream));
+  return rc;
 }
 
 }  // extern "C"

@@ -110,37 +110,50 @@ __global__ __launch_bounds__(512) void thin_fwd_kernel(const ThinFwdArgs a) {
     __builtin_amdgcn_s_setprio(0);
   }
 
-  // ---- optional moments: per lane over its column's pixels, lane halves, then the TH row-waves of a column group through LDS
+  // ---- optional moments (common.h: (mean, M2) of the bf16-rounded values about a pilot): per lane over its column's pixels,
+  // lane halves, then the TH row-waves of a column group merged through LDS with Chan's formula (equal counts, fixed order)
   if (a.mom != nullptr) {
     __syncthreads();                                   // the strips are dead
     float* const red = reinterpret_cast<float*>(smem);  // [TH][WN * TN * 32][2]
     constexpr int BNC = WN * TN * 32;
+    constexpr float kWaveCount = (float)(MI * 32);     // pixels per (row-wave, column)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+      const float pilot = bf16_round(acc[0][j][0]);      // this lane's own pilot
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float v = acc[i][j][e];
+          const float v = bf16_round(acc[i][j][e]) - pilot;
           s1 += v;
           s2 += v * v;
         }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
+      float mean, m2;                                    // lanes l and l + 32 share a column: half of its pixels each
+      shifted_to_mean_m2(s1, s2, pilot, 0.5f * kWaveCount, mean, m2);
+      const float mean_o = __shfl_xor(mean, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
+      chan_merge_equal(mean, m2, mean_o, m2_o, 0.5f * kWaveCount);
       if (lane < 32) {
         const int col = wcol * TN * 32 + j * 32 + lane;
-        red[(wrow * BNC + col) * 2] = s1;
-        red[(wrow * BNC + col) * 2 + 1] = s2;
+        red[(wrow * BNC + col) * 2] = mean;
+        red[(wrow * BNC + col) * 2 + 1] = m2;
       }
     }
     __syncthreads();
-    if (tid < BNC * 2) {
-      float t = 0.f;
-      for (int r = 0; r < TH; ++r) t += red[r * BNC * 2 + tid];
-      const int col = tid >> 1;
-      if (col < a.Ks)
-        a.mom[(((long long)n * a.Ks + col) * a.mom_slots + (th * a.tiles_w + tw)) * 2 + (tid & 1)] = t;
+    if (tid < BNC) {
+      float msum = 0.f;
+      for (int r = 0; r < TH; ++r) msum += red[(r * BNC + tid) * 2];
+      const float mean = msum * (1.f / TH);
+      float m2 = 0.f;
+      for (int r = 0; r < TH; ++r) {
+        const float dm = red[(r * BNC + tid) * 2] - mean;
+        m2 += red[(r * BNC + tid) * 2 + 1] + kWaveCount * dm * dm;
+      }
+      if (tid < a.Ks) {
+        float* const o = a.mom + (((long long)n * a.Ks + tid) * a.mom_slots + (th * a.tiles_w + tw)) * 2;
+        o[0] = mean;
+        o[1] = m2;
+      }
     }
   }
   // ---- epilogue: wave w = output row oh0 + w; bias + activation, 16-byte stores through LDS -----------------------

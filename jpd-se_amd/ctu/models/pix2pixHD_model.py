@@ -112,6 +112,10 @@ class Pix2PixHDModel(BaseModel):
     a('--checkpoint_resblocks', action='store_true',
       help='activation checkpointing of the ResnetBlocks (keep the block input, recompute in backward): the memory saver of '
            'BASELINE config 5; not needed on a 288 GB part, bit-identical results either way')
+    a('--ddp_overlap', type=str, default='d_backward', choices=['d_backward', 'layers'],
+      help='extension (data parallelism): where the generator gradient all-reduce runs -- behind the discriminator backward '
+           '(default; keeps RCCL off the chip while the one-workgroup-per-CU ResnetBlock GEMMs run) or layer by layer from '
+           'the backward hooks')
     a('--vgg_random_init', action='store_true',
       help='extension: explicitly accept a seeded random-weight VGG19 for the VGG loss (tests, benchmarks); without '
            'this flag training with the VGG loss and no --vgg19_state_dict is refused')
@@ -458,27 +462,59 @@ class Pix2PixHDModel(BaseModel):
     return True
 
   def train_step(self, x_dict, optimizer_G, optimizer_D, lambda_distortion_weight=1.0):
-    """One optimisation step with the reference's order (pix2pixHD_trainer.py:44-78): forward,
-    loss_G backward + Adam(G), loss_D backward + Adam(D).  One host sync (the loss readback)."""
+    """One optimisation step, results as the reference's (pix2pixHD_trainer.py:44-78: forward, loss_G backward + Adam(G),
+    loss_D backward + Adam(D)) -- executed as forward, loss_G backward, loss_D backward, Adam(G), Adam(D): loss_D does not
+    depend on G's weights, see below.  One host wait: for the loss copy queued after the forward pass."""
     opt = self.opt
     w_gan = 0.0 if opt.no_g_gan_loss else 1.0
     w_feat = 0.0 if opt.no_gan_feat_loss else opt.lambda_feat
     w_vgg = 0.0 if opt.no_vgg_loss else opt.lambda_feat
     w_dist = 0.0 if opt.no_distortion_loss else opt.lambda_distortion * lambda_distortion_weight
     state, slots, layout = self._forward_losses(x_dict, grad_w=dict(feat=w_feat, vgg=w_vgg, dist=w_dist))
-    bg = self.grad_buckets.get('G')
-    if self.backward_G(state, w_gan, w_feat, w_vgg, w_dist):
+    # All six losses are functions of the forward pass alone (the reference's .item() calls come after the optimizer
+    # steps, pix2pixHD_trainer.py:80-85, but read values computed before them), so their device->host copy is queued HERE,
+    # behind the loss kernels, and the host waits for THAT copy at the end of the step -- not for the backward passes and
+    # Adam updates it has meanwhile enqueued.  step() still returns this step's losses; the host just no longer idles the
+    # GPU for a launch round trip between two steps (0.3 ms per step in profiles/r02_step_breakdown.txt).
+    early = getattr(self, 'early_loss_readback', True)      # False: copy after the optimizer steps (A/B measurements only)
+    if early:
+      loss_host, loss_ready = self._queue_loss_readback(slots)
+    # Order: both backward passes first, then the two Adams.  The reference steps G before it back-propagates loss_D
+    # (pix2pixHD_trainer.py:64-78), but loss_D's graph -- D on fake.detach() and on the real image -- does not contain G's
+    # weights, so its gradients are the same numbers either way, bit for bit.  Under data parallelism this gives G's
+    # gradient all-reduce (93 % of the bytes) the whole D backward to hide behind (launch_all below), instead of the
+    # ResnetBlock GEMMs whose grids are exactly one workgroup per CU and take a second round when RCCL holds any CU.
+    bg, bd = self.grad_buckets.get('G'), self.grad_buckets.get('D')
+    did_G = self.backward_G(state, w_gan, w_feat, w_vgg, w_dist)
+    if did_G and bg is not None:
+      bg.launch_all()                  # no-op for buckets already started from the per-layer hooks (defer=False)
+    did_D = self.backward_D(state, 0.0 if opt.no_d_gan_loss else 0.5)
+    if did_G:
       if bg is not None:
         bg.finish()
       optimizer_G.step()
       self._repack('G')
-    bd = self.grad_buckets.get('D')
-    if self.backward_D(state, 0.0 if opt.no_d_gan_loss else 0.5):
+    if did_D:
       if bd is not None:
         bd.finish()
       optimizer_D.step()
       self._repack('D')
-    return self._reduce_losses(slots.cpu().tolist(), layout)
+    if not early:
+      loss_host, loss_ready = self._queue_loss_readback(slots)
+    loss_ready.synchronize()
+    return self._reduce_losses(loss_host.tolist(), layout)
+
+  def _queue_loss_readback(self, slots):
+    """Asynchronous copy of the loss slots into pinned host memory on the current stream; returns (host view, event)."""
+    n = slots.numel()
+    buf = getattr(self, '_loss_pinned', None)
+    if buf is None or buf.numel() < n:
+      buf = self._loss_pinned = torch.empty(max(n, 64), dtype=torch.float32).pin_memory()
+    host = buf[:n]
+    host.copy_(slots, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(slots.device))
+    return host, ev
 
   # ------------------------------------------------------------------------------------------
   def save(self):

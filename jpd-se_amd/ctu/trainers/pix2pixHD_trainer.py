@@ -36,7 +36,7 @@ class Pix2PixHDTrainer(BaseTrainer):
         self.enable_data_parallel(reduce_dtype=torch.bfloat16 if getattr(opt, 'bf16_grad_reduce', False) else None)
 
   # ---- data parallelism (no reference counterpart: base_parser.py:234-237 refuses >1 GPU) ----
-  def enable_data_parallel(self, bucket_bytes=64 << 20, process_group=None, reduce_dtype=None):
+  def enable_data_parallel(self, bucket_bytes=64 << 20, process_group=None, reduce_dtype=None, overlap=None):
     """Replicate-and-average: broadcast rank 0's weights once, re-home every gradient into flat all-reduce buckets, and
     let Adam divide by the world size.  Runs for any initialised process group, world size 1 included (the RCCL
     calls are then no-ops in value, which is how the path is exercised on a one-GPU box).  reduce_dtype
@@ -49,7 +49,13 @@ class Pix2PixHDTrainer(BaseTrainer):
         assert dense.is_contiguous()
         dist.broadcast(dense, src=0, group=process_group)
     bump_weights_epoch()
-    self._dp = dict(bucket_bytes=bucket_bytes, process_group=process_group, reduce_dtype=reduce_dtype, world=world)
+    # overlap: where the generator's gradient all-reduce runs.  'd_backward' (default): all of G's buckets start when G's
+    # backward has finished and overlap the discriminator's backward; 'layers': each bucket starts from the backward hook
+    # of its last layer and overlaps the rest of G's backward (round 1-2 behaviour).  Same results either way.
+    overlap = overlap or getattr(self.opt, 'ddp_overlap', 'd_backward')
+    assert overlap in ('d_backward', 'layers'), overlap
+    self._dp = dict(bucket_bytes=bucket_bytes, process_group=process_group, reduce_dtype=reduce_dtype, world=world,
+                    overlap=overlap)
     self._rebuild_buckets('G', self.model.netG, self.optimizer_G)
     self._rebuild_buckets('D', self.model.netD, self.optimizer_D)
 
@@ -60,7 +66,8 @@ class Pix2PixHDTrainer(BaseTrainer):
     trained = {id(p) for grp in optim.param_groups for p in grp['params']}
     named = [(n, p) for n, p in net.named_parameters() if id(p) in trained]
     buckets = GradBuckets(named, bucket_bytes=dp['bucket_bytes'], process_group=dp['process_group'],
-                          reduce_dtype=dp['reduce_dtype'], always_reduce=True)
+                          reduce_dtype=dp['reduce_dtype'], always_reduce=True,
+                          defer=(tag == 'G' and dp.get('overlap', 'd_backward') == 'd_backward'))
     self.model.grad_buckets[tag] = buckets
     optim.grad_scale = 1.0 / dp['world']
     for m in net.modules():

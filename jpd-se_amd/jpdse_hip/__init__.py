@@ -57,6 +57,8 @@ SIGNATURES = {
     'jpdse_prof_select': (_I32, [_I32, _I32, _I64, _I32]),
     'jpdse_prof_collect': (_I32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64)]),
     'jpdse_prof_collect_class': (_I32, [_I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64)]),
+    'jpdse_prof_hbm_select': (_I32, [_I32, _I32]),
+    'jpdse_prof_hbm_collect': (_I32, [_I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64)]),
     'jpdse_conv_out_shape': (_I32, [_CD, ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
     'jpdse_conv_plan_query': (_I32, [_CD, ctypes.POINTER(_I32), _I32]),
     'jpdse_conv_fwd_pack_size': (_SZ, [_CD]),
@@ -113,10 +115,17 @@ SIGNATURES = {
 
 # the developer build (same sources, -DJPDSE_DEV): the shipped ABI plus include/jpdse_dev.h
 DEV_LIB_PATH = os.path.join(_HERE, 'libjpdse_hip_dev.so')
-DEV_SIGNATURES = {'jpdse_debug_set_fast_path': (_I32, [_I32])}
+DEV_SIGNATURES = {'jpdse_debug_set_fast_path': (_I32, [_I32]),
+                  'jpdse_debug_occupy_cus': (_I32, [_I32, _P, _I32, _P])}
 
 _lib = None
 _dev = None
+_binding_epoch = [0]     # bumped whenever the bound library or its kernel-selection mode changes (dev_mode enter / exit)
+
+
+def binding_epoch():
+  """Changes whenever answers cached from the library (e.g. a layer's moment-slot count) may have become stale."""
+  return _binding_epoch[0]
 
 
 def _load(path, signatures):
@@ -147,6 +156,7 @@ class dev_mode(object):
       _dev = _load(DEV_LIB_PATH, sig)
     self._saved = _lib
     _lib = _dev
+    _binding_epoch[0] += 1
     check(_dev.jpdse_debug_set_fast_path(self.mode), 'jpdse_debug_set_fast_path')
     return _dev
 
@@ -154,6 +164,7 @@ class dev_mode(object):
     global _lib
     _dev.jpdse_debug_set_fast_path(1)
     _lib = self._saved
+    _binding_epoch[0] += 1
     return False
 
 

@@ -20,13 +20,16 @@ import torch.distributed as dist
 class GradBuckets(object):
 
   def __init__(self, named_params, bucket_bytes=64 << 20, process_group=None, reverse=True, reduce_dtype=None,
-               always_reduce=False):
+               always_reduce=False, defer=False):
     """named_params: iterable of (name, param) in FORWARD order.  reduce_dtype=torch.bfloat16: the bucket is cast
     to a bf16 wire buffer before the all-reduce and back afterwards (half the xGMI bytes; the sum then carries bf16
     rounding).  always_reduce: issue the collective even at world size 1 (exercises the RCCL path on one GPU)."""
     self.group = process_group
     self.reduce_dtype = reduce_dtype
     self.always_reduce = always_reduce
+    # defer=True: mark_ready only counts; the collectives start when the caller says so (launch_all) -- used to keep RCCL's
+    # kernels off the chip while the one-workgroup-per-CU GEMMs of the ResnetBlocks run (DESIGN.md 6, CU contention)
+    self.defer = defer
     items = [(n, p) for n, p in named_params if p.requires_grad]
     if reverse:
       items = items[::-1]
@@ -79,8 +82,14 @@ class GradBuckets(object):
       return
     b = self.buckets[bi]
     b['pending'] -= 1
-    if b['pending'] == 0:
+    if b['pending'] == 0 and not self.defer:
       self._launch(b)
+
+  def launch_all(self):
+    """Start the all-reduce of every bucket that has not been started, in bucket order (asynchronous; `finish` waits)."""
+    for b in self.buckets:
+      if b['handle'] is None:
+        self._launch(b)
 
   def _active(self):
     return dist.is_available() and dist.is_initialized() and (self.world_size() > 1 or self.always_reduce)
@@ -107,9 +116,7 @@ class GradBuckets(object):
   def finish(self):
     """Launch whatever has not been launched (parameters without a gradient this step) and make
     the current stream wait for every bucket; no host synchronisation with RCCL."""
-    for b in self.buckets:
-      if b['handle'] is None:
-        self._launch(b)
+    self.launch_all()
     for b in self.buckets:
       if b['handle'] is not None:
         b['handle'].wait()

@@ -183,7 +183,8 @@ class HipConv2d(nn.Module):
     if self.apply_bias or self.act != ACT_NONE or self.cdtype != BF16:
       return None
     d = self._desc(x.N, 2 * x.H, 2 * x.W) if self.transposed else self._desc(x.N, x.H, x.W)
-    key = (x.N, x.H, x.W)
+    from . import binding_epoch
+    key = (binding_epoch(), x.N, x.H, x.W)       # the answer depends on which library / kernel-selection mode is bound
     cache = self.__dict__.setdefault('_moment_slots', {})
     if key not in cache:
       cache[key] = ops.conv_moment_slots(d, self.transposed)

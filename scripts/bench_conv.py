@@ -23,9 +23,12 @@ LAYERS = [
   ('G first 7x7 39->64 @512x1024', 512, 1024, 39, 64, 7, 1, 3, PAD_REFLECT, False),
   ('G down 64->128 s2',            512, 1024, 64, 128, 3, 2, 1, PAD_ZERO, False),
   ('G down 128->256 s2',           256, 512, 128, 256, 3, 2, 1, PAD_ZERO, False),
+  ('G down 256->512 s2',           128, 256, 256, 512, 3, 2, 1, PAD_ZERO, False),
   ('G down 512->1024 s2',          64, 128, 512, 1024, 3, 2, 1, PAD_ZERO, False),
   ('ResBlock 1024 3x3 @32x64',     32, 64, 1024, 1024, 3, 1, 1, PAD_REFLECT, False),
   ('G up convT 1024->512',         32, 64, 1024, 512, 3, 2, 1, PAD_ZERO, True),
+  ('G up convT 512->256',          64, 128, 512, 256, 3, 2, 1, PAD_ZERO, True),
+  ('G up convT 256->128',          128, 256, 256, 128, 3, 2, 1, PAD_ZERO, True),
   ('G up convT 128->64',           256, 512, 128, 64, 3, 2, 1, PAD_ZERO, True),
   ('G last 7x7 64->3',             512, 1024, 64, 3, 7, 1, 3, PAD_REFLECT, False),
   ('VGG conv1_1 3->64',            512, 1024, 3, 64, 3, 1, 1, PAD_ZERO, False),
@@ -40,6 +43,9 @@ LAYERS = [
   ('D layer1 64->128 4x4 s2',      257, 513, 64, 128, 4, 2, 2, PAD_ZERO, False),
   ('D layer2 128->256 4x4 s2',     129, 257, 128, 256, 4, 2, 2, PAD_ZERO, False),
   ('D layer3 256->512 4x4 s1',     65, 129, 256, 512, 4, 1, 2, PAD_ZERO, False),
+  ('D1 layer1 64->128 4x4 s2',     129, 257, 64, 128, 4, 2, 2, PAD_ZERO, False),
+  ('D1 layer2 128->256 4x4 s2',    65, 129, 128, 256, 4, 2, 2, PAD_ZERO, False),
+  ('D1 layer3 256->512 4x4 s1',    33, 65, 256, 512, 4, 1, 2, PAD_ZERO, False),
 ]
 
 def timeit(fn, iters):
@@ -51,6 +57,7 @@ def timeit(fn, iters):
   return e0.elapsed_time(e1) / iters
 
 def _bench_one(name, layer, H, W, C, K, k, tr):
+  B = 2 * args.batch if name.startswith('D') else args.batch     # the discriminator sees [fake ; real]
   x = Act(torch.randn(B, H, W, (C + 7) // 8 * 8, device=dev).bfloat16(), C)
   y, ctx = layer.fwd(x)
   dy = Act(torch.randn_like(y.t.float()).bfloat16(), y.C)
@@ -67,25 +74,9 @@ def _bench_one(name, layer, H, W, C, K, k, tr):
 
 print('%-34s %10s %10s %10s   (TFLOP/s, ms)' % ('layer', 'fwd', 'dgrad', 'wgrad'))
 for (name, H, W, C, K, k, st, pad, mode, tr) in LAYERS:
-  if args.filter and args.filter not in name: continue
+  if args.filter and not any(f in name for f in args.filter.split(',')): continue
   for fm in modes:
    jpdse_hip.set_dev_mode(fm)
    layer = HipConv2d(C, K, k, st, pad, mode, apply_bias=False, transposed=tr, dtype=BF16, device=dev)
    name_m = '%s [m%d]' % (name[:28], fm)
    _bench_one(name_m, layer, H, W, C, K, k, tr)
-  continue
-  if tr:
-    x = Act(torch.randn(B, H, W, (C + 7) // 8 * 8, device=dev).bfloat16(), C)
-  else:
-    x = Act(torch.randn(B, H, W, (C + 7) // 8 * 8, device=dev).bfloat16(), C)
-  y, ctx = layer.fwd(x)
-  dy = Act(torch.randn_like(y.t.float()).bfloat16(), y.C)
-  if tr:
-    macs = B * H * W * C * K * 9            # ConvTranspose: N*Cin*Hin*Win*Cout*k^2
-  else:
-    macs = B * y.H * y.W * K * C * k * k
-  fl = 2.0 * macs
-  t_f = timeit(lambda: layer.fwd(x), args.iters)
-  t_d = timeit(lambda: layer.bwd(ctx, dy, True, False), args.iters)
-  t_w = timeit(lambda: layer.bwd(ctx, dy, False, True), args.iters)
-  print('%-34s %5.0f %5.2f %5.0f %5.2f %5.0f %5.2f' % (name, fl / t_f / 1e9, t_f, fl / t_d / 1e9, t_d, fl / t_w / 1e9, t_w))

@@ -19,3 +19,42 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
   return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _parity_report_context(request):
+  """Tags the comparisons recorded by tests/hip_util.py with the running test function and its dtype parameter."""
+  hu = sys.modules.get('hip_util')
+  if hu is not None:
+    params = getattr(getattr(request.node, 'callspec', None), 'params', {})
+    dt = params.get('dtype')
+    tag = {0: 'fp32', 1: 'bf16'}.get(dt, '') if isinstance(dt, int) else ''
+    hu.CURRENT[0] = (request.node.originalname or request.node.name) + (' ' + tag if tag else '')
+    case = params.get('case', params.get('name', ''))
+    hu.CASE[0] = case[0] if isinstance(case, (tuple, list)) and case and isinstance(case[0], str) else (case if isinstance(case, str) else '')
+  yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+  """Parity report: what every hip_util comparison of this run measured next to its bound (tests/hip_util.py REPORT)."""
+  hu = sys.modules.get('hip_util')
+  rows = getattr(hu, 'REPORT', None)
+  if not rows:
+    return
+  path = os.environ.get('JPDSE_PARITY_REPORT') or os.path.join(ROOT, 'gpurun_out', 'parity_report.txt')
+  try:
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    agg = {}
+    for what, measured, bound, note in rows:
+      a = agg.setdefault(what, [0, -1.0, bound, note])
+      a[0] += 1
+      if measured / max(bound, 1e-300) > a[1] / max(a[2], 1e-300):    # keep the call that used most of its bound
+        a[1], a[2], a[3] = measured, bound, note
+    with open(path, 'w') as fh:
+      fh.write('# parity report of one `pytest -m gpu` run: worst measured value over the calls of each comparison, next to its bound\n')
+      fh.write('# %-86s %5s %11s %9s %7s  %s\n' % ('test | comparison', 'calls', 'measured', 'bound', 'used', 'worst case'))
+      for what in sorted(agg):
+        n, m, b, note = agg[what]
+        fh.write('%-88s %5d %11.3e %9.1e %6.1f%%  %s\n' % (what[:88], n, m, b, 100.0 * m / b if b > 0 else 0.0, note))
+  except OSError:
+    pass

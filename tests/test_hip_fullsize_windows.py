@@ -1,0 +1,183 @@
+"""GPU: element-wise parity at BASELINE.json's sizes (batch 4 @ 1024x512, and 2048x1024), where a whole-tensor oracle run
+takes minutes.
+
+The kernels that run at the bench size are not the ones the small parity cases of tests/test_hip_ops.py reach by default:
+the row-streaming family (conv_rows / dgrad2_rows / head_rows / thin_rows / thin_in_rows), the halo kernel and the all-taps
+weight gradients pick band heights, strip counts and pixel-range partitions from the problem size.  Their risk sits at strip
+seams (multiples of 64 / 128 pixels), band seams (multiples of 16 / 32 / 64 rows), the image border and the batch boundary.
+Here every layer runs ONCE at full size on the device and
+
+  * forward and data gradient are compared element by element against torch-CPU (fp32 arithmetic on the same bf16-rounded
+    operands) on full-width row bands -- top border, a band across row 64, a band across the middle seam, bottom border --
+    of the first and the last image of the batch (>= 8 windows per layer; full width = every strip seam);
+  * the weight gradient, a reduction over ALL pixels and images, is compared as the complete tensor against the sum of
+    torch-CPU per-image weight gradients.
+
+The ResnetBlock shape (32x64 pixels) is compared as complete tensors.  Criterion: hip_util.assert_close (max-norm AND
+element-wise, RTOL[bf16]).  References: torch.nn.functional conv2d / conv_transpose2d as the reference's nn.Conv2d /
+nn.ConvTranspose2d layers call them (ctu/models/pix2pixHD_networks/networks.py:204-262, 430-449).
+"""
+import zlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from jpdse_hip import BF16, PAD_ZERO, PAD_REFLECT, ACT_NONE
+from jpdse_hip.ops import Act
+from jpdse_hip.layers import HipConv2d
+from hip_util import DEV, RTOL, assert_close
+
+
+def _nchw(t_nhwc, C):
+  """NHWC device slice -> fp32 NCHW on the CPU (logical channels only)."""
+  return t_nhwc[..., :C].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _bands(OH):
+  """Output-row bands [o0, o1): both borders, across row 64 (band seam of every band height <= 64) and across the middle."""
+  if OH <= 48:
+    return [(0, OH)]
+  out = [(0, 12), (OH - 12, OH)]
+  if OH >= 96:
+    out.append((58, 70))
+  mid = (OH // 2) // 2 * 2
+  if OH >= 160:
+    out.append((mid - 6, mid + 6))
+  return out
+
+
+def _conv_band(xb, w, k, st, pad, mode, pt, pb):
+  xp = F.pad(xb, (pad, pad, pt, pb), mode='reflect' if mode == PAD_REFLECT else 'constant')
+  return F.conv2d(xp, w, stride=st)
+
+
+def _make(name, N, H, W, C, K, k, st, pad, mode, transposed):
+  g = torch.Generator(device=DEV).manual_seed(zlib.crc32(name.encode()) % 1000)
+  layer = HipConv2d(C, K, k, st, pad, mode, act=ACT_NONE, apply_bias=False, transposed=transposed, dtype=BF16, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(torch.randn(layer.weight.shape, generator=g, device=DEV) * (1.0 / (C * k * k) ** 0.5))
+  x = Act.empty(N, H, W, C, BF16, DEV)
+  x.t.zero_()
+  x.t[..., :C] = torch.randn((N, H, W, C), generator=g, device=DEV).to(torch.bfloat16)
+  y, ctx = layer.fwd(x)
+  Ky = y.C
+  dy = y.empty_like()
+  dy.t.zero_()
+  dy.t[..., :Ky] = torch.randn(tuple(y.t.shape[:3]) + (Ky,), generator=g, device=DEV).to(torch.bfloat16)
+  dx = layer.bwd(ctx, dy, need_dx=True, need_dw=True)
+  torch.cuda.synchronize()
+  wq = layer.weight.detach().to(torch.bfloat16).float().cpu()      # what the packed panels hold
+  return layer, x, y, dy, dx, wq
+
+
+def _check_layer(name, N, H, W, C, K, k, st, pad, mode, transposed=False, wgrad_images=None):
+  layer, x, y, dy, dx, wq = _make(name, N, H, W, C, K, k, st, pad, mode, transposed)
+  tol = RTOL[BF16]
+  OH, OW, Ky = y.H, y.W, y.C
+  assert (y.t[..., Ky:] == 0).all() and (dx.t[..., C:] == 0).all(), 'padding lanes must stay zero'
+  images = sorted({0, N - 1})
+  nwin = 0
+  if not transposed:
+    for n in images:
+      for (o0, o1) in _bands(OH):
+        a0, a1 = o0 * st - pad, (o1 - 1) * st - pad + k
+        pt, pb = max(0, -a0), max(0, a1 - H)
+        a0c, a1c = max(0, a0), min(H, a1)
+        xb = _nchw(x.t[n:n + 1, a0c:a1c], C).requires_grad_(True)
+        yb = _conv_band(xb, wq, k, st, pad, mode, pt, pb)
+        assert yb.shape[2] == o1 - o0
+        assert_close(_nchw(y.t[n:n + 1, o0:o1], Ky), yb.detach(), tol, name + ' fwd band', detail='rows %d..%d image %d' % (o0, o1, n))
+        yb.backward(_nchw(dy.t[n:n + 1, o0:o1], Ky))
+        # input rows all of whose outputs lie inside the band (everything up to a true border)
+        lo = 0 if o0 == 0 else a0c + (k - 1)
+        hi = H if o1 == OH else a1c - (k - 1)
+        if hi - lo >= 2:
+          assert_close(_nchw(dx.t[n:n + 1, lo:hi], C), xb.grad[:, :, lo - a0c:hi - a0c], tol,
+                       name + ' dgrad band', detail='rows %d..%d image %d' % (lo, hi, n))
+        nwin += 1
+  else:
+    for n in images:
+      for (o0, o1) in _bands(H):                     # bands of INPUT rows [a0, a1) -> output rows [2 a0, 2 a1)
+        a0, a1 = o0, o1
+        xb = _nchw(x.t[n:n + 1, a0:a1], C).requires_grad_(True)
+        yb = F.conv_transpose2d(xb, wq, stride=2, padding=1, output_padding=1)
+        ylo = 0 if a0 == 0 else 2
+        yhi = yb.shape[2] if a1 == H else yb.shape[2] - 2
+        assert_close(_nchw(y.t[n:n + 1, 2 * a0 + ylo:2 * a0 + yhi], Ky), yb.detach()[:, :, ylo:yhi], tol,
+                     name + ' fwd band', detail='rows %d..%d image %d' % (2 * a0 + ylo, 2 * a0 + yhi, n))
+        yb.backward(_nchw(dy.t[n:n + 1, 2 * a0:2 * a1], Ky))
+        lo = 0 if a0 == 0 else 1
+        hi = (a1 - a0) if a1 == H else (a1 - a0) - 1
+        assert_close(_nchw(dx.t[n:n + 1, a0 + lo:a0 + hi], C), xb.grad[:, :, lo:hi], tol,
+                     name + ' dgrad band', detail='rows %d..%d image %d' % (a0 + lo, a0 + hi, n))
+        nwin += 1
+  assert nwin >= 2
+  # weight gradient: the complete tensor, summed over the images on the CPU
+  wref = torch.zeros_like(wq)
+  wl = wq.clone().requires_grad_(True)
+  for n in (range(N) if wgrad_images is None else wgrad_images):
+    xi = _nchw(x.t[n:n + 1], C)
+    if transposed:
+      yi = F.conv_transpose2d(xi, wl, stride=2, padding=1, output_padding=1)
+    else:
+      yi = _conv_band(xi, wl, k, st, pad, mode, pad, pad)
+    (gw,) = torch.autograd.grad(yi, wl, _nchw(dy.t[n:n + 1], Ky))
+    wref += gw
+    del xi, yi, gw
+  if wgrad_images is None:
+    assert_close(layer.weight.grad.cpu(), wref, tol, name + ' wgrad (complete tensor, all images)')
+
+
+# name, N, H, W, C, K, k, stride, pad, mode, transposed  -- the bench step's layers at 1024x512, batch 4 (PatchGAN: 8)
+LAYERS_1024 = [
+    ('g_first_7x7',      4, 512, 1024, 39,  64,  7, 1, 3, PAD_REFLECT, False),   # thin_fwd, wgrad_thin
+    ('g_down_64_128',    4, 512, 1024, 64,  128, 3, 2, 1, PAD_ZERO,    False),   # conv_rows<2>, dgrad2_rows, wgrad_taps
+    ('g_down_128_256',   4, 256, 512,  128, 256, 3, 2, 1, PAD_ZERO,    False),   # gemm_fast fwd / merged-phase dgrad
+    ('g_up_convT_128_64', 4, 256, 512, 128, 64,  3, 2, 1, PAD_ZERO,    True),    # dgrad2_rows as the forward
+    ('g_head_7x7',       4, 512, 1024, 64,  3,   7, 1, 3, PAD_REFLECT, False),   # head_rows<7>, thin_in_rows<7> + ring fold
+    ('vgg_conv1_1',      4, 512, 1024, 3,   64,  3, 1, 1, PAD_ZERO,    False),   # thin_in_rows<3>, head_rows<3>
+    ('vgg_conv1_2',      4, 512, 1024, 64,  64,  3, 1, 1, PAD_ZERO,    False),   # conv_rows<1,2>
+    ('vgg_conv2_1',      4, 256, 512,  64,  128, 3, 1, 1, PAD_ZERO,    False),   # conv_rows<1,4>
+    ('vgg_conv2_2',      4, 256, 512,  128, 128, 3, 1, 1, PAD_ZERO,    False),   # gemm_halo (zero padding, 2 slabs)
+    ('d_layer0',         8, 512, 1024, 39,  64,  4, 2, 2, PAD_ZERO,    False),   # thin_rows
+    ('d_layer1',         8, 257, 513,  64,  128, 4, 2, 2, PAD_ZERO,    False),   # odd sizes: ragged tiles
+    ('d_layer3',         8, 65,  129,  256, 512, 4, 1, 2, PAD_ZERO,    False),   # 4x4 stride 1
+]
+
+
+@pytest.mark.parametrize('case', LAYERS_1024, ids=[c[0] for c in LAYERS_1024])
+def test_1024x512_windows_vs_torch_cpu_bf16(case):
+  _check_layer(*case)
+
+
+def test_1024x512_resblock_complete_tensors_vs_torch_cpu_bf16():
+  """The headline kernel set (gemm_halo forward, halo + ring strips data gradient, wgrad_nine) at its bench shape: the
+  complete forward, data-gradient and weight-gradient tensors (4 x 32 x 64 x 1024) against torch-CPU."""
+  name, N, H, W, C = 'resblock_1024', 4, 32, 64, 1024
+  layer, x, y, dy, dx, wq = _make(name, N, H, W, C, C, 3, 1, 1, PAD_REFLECT, False)
+  tol = RTOL[BF16]
+  xr = _nchw(x.t, C).requires_grad_(True)
+  wl = wq.clone().requires_grad_(True)
+  yr = _conv_band(xr, wl, 3, 1, 1, PAD_REFLECT, 1, 1)
+  assert_close(_nchw(y.t, C), yr.detach(), tol, name + ' fwd (complete)')
+  yr.backward(_nchw(dy.t, C))
+  assert_close(_nchw(dx.t, C), xr.grad, tol, name + ' dgrad (complete)')
+  assert_close(layer.weight.grad.cpu(), wl.grad, tol, name + ' wgrad (complete)')
+
+
+# 2048x1024 (BASELINE config 5), batch 1: forward / data-gradient windows; the weight gradient from image 0 only would be the
+# same tensor as the device's (batch 1), so it is compared completely as well for the cheaper layers
+LAYERS_2048 = [
+    ('g_first_7x7@2k',   1, 1024, 2048, 39, 64,  7, 1, 3, PAD_REFLECT, False),
+    ('g_down_64_128@2k', 1, 1024, 2048, 64, 128, 3, 2, 1, PAD_ZERO,    False),
+    ('vgg_conv1_2@2k',   1, 1024, 2048, 64, 64,  3, 1, 1, PAD_ZERO,    False),
+    ('g_head_7x7@2k',    1, 1024, 2048, 64, 3,   7, 1, 3, PAD_REFLECT, False),
+]
+
+
+@pytest.mark.parametrize('case', LAYERS_2048, ids=[c[0] for c in LAYERS_2048])
+def test_2048x1024_windows_vs_torch_cpu_bf16(case):
+  _check_layer(*case)

@@ -186,10 +186,10 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, seed):
   z_ref.backward(gy * _act_grad_from_output(y_dev, act))            # reference backward through the device's mask
   dx = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=True)
   torch.cuda.synchronize()
-  assert_close(to_nchw(dx), xr.grad, 2 * tol, name + ' dgrad')
+  assert_close(to_nchw(dx), xr.grad, tol, name + ' dgrad')
   assert (dx.t[..., C:] == 0).all()
-  assert_close(layer.weight.grad.cpu(), wr.grad, 2 * tol, name + ' wgrad')
-  assert_close(layer.bias.grad.cpu(), br.grad, 2 * tol, name + ' bias grad')
+  assert_close(layer.weight.grad.cpu(), wr.grad, tol, name + ' wgrad')
+  assert_close(layer.bias.grad.cpu(), br.grad, tol, name + ' bias grad')
 
 
 @pytest.mark.parametrize('name', ['halo_vgg_64', 'halo_vgg_256', 'ring_dgrad_192'])
@@ -233,16 +233,16 @@ def test_conv_dgrad_fused_relu(case, dtype):
   y, ctx = layer.fwd(x)
   dz = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False, relu_input=True)
   torch.cuda.synchronize()
-  assert_close(to_nchw(dz), zr.grad, 2 * RTOL[dtype], name + ' dgrad with fused ReLU mask')
+  assert_close(to_nchw(dz), zr.grad, RTOL[dtype], name + ' dgrad with fused ReLU mask')
   assert (to_nchw(dz)[z <= 0] == 0).all()
   # gradient fan-in summed in the same epilogue: dz = (dgrad + other) * mask, and without the mask
   other = quantize_like(torch.randn(z.shape, generator=g), dtype)
   dz2 = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False, relu_input=True, addend=to_act(other, dtype))
-  assert_close(to_nchw(dz2), zr.grad + other * (z > 0), 2 * RTOL[dtype], name + ' dgrad + addend, masked')
+  assert_close(to_nchw(dz2), zr.grad + other * (z > 0), RTOL[dtype], name + ' dgrad + addend, masked')
   dx3 = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False, addend=to_act(other, dtype))
   y2 = _torch_conv(x_leaf := F.relu(z).clone().requires_grad_(True), wr, None, st, pad, mode, ACT_NONE)
   y2.backward(gy)
-  assert_close(to_nchw(dx3), x_leaf.grad + other, 2 * RTOL[dtype], name + ' dgrad + addend')
+  assert_close(to_nchw(dx3), x_leaf.grad + other, RTOL[dtype], name + ' dgrad + addend')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -302,8 +302,8 @@ def test_conv_transpose(shape, dtype):
   tol = RTOL[dtype]
   assert_close(to_nchw(y), y_ref.detach(), tol, 'convT fwd')
   dx = layer.bwd(ctx, to_act(gy, dtype), True, True)
-  assert_close(to_nchw(dx), xr.grad, 2 * tol, 'convT dgrad')
-  assert_close(layer.weight.grad.cpu(), wr.grad, 2 * tol, 'convT wgrad')
+  assert_close(to_nchw(dx), xr.grad, tol, 'convT dgrad')
+  assert_close(layer.weight.grad.cpu(), wr.grad, tol, 'convT wgrad')
 
 
 # PatchGAN layer 0, data gradient with respect to the 3 image channels only (HipConv2d.bwd_input_slice): the row-streaming
@@ -328,7 +328,7 @@ def test_conv_dgrad_input_slice(shape, dtype):
   dx = layer.bwd_input_slice(ctx, to_act(gy, dtype), 36, 39)
   torch.cuda.synchronize()
   assert dx.C == 3 and dx.t.shape[1:3] == (H, W)
-  assert_close(to_nchw(dx), xr.grad[:, 36:39], 2 * RTOL[dtype], 'layer-0 data gradient, image channels')
+  assert_close(to_nchw(dx), xr.grad[:, 36:39], RTOL[dtype], 'layer-0 data gradient, image channels')
   assert (dx.t[..., 3:] == 0).all()
 
 
@@ -366,13 +366,59 @@ def test_conv_norm_fused_moments(name, make, shape):
   torch.cuda.synchronize()
   C = to_nchw(y).shape[1]
   assert torch.equal(ctx.items[1].items[0].t, ctx2.items[1].items[0].t), 'the conv output itself must not change'
-  assert_close(stats.cpu()[:, :C], ctx2.items[1].items[1].cpu()[:, :C], 1e-3, name + ' stats (moments of the fp32 accumulators vs a pass over the bf16-rounded output)')
+  assert_close(stats.cpu()[:, :C], ctx2.items[1].items[1].cpu()[:, :C], 2e-5, name + ' stats (per-block (mean, M2) of the stored values, Chan merge) vs the separate shifted pass')
   assert_close(to_nchw(y), to_nchw(y2), RTOL[BF16], name + ' norm output')
-  assert_close(to_nchw(dx), to_nchw(dx2), 3 * RTOL[BF16], name + ' dx')
-  assert_close(dw.cpu(), conv.weight.grad.cpu(), 3 * RTOL[BF16], name + ' dw')
+  assert_close(to_nchw(dx), to_nchw(dx2), RTOL[BF16], name + ' dx')
+  assert_close(dw.cpu(), conv.weight.grad.cpu(), RTOL[BF16], name + ' dw')
   # and against torch on the fp32 view of the same conv output
   h = to_nchw(ctx.items[1].items[0])
   assert_close(to_nchw(y), F.relu(F.instance_norm(h, eps=1e-5)), RTOL[BF16], name + ' vs torch')
+
+
+FUSED_MOMENT_FULL = [
+    ('first7x7@1024x512', lambda: HipConv2d(39, 64, 7, 1, 3, PAD_REFLECT, apply_bias=False, dtype=BF16, device=DEV), (2, 39, 512, 1024)),
+    ('down_s2@1024x512',  lambda: HipConv2d(64, 128, 3, 2, 1, PAD_ZERO, apply_bias=False, dtype=BF16, device=DEV), (2, 64, 512, 1024)),
+    ('convT_up@1024x512', lambda: HipConv2d(128, 64, 3, 2, 1, transposed=True, apply_bias=False, dtype=BF16, device=DEV), (2, 128, 256, 512)),
+]
+
+
+@pytest.mark.parametrize('name,make,shape', FUSED_MOMENT_FULL, ids=[c[0] for c in FUSED_MOMENT_FULL])
+def test_conv_norm_fused_moments_offset_channels_full_size(name, make, shape):
+  """channels whose mean is tens of standard deviations away from zero (a one-hot label plane times a filter with
+  a non-zero sum does that), at the bench resolution (HW = 524288 per channel): the fused moments -- per-block (mean, M2)
+  about a pilot, Chan merge -- must give the statistics of the separate, shifted moment pass.  Inputs 4 + N(0,1), filter
+  N(0.01, 0.02): channel means ~ +-20 .. 40 sigma."""
+  g = G(zlib.crc32(name.encode()) & 0xfff)
+  conv = make()
+  with torch.no_grad():
+    conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.02 + 0.01)
+  stage = ConvNormAct(conv, InstNormAct(ACT_RELU))
+  N, C, H, W = shape
+  xd = torch.randn((N, H, W, C), generator=torch.Generator(device=DEV).manual_seed(7), device=DEV) + 4.0
+  x = Act.empty(N, H, W, C, BF16, DEV)
+  x.t.zero_()
+  x.t[..., :C] = xd.to(torch.bfloat16)
+  del xd
+  assert conv.fwd_moments(x) is not None, 'this layer is expected to take the fused epilogue'
+  y, ctx = stage.fwd(x)
+  stats = ctx.items[1].items[1].clone()
+  h = ctx.items[1].items[0]
+  K = h.C
+  hf = h.t[..., :K].float()
+  mean_ref = hf.mean(dim=(1, 2)).double()
+  var_ref = hf.double().var(dim=(1, 2), unbiased=False)
+  ratio = (mean_ref.abs() / var_ref.sqrt()).min().item()
+  assert ratio >= 10.0, 'test premise: every channel at least 10 sigma off zero (got %.1f)' % ratio
+  conv.fwd_moments = lambda _x: None          # the separate (shifted) moment pass on the same conv output
+  y2, ctx2 = stage.fwd(x)
+  torch.cuda.synchronize()
+  stats2 = ctx2.items[1].items[1]
+  assert torch.equal(h.t, ctx2.items[1].items[0].t)
+  rstd_ref = (var_ref + 1e-5).rsqrt()
+  assert_close(stats[:, :K, 0].cpu(), mean_ref.cpu(), 1e-6, name + ' fused mean vs fp64 of the stored tensor')
+  assert_close(stats[:, :K, 1].cpu(), rstd_ref.cpu(), 2e-5, name + ' fused rstd vs fp64 of the stored tensor')
+  assert_close(stats2[:, :K, 1].cpu(), rstd_ref.cpu(), 2e-5, name + ' separate-pass rstd vs fp64 of the stored tensor')
+  assert_close(y.t.float().cpu(), y2.t.float().cpu(), RTOL[BF16], name + ' norm output, fused vs separate moments')
 
 
 # ---- instance norm -----------------------------------------------------------------------------
@@ -396,7 +442,7 @@ def test_instance_norm_act(shape, act, dtype):
   tol = RTOL[dtype]
   assert_close(to_nchw(y), y_ref.detach(), tol, 'inorm fwd')
   dx = layer.bwd(ctx, to_act(gy, dtype))
-  assert_close(to_nchw(dx), xr.grad, 3 * tol, 'inorm bwd')
+  assert_close(to_nchw(dx), xr.grad, tol, 'inorm bwd')
 
 
 
@@ -438,7 +484,7 @@ def test_instance_norm_exchange(name, shape, with_res, dtype):
   y, stats, dx = run()
   tol = RTOL[dtype]
   assert_close(to_nchw(y), y_ref.detach(), tol, 'inorm fwd')
-  assert_close(to_nchw(dx), xr.grad, 3 * tol, 'inorm bwd')
+  assert_close(to_nchw(dx), xr.grad, tol, 'inorm bwd')
   for rep in range(3):                      # every launch uses a fresh epoch of the exchange flags
     y2, stats2, dx2 = run()
     assert torch.equal(y2.t, y.t) and torch.equal(stats2, stats) and torch.equal(dx2.t, dx.t), 'not reproducible'
@@ -448,12 +494,12 @@ def test_instance_norm_exchange(name, shape, with_res, dtype):
   st_tol = 2e-5
   assert_close(stats3.cpu()[:, :C], stats.cpu()[:, :C], st_tol, 'stats vs three-kernel form')
   assert_close(to_nchw(y3), to_nchw(y), tol, 'fwd vs three-kernel form')
-  assert_close(to_nchw(dx3), to_nchw(dx), 3 * tol, 'bwd vs three-kernel form')
+  assert_close(to_nchw(dx3), to_nchw(dx), tol, 'bwd vs three-kernel form')
   with jpdse_hip.dev_mode(28):              # one kernel, rows exchanged inside the launch (8 or 16 pixels per thread: its own
     y4, stats4, dx4 = run()                 # split count, so another summation order than the shipped form)
     assert_close(stats4.cpu()[:, :C], stats.cpu()[:, :C], st_tol, 'stats vs one-kernel form')
     assert_close(to_nchw(y4), to_nchw(y), tol, 'fwd vs one-kernel form')
-    assert_close(to_nchw(dx4), to_nchw(dx), 3 * tol, 'bwd vs one-kernel form')
+    assert_close(to_nchw(dx4), to_nchw(dx), tol, 'bwd vs one-kernel form')
     for rep in range(3):
       y5, stats5, dx5 = run()
       assert torch.equal(y5.t, y4.t) and torch.equal(stats5, stats4) and torch.equal(dx5.t, dx4.t), 'one-kernel form not reproducible'
@@ -477,11 +523,11 @@ def test_resnet_block(dtype):
   y_ref.backward(gy)
   y, ctx = blk.fwd(to_act(x, dtype))
   tol = RTOL[dtype]
-  assert_close(to_nchw(y), y_ref.detach(), 2 * tol, 'resblock fwd')
+  assert_close(to_nchw(y), y_ref.detach(), tol, 'resblock fwd')
   dx = blk.bwd(ctx, to_act(gy, dtype), True, True)
-  assert_close(to_nchw(dx), xr.grad, 4 * tol, 'resblock dx')
-  assert_close(blk.conv_block[1].weight.grad.cpu(), ref_sd['b.conv_block.1.weight'].grad, 4 * tol, 'resblock dw1')
-  assert_close(blk.conv_block[5].weight.grad.cpu(), ref_sd['b.conv_block.5.weight'].grad, 4 * tol, 'resblock dw5')
+  assert_close(to_nchw(dx), xr.grad, tol, 'resblock dx')
+  assert_close(blk.conv_block[1].weight.grad.cpu(), ref_sd['b.conv_block.1.weight'].grad, tol, 'resblock dw1')
+  assert_close(blk.conv_block[5].weight.grad.cpu(), ref_sd['b.conv_block.5.weight'].grad, tol, 'resblock dw5')
 
 
 # ---- pooling -----------------------------------------------------------------------------------
@@ -643,34 +689,12 @@ FULL_SIZE_LAYERS = [
 
 @pytest.mark.parametrize('case', FULL_SIZE_LAYERS, ids=[c[0] for c in FULL_SIZE_LAYERS])
 def test_full_size_adjointness_bf16(case):
-  name, N, H, W, C, K, k, st, pad, mode = case
-  g = torch.Generator(device=DEV).manual_seed(zlib.crc32(name.encode()) % 1000)
-  layer = HipConv2d(C, K, k, st, pad, mode, act=ACT_NONE, apply_bias=False, dtype=BF16, device=DEV)
-  with torch.no_grad():
-    layer.weight.copy_(torch.randn(layer.weight.shape, generator=g, device=DEV) * (1.0 / (C * k * k) ** 0.5))
-  x = Act.empty(N, H, W, C, BF16, DEV)
-  x.t.zero_()
-  x.t[..., :C] = torch.randn((N, H, W, C), generator=g, device=DEV).to(torch.bfloat16)
-  y, ctx = layer.fwd(x)
-  dy = y.empty_like()
-  dy.t.zero_()
-  dy.t[..., :K] = torch.randn(tuple(y.t.shape[:3]) + (K,), generator=g, device=DEV).to(torch.bfloat16)
-  dx = layer.bwd(ctx, dy, need_dx=True, need_dw=True)
-  torch.cuda.synchronize()
-  dot = lambda a, b: (a.double() * b.double()).sum().item()
-  wq = layer.weight.detach().to(torch.bfloat16)             # the packed panel holds the bf16-rounded master
-  lhs = dot(y.t, dy.t)
-  via_dx = dot(x.t, dx.t)
-  via_dw = dot(wq, layer.weight.grad)
-  scale = (dot(y.t, y.t) * dot(dy.t, dy.t)) ** 0.5          # Cauchy-Schwarz bound of the three products
-  # Random x, dy make <y,dy> itself ~1e-4 of scale (n ~ 1e8 terms of random sign); measured residuals are 4e-8 .. 1.1e-6
-  # of scale (bf16 storage of y / dx, fp32 atomics in wgrad).  A bound of 4e-6 of scale = ~4 % of the product: dropping
-  # 0.2 % of the terms (one border ring at 1024x512) moves it by more than that.
-  print('%s: |<y,dy>-<x,dx>|/scale = %.2e, |<y,dy>-<w,dw>|/scale = %.2e, <y,dy>/scale = %.2e' % (
-      name, abs(lhs - via_dx) / scale, abs(lhs - via_dw) / scale, lhs / scale))
-  assert abs(lhs - via_dx) <= 4e-6 * scale, '%s: <y,dy> %.6e vs <x,dx> %.6e (scale %.3e)' % (name, lhs, via_dx, scale)
-  assert abs(lhs - via_dw) <= 4e-6 * scale, '%s: <y,dy> %.6e vs <w,dw> %.6e (scale %.3e)' % (name, lhs, via_dw, scale)
-  assert scale > 0 and abs(lhs) < scale
+  """Three seeds per layer; the bound of each layer is 3x its largest measured residual (hip_util.ADJ_BOUND).  Random x, dy
+  make <y,dy> itself ~1e-4 of the scale (n ~ 1e8 terms of random sign): dropping one border ring at 1024x512 (0.2 % of the
+  terms) moves the product by ~2e-7 of the scale per ring row -- the element-wise window checks of
+  tests/test_hip_fullsize_windows.py are what sees a wrong row; this ties the three kernels of a layer to one number."""
+  from hip_util import adjointness
+  assert adjointness(*case, seeds=(0, 1, 2)), 'weight gradient not bit-reproducible'
 
 
 def test_conv_entry_points_refuse_short_workspace_before_launching():

@@ -100,6 +100,12 @@ def _check_grads(tr, ora, xd, what):
           '%s grad %s: vs oracle-fp32 %.2e; vs fp64 HIP %.2e, torch-fp32 %.2e' % (what, k, direct, e_hip, e_t32)
   # which tensors needed the fp64 yardstick, and by how much (visible with -s / in the failure output)
   escaped = [r for r in report if r[1] > GRAD_TOL]
+  import hip_util
+  hip_util.record('%s: weight gradients vs fp32 oracle, direct (max over the %d tensors that met it)' % (what, len(report) - len(escaped)),
+                  max([r[1] for r in report if r[1] <= GRAD_TOL] or [0.0]), GRAD_TOL)
+  hip_util.record('%s: tensors judged against fp64 instead: worst (HIP-vs-fp64) / (torch-fp32-vs-fp64)' % what,
+                  max([r[2] / max(r[3], 1e-30) for r in escaped] or [0.0]), 2.0,
+                  '%d of %d tensors; worst direct %.2e' % (len(escaped), len(report), max([r[1] for r in escaped] or [0.0])))
   print('%s: %d of %d weight gradients within %.0e of the fp32 oracle directly; %d judged against fp64:'
         % (what, len(report) - len(escaped), len(report), GRAD_TOL, len(escaped)))
   for k, direct, e_hip, e_t32 in escaped:
@@ -148,7 +154,7 @@ def _golden_steps(golden_dir, name):
   xd = omodel.synthetic_batch(b, h, w, seed=999, num_labels=opt.num_labels)
   img = tr.get_img(xd)
   assert img.shape == (b, 3, h, w) and img.is_cuda
-  assert_close(img.cpu(), ora.get_img(xd), 1e-3, name + ' get_img')
+  assert_close(img.cpu(), ora.get_img(xd), 4e-4, name + ' get_img')     # measured <= 4.1e-5 (profiles/r03_parity_report.txt)
   np.testing.assert_allclose(tr.get_eval_loss(xd), ora.get_eval_loss(xd), rtol=1e-3)
   assert tuple(g['get_img'].shape) == tuple(img.shape)
   return tr

@@ -146,6 +146,9 @@ def test_bench_gpus_n_without_launcher_fails_cleanly_when_gpus_are_missing():
   on a box with fewer GPUs it says so and exits 2 before touching any device."""
   env = dict(os.environ)
   env.pop('WORLD_SIZE', None)
+  # hide every GPU from the child: "fewer GPUs than ranks" must hold on any box (on a multi-GPU node the unhidden child
+  # would really launch a 2-rank benchmark from the CPU suite)
+  env['HIP_VISIBLE_DEVICES'] = env['ROCR_VISIBLE_DEVICES'] = env['CUDA_VISIBLE_DEVICES'] = ''
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
   assert r.returncode == 2, r.stderr[-2000:]
