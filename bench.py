@@ -252,9 +252,14 @@ def main():
   L = lib()
   if args.late_readback:
     trainer.model.early_loss_readback = False
-  if not args.no_kernel_timers:
-    check(L.jpdse_prof_select(1, 1024, 9216, 96 * max(args.steps, 1)), 'prof_select')
-    check(L.jpdse_prof_hbm_select(1, 160 * max(args.steps, 1)), 'prof_hbm_select')   # ~72 norm calls + 2 Adams per step
+  # In-library kernel timers (hipEvent pairs on the kernels' own stream, inside the timed region).  Every event costs the
+  # stream ~3.7 us (measured round 3: 296 events per step = 1.1 ms of a 26.3 ms step), so they cover the FIRST `timed_steps`
+  # steps of the timed region only -- one step holds 36 ResnetBlock GEMM launches, 18 weight gradients, 72 norm calls.
+  timed_steps = 0 if args.no_kernel_timers else min(2, args.steps)
+  tsteps = max(timed_steps, 1)
+  if timed_steps:
+    check(L.jpdse_prof_select(1, 1024, 9216, 72 * timed_steps), 'prof_select')        # 36 halo + 18 ring + 18 wgrad regions per step
+    check(L.jpdse_prof_hbm_select(1, 74 * timed_steps), 'prof_hbm_select')           # 72 norm calls + 2 Adams per step
   barrier()
   t0 = time.perf_counter()
   for _ in range(args.steps):
@@ -289,7 +294,7 @@ def main():
       achieved = fl.value / (ms.value * 1e-3) / 1e12
       roof = dict(bound='mfma', kernel='gemm_halo_kernel (ResnetBlock 3x3 conv fwd + data gradient, N=1024 K=9216)',
                   achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4),
-                  traffic=None, launches_per_step=n.value / args.steps,
+                  traffic=None, launches_per_step=n.value / tsteps,
                   avg_launch_ms=round(ms.value / n.value, 4),
                   flops_per_launch=fl.value / n.value)
       # HBM-side bytes per launch of the same kernel: rocprofv3 PMC counters cannot be read from inside this
@@ -315,10 +320,10 @@ def main():
       roof_all = dict(bound='mfma', kernel='ResnetBlock 3x3 conv, all passes: gemm_halo_kernel (fwd, dgrad) + ring strips / fold '
                                           '(gemm_fast_kernel, ring_fold_kernel) + wgrad_nine_kernel',
                       achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                      ms_per_step=dict(fwd_dgrad=round(ms.value / args.steps, 4), ring=round(extra['ring'][0] / args.steps, 4),
-                                       wgrad=round(wg[0] / args.steps, 4)),
+                      ms_per_step=dict(fwd_dgrad=round(ms.value / tsteps, 4), ring=round(extra['ring'][0] / tsteps, 4),
+                                       wgrad=round(wg[0] / tsteps, 4)),
                       wgrad=dict(achieved=round(wg[1] / (wg[0] * 1e-3) / 1e12, 2), avg_launch_ms=round(wg[0] / wg[2], 4),
-                                 launches_per_step=wg[2] / args.steps, frac=round(wg[1] / (wg[0] * 1e-3) / 1e12 / peak, 4)))
+                                 launches_per_step=wg[2] / tsteps, frac=round(wg[1] / (wg[0] * 1e-3) / 1e12 / peak, 4)))
     # third roofline entry, HBM-bound: the InstanceNorm + activation (+ residual) calls, forward and backward (north_star:
     # "HBM GB/s on the norm/activation kernels against gfx950 peak"), and the fused Adam next to them
     roof_hbm = None
@@ -329,11 +334,11 @@ def main():
       roof_hbm = dict(bound='hbm', kernel='InstanceNorm + activation (+ residual): moment / finalize / apply and register-held kernels, '
                                            'forward and backward (norm.hip)',
                       achieved=gbs(nb, nt), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nb / (nt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                      traffic=None, calls_per_step=(hbm['inorm_fwd'][2] + hbm['inorm_bwd'][2]) / args.steps,
-                      ms_per_step=round(nt / args.steps, 4), algorithmic_bytes_per_step=nb / args.steps,
-                      forward=dict(achieved=gbs(hbm['inorm_fwd'][1], hbm['inorm_fwd'][0]), ms_per_step=round(hbm['inorm_fwd'][0] / args.steps, 4)),
-                      backward=dict(achieved=gbs(hbm['inorm_bwd'][1], hbm['inorm_bwd'][0]), ms_per_step=round(hbm['inorm_bwd'][0] / args.steps, 4)),
-                      adam=dict(achieved=gbs(hbm['adam'][1], hbm['adam'][0]), ms_per_step=round(hbm['adam'][0] / args.steps, 4),
+                      traffic=None, calls_per_step=(hbm['inorm_fwd'][2] + hbm['inorm_bwd'][2]) / tsteps,
+                      ms_per_step=round(nt / tsteps, 4), algorithmic_bytes_per_step=nb / tsteps,
+                      forward=dict(achieved=gbs(hbm['inorm_fwd'][1], hbm['inorm_fwd'][0]), ms_per_step=round(hbm['inorm_fwd'][0] / tsteps, 4)),
+                      backward=dict(achieved=gbs(hbm['inorm_bwd'][1], hbm['inorm_bwd'][0]), ms_per_step=round(hbm['inorm_bwd'][0] / tsteps, 4)),
+                      adam=dict(achieved=gbs(hbm['adam'][1], hbm['adam'][0]), ms_per_step=round(hbm['adam'][0] / tsteps, 4),
                                 frac=round(hbm['adam'][1] / (hbm['adam'][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hbm['adam'][0] > 0 else None))
       tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
       if (os.path.exists(tpath) and (args.netG, args.width, args.height, args.batch, args.dtype) == ('global', 1024, 512, 4, 'bf16')):
@@ -363,6 +368,8 @@ def main():
         'roofline': roof,
         'roofline_resblock_all_passes': roof_all,
         'roofline_hbm': roof_hbm,
+        'kernel_timers': {'steps_covered': timed_steps, 'of_timed_steps': args.steps,
+                          'note': 'hipEvent pairs inside the timed region, first steps only (each event costs the stream ~3.7 us)'},
     }
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args)

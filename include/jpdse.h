@@ -253,6 +253,19 @@ int jpdse_onehot_edge(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t nu
                       const float* label, const int64_t* instance, void* dst, int32_t cs,
                       void* stream);
 
+/* The whole input builder of a train step in ONE pass (model.py:375-394 one-hot + edges, :595 and :456 the two torch.cat):
+ * for i < n_dst (1..3), dst[i] ([N,H,W,cs] NHWC) receives channels [0, num_labels) = one-hot(label), channel num_labels =
+ * instance edge, channels [c0, c0 + nch) = img[i] ([N,H,W,img_cs] NHWC, same dtype; NULL: those lanes are zeroed and filled
+ * in later by jpdse_insert_channels), every other lane zero.  The generator input and both halves of the discriminator
+ * input are three destinations of one call: the label planes are read once and no intermediate "base" tensor exists. */
+int jpdse_input_builder(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t num_labels, const float* label,
+                        const int64_t* instance, int32_t n_dst, void* const* dst, const void* const* img, int32_t cs,
+                        int32_t img_cs, int32_t c0, int32_t nch, void* stream);
+/* dst[..., c0 : c0 + nch] = img[..., 0 : nch] in place (the generated image into the discriminator input, model.py:456):
+ * touches only the 16-byte vectors of dst that hold those channels. */
+int jpdse_insert_channels(int32_t dtype, int64_t npix, void* dst, int32_t cs, const void* img, int32_t img_cs, int32_t c0,
+                          int32_t nch, void* stream);
+
 /* ---- losses ------------------------------------------------------------------------- */
 /* All reductions are fp32 and deterministic (two-stage).  `count` is the LOGICAL element
  * count the mean divides by (padding lanes are zero in both operands).

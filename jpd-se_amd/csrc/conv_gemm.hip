@@ -78,6 +78,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 }  // namespace jpdse
 #include "gemm_fast.h"
 #include "gemm_halo.h"
+#include "gemm_taps.h"
 #include "wgrad_fast.h"
 #include "wgrad_thin.h"
 #include "wgrad_nine.h"
@@ -1500,6 +1501,85 @@ static int launch_thin_in_rows(ThinInArgs a, hipStream_t s) {
   return JPDSE_OK;
 }
 
+// ---- tap-program halo kernel (gemm_taps.h): all four sub-pixel phases of a stride-2 data gradient / ConvTranspose forward
+JPDSE_SWITCH(int, g_taps_enabled, 1);       // 35: these layers on the merged-phase fast kernel (A/B)
+
+// 3x3 stride-2 (pad 1, even input): phases (0,0) 2x2 taps, (0,1) 2x1, (1,0) 1x2, (1,1) 1x1 over the same dy pixels
+static bool taps_dgrad2_ok(const jpdse_conv_desc* d, const ConvPlan& p, const void* mask, const void* addend, const float* mom) {
+  if (!(g_fast_enabled && g_taps_enabled) || d->dtype != JPDSE_BF16 || d->pad_mode == JPDSE_PAD_REFLECT) return false;
+  if (d->stride != 2 || d->R != 3 || d->S != 3 || d->pad != 1 || p.nph != 4) return false;
+  if (mask != nullptr || addend != nullptr || mom != nullptr) return false;
+  if (d->H != 2 * p.OH || d->W != 2 * p.OW || p.OH % 4 != 0 || p.OW % 64 != 0) return false;
+  if (p.Ks % 64 != 0 || p.Ks < 128 || p.Cs % 64 != 0) return false;
+  // the kernel's loaders carry 32-bit element offsets into dy and into each phase's panel
+  if ((long long)d->N * p.OH * p.OW * p.Ks >= (1LL << 31) || (long long)p.Cs * 4 * p.Ks >= (1LL << 31)) return false;
+  for (int i = 0; i < 4; ++i) {
+    const Phase& f = p.ph[i];
+    if (f.cnth != p.OH || f.cntw != p.OW || f.Lk != f.Uw * p.Ks) return false;
+    if (f.Uh != (f.qh == 0 ? 2 : 1) || f.Uw != (f.qw == 0 ? 2 : 1)) return false;
+    if ((f.Uh - 1) - f.i0h != 0 || (f.Uw - 1) - f.i0w != 0) return false;      // every phase starts at dy pixel (oh, ow)
+  }
+  return true;
+}
+
+template <int TN>
+static int launch_taps_dgrad2_cfg(const TapsArgs& a, int total, hipStream_t s) {
+  constexpr int PH = 5, PW = 65;
+  constexpr int lds = 2 * ((PH * PW + 7) / 8) * 1024 + 3 * (2 * TN * 32) * 128;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_taps_kernel<TN, 4, 1, 2, 2, 1, PH, PW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_taps: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_taps_kernel<TN, 4, 1, 2, 2, 1, PH, PW>), dim3(total), dim3(512), lds, s, a);
+  return check_launch("gemm_taps_kernel");
+}
+
+static int launch_taps_dgrad2(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx, hipStream_t s) {
+  TapsArgs a = {};
+  a.X = reinterpret_cast<const bf16_t*>(dy);
+  a.Y = reinterpret_cast<bf16_t*>(dx);
+  a.N = d->N;
+  a.OH = p.OH;
+  a.OW = p.OW;
+  a.IH = p.OH;
+  a.IW = p.OW;
+  a.Cs = p.Ks;
+  a.py = a.px = 0;
+  a.Kout = d->C;
+  a.Ks = p.Cs;
+  a.b_rows = p.Cs;
+  a.out_sn = (long long)d->H * d->W * p.Cs;
+  a.out_sh = 2LL * d->W * p.Cs;
+  a.out_sw = 2LL * p.Cs;
+  a.act = JPDSE_ACT_NONE;
+  // program 0 = {phase (0,0): 4 taps, phase (1,1): 1 tap}, program 1 = {phase (0,1): 2 taps, phase (1,0): 2 taps}
+  const Phase* byq[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  for (int i = 0; i < 4; ++i) byq[p.ph[i].qh][p.ph[i].qw] = &p.ph[i];
+  const Phase* sets[2][2] = {{byq[0][0], byq[1][1]}, {byq[0][1], byq[1][0]}};
+  constexpr int PW = 65;
+  for (int g = 0; g < 2; ++g) {
+    int t = 0;
+    for (int q = 0; q < 2; ++q) {
+      const Phase& f = *sets[g][q];
+      a.prog[g].B[q] = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
+      a.prog[g].ktot[q] = (long long)f.Uh * f.Lk;
+      a.prog[g].out_base[q] = ((long long)(2 * f.i0h + f.qh - d->pad) * d->W + (2 * f.i0w + f.qw - d->pad)) * p.Cs;
+      for (int u = 0; u < f.Uh; ++u)
+        for (int w = 0; w < f.Uw; ++w) {
+          a.prog[g].tap_off[t] = u * PW + w;
+          a.prog[g].tap_koff[t] = u * f.Lk + w * p.Ks;
+          ++t;
+        }
+    }
+  }
+  const int bn = p.Cs % 128 == 0 ? 128 : 64;
+  a.nblk0 = d->N * (p.OH / 4) * (p.OW / 64) * ((p.Cs + bn - 1) / bn);
+  return bn == 128 ? launch_taps_dgrad2_cfg<2>(a, 2 * a.nblk0, s) : launch_taps_dgrad2_cfg<1>(a, 2 * a.nblk0, s);
+}
+
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
 // gradient of the zero-padded ones): LDS-resident input halo, see gemm_halo.h
 static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_out) {
@@ -2268,6 +2348,9 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       return launch_thin_in_rows<7, true>(g, s);
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    if (taps_dgrad2_ok(d, p, mask, addend, mom)) return launch_taps_dgrad2(d, p, dy, pack, dx, s);
+  }
   bool fast = false;
   int nlive_phases = 0;
   if constexpr (sizeof(T) == 2) {
@@ -2984,6 +3067,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_moments_fused = enable != 32 && enable != 6;   // 32: InstanceNorm moments always in their own pass (A/B); 6 keeps the generic kernels' rounding points
   g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
   g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
+  g_taps_enabled = enable != 35;     // 35: stride-2 data gradients on the merged-phase fast kernel instead of the tap-program halo kernel (A/B)
   g_rows_enabled = enable != 29 && enable != 3;   // 29: 64-channel 3x3 layers on the halo / fast kernels instead of conv_rows (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_nine_sched = enable == 21 ? 0 : (enable == 22 ? 1 : (enable == 24 ? 2 : 3));   // 21 / 22 / 24: unpipelined loop forms of the nine-tap weight gradient (A/B); default 3 = software-pipelined fragment reads   // 21 / 22: DMA issue placement of the nine-tap weight gradient (A/B)

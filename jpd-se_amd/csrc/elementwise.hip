@@ -340,6 +340,84 @@ __global__ void onehot_edge_kernel(const float* __restrict__ label, const long l
   }
 }
 
+// The whole input builder in one pass: one-hot labels + instance edge + the image channels, written to up to three
+// destinations that differ only in the image (generator input with the decoded frame, discriminator input halves with the
+// real / the generated image) -- model.py:375-394 (one-hot, edges), :595 and :456 (the two torch.cat).  img[i] == nullptr
+// leaves the image lanes of destination i zero (the generated image does not exist yet: insert_channels_kernel fills it in).
+struct BuilderArgs {
+  const float* label;
+  const long long* inst;
+  void* dst[3];
+  const void* img[3];
+  int n_dst;
+  int H, W, nlab, cs, img_cs, c0, nch;
+};
+template <typename T>
+__global__ void input_builder_kernel(const BuilderArgs a, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = a.cs / VE;
+  GRID_STRIDE(idx, total_vec) {
+    const int c = (int)(idx % cv);
+    const long long pix = idx / cv;  // n*H*W + h*W + w
+    const int w = (int)(pix % a.W);
+    const int h = (int)((pix / a.W) % a.H);
+    const int lab = (int)(long long)a.label[pix];
+    const int cb = c * VE;
+    T v[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) ElemOps<T>::st(&v[e], (cb + e == lab && lab < a.nlab) ? 1.f : 0.f);
+    if (a.nlab >= cb && a.nlab < cb + VE) {
+      const long long me = a.inst[pix];
+      bool edge = false;
+      if (w > 0) edge |= a.inst[pix - 1] != me;
+      if (w < a.W - 1) edge |= a.inst[pix + 1] != me;
+      if (h > 0) edge |= a.inst[pix - a.W] != me;
+      if (h < a.H - 1) edge |= a.inst[pix + a.W] != me;
+      ElemOps<T>::st(&v[a.nlab - cb], edge ? 1.f : 0.f);
+    }
+    const bool has_img = cb + VE > a.c0 && cb < a.c0 + a.nch;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i >= a.n_dst) break;
+      T o[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o[e] = v[e];
+      if (has_img) {
+        const T* img = reinterpret_cast<const T*>(a.img[i]);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+          const int ch = cb + e;
+          if (ch >= a.c0 && ch < a.c0 + a.nch) {
+            if (img != nullptr) o[e] = img[pix * a.img_cs + (ch - a.c0)];
+            else ElemOps<T>::st(&o[e], 0.f);
+          }
+        }
+      }
+      *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.dst[i]) + idx * VE) = *reinterpret_cast<const u32x4*>(o);
+    }
+  }
+}
+
+// dst[..., c0 : c0 + nch] = img[..., 0 : nch] in place: only the 16-byte vectors of dst that hold those channels are touched
+template <typename T>
+__global__ void insert_channels_kernel(T* __restrict__ dst, const T* __restrict__ img, int cs, int img_cs, int c0, int nch,
+                                       int v0, int nv, long long total) {
+  constexpr int VE = Vec16<T>::N;
+  GRID_STRIDE(idx, total) {
+    const int v = v0 + (int)(idx % nv);
+    const long long p = idx / nv;
+    const int cb = v * VE;
+    T tmp[VE];
+    *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(dst + p * cs + cb);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const int c = cb + e;
+      if (c >= c0 && c < c0 + nch) tmp[e] = img[p * img_cs + (c - c0)];
+    }
+    *reinterpret_cast<u32x4*>(dst + p * cs + cb) = *reinterpret_cast<const u32x4*>(tmp);
+  }
+}
+
 // ---- loss reductions (deterministic two-stage) --------------------------------------------------
 enum { RED_L1 = 0, RED_MSE = 1, RED_MSE_CONST = 2 };
 static constexpr int kRedBlocks = 1024;
@@ -769,6 +847,54 @@ int jpdse_onehot_edge(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t nu
     hipLaunchKernelGGL((onehot_edge_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream), label,
                        reinterpret_cast<const long long*>(instance), mptr<float>(dst), H, W, num_labels, cs, tv);
   return check_launch("onehot_edge");
+}
+
+int jpdse_input_builder(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t num_labels, const float* label,
+                        const int64_t* instance, int32_t n_dst, void* const* dst, const void* const* img, int32_t cs,
+                        int32_t img_cs, int32_t c0, int32_t nch, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && label && instance && dst && img && N > 0 && H > 0 && W > 0, "input_builder: bad argument");
+  JPDSE_REQUIRE(n_dst >= 1 && n_dst <= 3, "input_builder: 1..3 destinations");
+  JPDSE_REQUIRE(num_labels >= 0 && num_labels < cs && cs % 8 == 0 && img_cs % 8 == 0, "input_builder: bad channel counts");
+  JPDSE_REQUIRE(nch > 0 && nch <= img_cs && c0 >= 0 && c0 + nch <= cs, "input_builder: image channels [%d, %d) outside 0..%d", c0, c0 + nch, cs);
+  BuilderArgs a = {};
+  a.label = label;
+  a.inst = reinterpret_cast<const long long*>(instance);
+  for (int i = 0; i < n_dst; ++i) {
+    JPDSE_REQUIRE(dst[i] != nullptr, "input_builder: destination %d is null", i);
+    a.dst[i] = dst[i];
+    a.img[i] = img[i];
+  }
+  a.n_dst = n_dst;
+  a.H = H;
+  a.W = W;
+  a.nlab = num_labels;
+  a.cs = cs;
+  a.img_cs = img_cs;
+  a.c0 = c0;
+  a.nch = nch;
+  const long long tv = (long long)N * H * W * (cs / (16 / (int)esize(dtype)));
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((input_builder_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream), a, tv);
+  else
+    hipLaunchKernelGGL((input_builder_kernel<float>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream), a, tv);
+  return check_launch("input_builder");
+}
+
+int jpdse_insert_channels(int32_t dtype, int64_t npix, void* dst, int32_t cs, const void* img, int32_t img_cs, int32_t c0,
+                          int32_t nch, void* stream) {
+  JPDSE_REQUIRE(!bad_dtype(dtype) && dst && img && npix > 0, "insert_channels: bad argument");
+  JPDSE_REQUIRE(cs % 8 == 0 && img_cs % 8 == 0 && nch > 0 && nch <= img_cs && c0 >= 0 && c0 + nch <= cs,
+                "insert_channels: channels [%d, %d) outside 0..%d", c0, c0 + nch, cs);
+  const int VE = 16 / (int)esize(dtype);
+  const int v0 = c0 / VE, v1 = (c0 + nch - 1) / VE, nv = v1 - v0 + 1;
+  const long long total = (long long)npix * nv;
+  if (dtype == JPDSE_BF16)
+    hipLaunchKernelGGL((insert_channels_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                       mptr<bf16_t>(dst), cptr<bf16_t>(img), cs, img_cs, c0, nch, v0, nv, total);
+  else
+    hipLaunchKernelGGL((insert_channels_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
+                       mptr<float>(dst), cptr<float>(img), cs, img_cs, c0, nch, v0, nv, total);
+  return check_launch("insert_channels");
 }
 
 size_t jpdse_loss_workspace_size(int64_t n) { return kRedBlocks * sizeof(float); }

@@ -252,10 +252,11 @@ class Pix2PixHDModel(BaseModel):
     return codec.compress_images(x_dict['image'], self.opt, tmp_folder)
 
   # ---- input builder ------------------------------------------------------------------------
-  def preprocess(self, x_dict):
+  def preprocess(self, x_dict, build_base=True):
     """x_dict (CPU or cuda tensors from the loader) -> NHWC device activations.
-    Returns dict(base=Act[B,H,W,label_nc+3] with one-hot+edge filled (model.py:375-394),
-    real=Act 3ch, src=Act 3ch (decoded frame when use_compressed else real))."""
+    Returns dict(base=Act[B,H,W,label_nc+3] with one-hot+edge filled (model.py:375-394) -- None when build_base is False:
+    the train step writes the network inputs directly (ops.input_builder) --, real=Act 3ch, src=Act 3ch (decoded frame
+    when use_compressed else real), label / inst = the device label and instance maps)."""
     dev = self._device()
     opt = self.opt
     comp = None
@@ -269,12 +270,12 @@ class Pix2PixHDModel(BaseModel):
     if getattr(opt, 'no_instance', False):
       inst = torch.zeros_like(inst)      # a constant map has no edges; its channel is not part of label_nc
     total_c = self.label_nc + opt.input_nc
-    base = ops.onehot_edge(label, inst, self.n_onehot, total_c, self.cdtype)
+    base = ops.onehot_edge(label, inst, self.n_onehot, total_c, self.cdtype) if build_base else None
     real = ops.nchw_to_nhwc(image, self.cdtype)
     src = real
     if comp is not None:
       src = ops.nchw_to_nhwc(comp.to(dev, dtype=torch.float32, non_blocking=True).contiguous(), self.cdtype)
-    return dict(base=base, real=real, src=src, image_nchw=image)
+    return dict(base=base, real=real, src=src, image_nchw=image, label=label, inst=inst, total_c=total_c)
 
   def _with_image(self, base, img, out=None):
     """torch.cat((input_label, img), dim=1) in NHWC: copy of `base` with the image channels filled."""
@@ -309,29 +310,45 @@ class Pix2PixHDModel(BaseModel):
     (jpdse_l1_fwd_bwd) and handed to backward_G through `state`."""
     opt = self.opt
     dev = self._device()
-    pre = self.preprocess(x_dict)
-    base, real, src = pre['base'], pre['real'], pre['src']
-    B = base.N
-    fake, g_ctx = self.netG.fwd(self._with_image(base, src))
-
     skip = bool(getattr(opt, 'skip_unused_losses', False))
     run_d = not (skip and opt.no_g_gan_loss and opt.no_gan_feat_loss and opt.no_d_gan_loss)
     run_vgg = not (skip and opt.no_vgg_loss)
 
-    # one batched discriminator pass: [label|fake ; label|real]  (model.py:717,722,733)
+    # Input builder, one pass (ops.input_builder): the generator input [label | edge | decoded frame] and both halves of the
+    # ONE batched discriminator pass [label | edge | fake ; label | edge | real] (model.py:375-394, 595, 456, 717-733) are
+    # written straight from the label / instance maps; the fake half gets its image channels once G has produced them.
+    pre = self.preprocess(x_dict, build_base=False)
+    real, src, label, inst = pre['real'], pre['src'], pre['label'], pre['inst']
+    B, H, W = real.N, real.H, real.W
+    g_in = Act.empty(B, H, W, pre['total_c'], self.cdtype, dev)
+    d_in = Act.empty(2 * B, H, W, pre['total_c'], self.cdtype, dev) if run_d else None
+    if run_d:
+      ops.input_builder(label, inst, self.n_onehot, [g_in, d_in.batch_slice(B, 2 * B), d_in.batch_slice(0, B)],
+                        [src, real, None], self.label_nc)
+    else:
+      ops.input_builder(label, inst, self.n_onehot, [g_in], [src], self.label_nc)
+    fake, g_ctx = self.netG.fwd(g_in)
+
     pred, d_ctx = None, None
     if run_d:
-      d_in = Act.empty(2 * B, base.H, base.W, base.C, self.cdtype, dev)
-      self._with_image(base, fake, out=d_in.batch_slice(0, B))
-      self._with_image(base, real, out=d_in.batch_slice(B, 2 * B))
+      ops.insert_channels(d_in.batch_slice(0, B), fake, self.label_nc)
       pred, d_ctx = self.netD.fwd(d_in)
 
     vf, vr, v_ctx = [], [], None
     n_vgg = len(networks.VGGLoss.weights)
     if run_vgg:
+      # VGG19 on the generated and the real image as ONE pass over [fake ; real] (networks.py:124-139 runs vgg(x), vgg(y)):
+      # the convolutions are per image, so the two halves of every feature map equal the two separate passes bit for bit,
+      # the launch count halves and the deep, small layers (relu5_1: 32x64 pixels) fill the chip.  Backward goes through the
+      # fake half of the saved tensors only (Ctx.slice).
       vgg = self.criterionVGG.vgg
-      vf, v_ctx = vgg.fwd(fake, save=not opt.no_vgg_loss)
-      vr, _ = vgg.fwd(real, save=False)
+      both = Act.empty(2 * B, H, W, fake.C, self.cdtype, dev)
+      both.t[:B].copy_(fake.t)               # two 33 MB device-to-device copies (memory plumbing, no arithmetic)
+      both.t[B:].copy_(real.t)
+      maps, ctxs = vgg.fwd(both, save=not opt.no_vgg_loss)
+      vf = [m.batch_slice(0, B) for m in maps]
+      vr = [m.batch_slice(B, 2 * B) for m in maps]
+      v_ctx = [c.slice(0, B) if c is not None else None for c in ctxs] if not opt.no_vgg_loss else None
 
     nD, nF = opt.num_D, opt.n_layers_D + 1
     layout = dict(D_fake=list(range(0, nD)), D_real=list(range(nD, 2 * nD)), G_GAN=list(range(2 * nD, 3 * nD)))

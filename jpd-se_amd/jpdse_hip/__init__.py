@@ -101,6 +101,9 @@ SIGNATURES = {
     'jpdse_nchw_to_nhwc': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     'jpdse_nhwc_to_nchw': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     'jpdse_onehot_edge': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
+    'jpdse_input_builder': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _I32, ctypes.POINTER(_P), ctypes.POINTER(_P), _I32, _I32,
+                                   _I32, _I32, _P]),
+    'jpdse_insert_channels': (_I32, [_I32, _I64, _P, _I32, _P, _I32, _I32, _I32, _P]),
     'jpdse_loss_workspace_size': (_SZ, [_I64]),
     'jpdse_l1_fwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_l1_bwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),

@@ -284,11 +284,13 @@ def concat_channels(base, img, c0, out):
   return out
 
 
-def nchw_to_nhwc(src, dtype_code):
-  """fp32 NCHW device tensor -> Act."""
+def nchw_to_nhwc(src, dtype_code, out=None):
+  """fp32 NCHW device tensor -> Act (into `out` when given: an Act of the same shape, e.g. a batch slice of a larger one)."""
   assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 4
   N, C, H, W = src.shape
-  out = Act.empty(N, H, W, C, dtype_code, src.device)
+  if out is None:
+    out = Act.empty(N, H, W, C, dtype_code, src.device)
+  assert tuple(out.t.shape) == (N, H, W, cpad(C)) and out.dtype == dtype_code
   check(lib().jpdse_nchw_to_nhwc(dtype_code, N, C, H, W, _p(src), _p(out.t), _stream()), 'nchw_to_nhwc')
   return out
 
@@ -309,6 +311,33 @@ def onehot_edge(label, instance, num_labels, total_c, dtype_code):
   check(lib().jpdse_onehot_edge(dtype_code, N, H, W, num_labels, _p(label), _p(instance), _p(out.t), out.Cs, _stream()),
         'onehot_edge')
   return out
+
+
+def input_builder(label, instance, num_labels, dsts, imgs, c0):
+  """One pass: every Act of `dsts` (same N,H,W,C) gets one-hot(label) | edge(instance) | its image of `imgs` (Act or None)
+  at channels [c0, c0 + 3).  Replaces onehot_edge + one concat_channels per destination."""
+  assert label.dtype == torch.float32 and instance.dtype == torch.int64 and label.is_contiguous() and instance.is_contiguous()
+  assert 1 <= len(dsts) <= 3 and len(imgs) == len(dsts)
+  N, _, H, W = label.shape
+  d0 = dsts[0]
+  present = [im for im in imgs if im is not None]
+  img_cs, nch = (present[0].Cs, present[0].C) if present else (8, 3)
+  for d, im in zip(dsts, imgs):
+    assert tuple(d.t.shape) == tuple(d0.t.shape) and d.t.shape[:3] == (N, H, W) and d.dtype == d0.dtype
+    assert im is None or (im.Cs == img_cs and im.C == nch and im.dtype == d0.dtype and im.t.shape[:3] == (N, H, W))
+  arr = ctypes.c_void_p * len(dsts)
+  check(lib().jpdse_input_builder(d0.dtype, N, H, W, num_labels, _p(label), _p(instance), len(dsts),
+                                  arr(*[d.t.data_ptr() for d in dsts]), arr(*[(im.t.data_ptr() if im is not None else None) for im in imgs]),
+                                  d0.Cs, img_cs, c0, nch, _stream()), 'input_builder')
+  return dsts
+
+
+def insert_channels(dst, img, c0):
+  """dst[..., c0 : c0 + img.C] = img in place."""
+  assert dst.t.shape[:3] == img.t.shape[:3] and dst.dtype == img.dtype
+  npix = dst.N * dst.H * dst.W
+  check(lib().jpdse_insert_channels(dst.dtype, npix, _p(dst.t), dst.Cs, _p(img.t), img.Cs, c0, img.C, _stream()), 'insert_channels')
+  return dst
 
 
 # ---- losses -------------------------------------------------------------------------------------

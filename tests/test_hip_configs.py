@@ -28,7 +28,7 @@ def _opts(**kw):
   return omodel.default_opt(gpu_ids=[0], print_losses=False, **kw)
 
 
-def _adjointness(name, N, H, W, C, K, k, st, pad, mode, seeds=(0,)):
+def _adjointness(name, N, H, W, C, K, k, st, pad, mode, seeds=(0, 1, 2)):
   """<conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)> on the bf16 kernels (hip_util.adjointness: per-layer bounds)."""
   from hip_util import adjointness
   return adjointness(name, N, H, W, C, K, k, st, pad, mode, seeds=seeds)
@@ -178,7 +178,7 @@ def test_1024x512_layer0_image_slice_gradient_is_the_adjoint_of_the_slice_bf16()
   scale = (dot(y.t, y.t) * dot(dy.t, dy.t)) ** 0.5
   import hip_util
   bound = hip_util.ADJ_BOUND.get('d_layer0_slice', hip_util.ADJ_DEFAULT)
-  hip_util.record('d_layer0_slice adjointness |<y,dy>-<x,dx>| / (|y||dy|)', abs(lhs - rhs) / scale, bound)
+  hip_util.record('adjointness <y,dy> vs <x,dx>: d_layer0_slice', abs(lhs - rhs) / scale, bound)
   assert abs(lhs - rhs) <= bound * scale, (lhs, rhs, scale)
 
 

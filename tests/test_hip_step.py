@@ -329,7 +329,7 @@ def test_bf16_local_enhancer_full_width_in_situ():
   1024-channel trunk at 1/32 resolution) in bf16 at 128x256: the all-taps weight gradient, the head kernels with
   32-channel inputs and split-K run in situ.  Yardstick: the fp32 HIP path on the same weights and batch
   (itself checked against the oracle by the golden tests): losses within 2 %, every weight gradient with
-  cosine >= 0.83 (bf16 storage noise, see test_bf16_full_width_fast_kernels_in_situ) and norm within 6 %."""
+  cosine >= 0.85 (bf16 storage noise, see test_bf16_full_width_fast_kernels_in_situ) and norm within 6 %."""
   kw = dict(netG='local', ngf=32)
   xd = omodel.synthetic_batch(1, 128, 256, seed=33)
   opt32 = _opts(**kw)
@@ -354,9 +354,12 @@ def test_bf16_local_enhancer_full_width_in_situ():
       continue
     a = p.grad.detach().cpu().double().flatten()
     c = cos(a, g32[k])
-    # the deep layers sit at 0.849-0.860 (with and without the fused InstanceNorm moments: developer modes 1 / 32): noise floor of
-    # bf16 storage at random init, not a property of any one kernel -- the bound leaves 0.02 below it
-    assert c >= 0.83, '%s: bf16 vs fp32 weight-gradient cosine %.4f' % (k, c)
+    # the deep layers are the lowest: measured per kernel-selection mode (scripts/diag_cos_modes.py, round 3) 0.8505 with the
+    # shipped selection, 0.8510 without the row-streaming kernels (mode 29), 0.8531 without the fused InstanceNorm moments
+    # (mode 32) -- the noise floor of bf16 storage at random init, not a property of any one kernel.  Round 2's fused moments
+    # were taken from the un-rounded accumulators and sat at 0.849 (bound lowered to 0.83 then); with the moments of the
+    # stored values (common.h) every mode meets the original 0.85 again.
+    assert c >= 0.85, '%s: bf16 vs fp32 weight-gradient cosine %.4f' % (k, c)
     assert abs(float(a.norm() / g32[k].norm()) - 1.0) < 6e-2, k
 
 
