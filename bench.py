@@ -253,9 +253,9 @@ def main():
   if args.late_readback:
     trainer.model.early_loss_readback = False
   # In-library kernel timers (hipEvent pairs on the kernels' own stream, inside the timed region).  Every event costs the
-  # stream ~3.7 us (measured round 3: 296 events per step = 1.1 ms of a 26.3 ms step), so they cover the FIRST `timed_steps`
-  # steps of the timed region only -- one step holds 36 ResnetBlock GEMM launches, 18 weight gradients, 72 norm calls.
-  timed_steps = 0 if args.no_kernel_timers else min(2, args.steps)
+  # stream ~3.7 us (measured round 3: 296 events per step = 1.1 ms of a 26.3 ms step), so they cover the FIRST
+  # step of the timed region only -- one step holds 36 ResnetBlock GEMM launches, 18 weight gradients, 72 norm calls.
+  timed_steps = 0 if args.no_kernel_timers else min(1, args.steps)
   tsteps = max(timed_steps, 1)
   if timed_steps:
     check(L.jpdse_prof_select(1, 1024, 9216, 72 * timed_steps), 'prof_select')        # 36 halo + 18 ring + 18 wgrad regions per step

@@ -1580,6 +1580,144 @@ static int launch_taps_dgrad2(const jpdse_conv_desc* d, const ConvPlan& p, const
   return bn == 128 ? launch_taps_dgrad2_cfg<2>(a, 2 * a.nblk0, s) : launch_taps_dgrad2_cfg<1>(a, 2 * a.nblk0, s);
 }
 
+// ---- 4x4 stride-1 zero-padded convs and their (single-phase) data gradient on the tap-program kernel: PatchGAN layer 3 of
+// both scales (networks.py:430-449).  Their grids are odd (66 x 130, 34 x 66): the kernel's 8 x 32 tiles cover the CORE
+// (64 x 128: 95 % of the pixels) with the 11 x 35 input patch staged once per 64-channel slab for all 16 taps; the fringe (the
+// last OH % 8 rows, the last OW % 32 columns) runs as two sub-rectangle problems of ONE split-K launch of gemm_fast_kernel
+// (fp32 slabs, fixed summation order) + its finish kernels.
+JPDSE_SWITCH(int, g_taps4_enabled, 1);      // 36: these layers on the fast kernel alone (A/B)
+
+struct Taps4View {            // a stride-1 4x4 conv as the kernels see it: forward, or the data gradient over dy
+  const bf16_t* X; const bf16_t* B; const float* bias; bf16_t* Y;
+  int N, IH, IW, Cin_s, OH, OW, py, px, Kout, Ks_out;
+  long long ktot;             // panel row stride (elements)
+  int tap_r, tap_s;           // panel offsets per filter-row / filter-column step
+  int act; float slope;
+};
+
+static bool taps4_shape_ok(int R, int S, int stride, int OH, int OW, int Cin_s, int Ks_out, long long x_elems, long long b_elems) {
+  return g_fast_enabled && g_taps4_enabled && R == 4 && S == 4 && stride == 1 && OH >= 8 && OW >= 32 && Cin_s % 64 == 0 &&
+         Cin_s >= 128 && Ks_out % 64 == 0 && Ks_out >= 64 && x_elems < (1LL << 31) && b_elems < (1LL << 31);
+}
+
+static int taps4_fringe_splits(int N, int OH, int OW, int Ks_out, int k_tiles) {
+  const int OHc = OH / 8 * 8, OWc = OW / 32 * 32;
+  const long long m_bot = (long long)N * (OH - OHc) * OW, m_right = (long long)N * OHc * (OW - OWc);
+  const long long nt = (Ks_out + 127) / 128;
+  const long long tiles = ((m_bot + 255) / 256 + (m_right + 255) / 256) * nt;
+  if (tiles <= 0) return 0;
+  long long sp = 256 / tiles;
+  if (sp > k_tiles / 8) sp = k_tiles / 8;
+  if (sp > 8) sp = 8;
+  return sp < 1 ? 1 : (int)sp;
+}
+
+static size_t taps4_fringe_bytes(int N, int OH, int OW, int Ks_out, int k_tiles) {
+  const int OHc = OH / 8 * 8, OWc = OW / 32 * 32;
+  const long long m = (long long)N * (OH - OHc) * OW + (long long)N * OHc * (OW - OWc);
+  return (size_t)taps4_fringe_splits(N, OH, OW, Ks_out, k_tiles) * m * Ks_out * sizeof(float);
+}
+
+template <int TN>
+static int launch_taps4_cfg(const TapsArgs& a, int total, hipStream_t s) {
+  constexpr int PH = 11, PW = 35;
+  constexpr int lds = 2 * ((PH * PW + 7) / 8) * 1024 + 3 * (2 * TN * 32) * 128;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_taps_kernel<TN, 16, 0, 0, 0, 2, PH, PW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_taps(4x4): hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_taps_kernel<TN, 16, 0, 0, 0, 2, PH, PW>), dim3(total), dim3(512), lds, s, a);
+  return check_launch("gemm_taps_kernel(4x4)");
+}
+
+static int launch_taps4(const Taps4View& v, void* ws, hipStream_t s) {
+  const int OHc = v.OH / 8 * 8, OWc = v.OW / 32 * 32;
+  TapsArgs a = {};
+  a.X = v.X;
+  a.Y = v.Y;
+  a.bias = v.bias;
+  a.N = v.N;
+  a.OH = OHc;
+  a.OW = OWc;
+  a.IH = v.IH;
+  a.IW = v.IW;
+  a.Cs = v.Cin_s;
+  a.py = v.py;
+  a.px = v.px;
+  a.Kout = v.Kout;
+  a.Ks = v.Ks_out;
+  a.b_rows = v.Ks_out;
+  a.out_sn = (long long)v.OH * v.OW * v.Ks_out;
+  a.out_sh = (long long)v.OW * v.Ks_out;
+  a.out_sw = v.Ks_out;
+  a.act = v.act;
+  a.slope = v.slope;
+  a.prog[0].B[0] = v.B;
+  a.prog[0].ktot[0] = v.ktot;
+  a.prog[0].out_base[0] = 0;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      a.prog[0].tap_off[r * 4 + c] = r * 35 + c;
+      a.prog[0].tap_koff[r * 4 + c] = r * v.tap_r + c * v.tap_s;
+    }
+  const int bn = v.Ks_out % 128 == 0 ? 128 : 64;
+  a.nblk0 = v.N * (OHc / 8) * (OWc / 32) * ((v.Ks_out + bn - 1) / bn);
+  if (int rc = bn == 128 ? launch_taps4_cfg<2>(a, a.nblk0, s) : launch_taps4_cfg<1>(a, a.nblk0, s)) return rc;
+  // fringe: bottom rows [OHc, OH) x all columns, right columns [OWc, OW) x rows [0, OHc)
+  const int k_tiles = 16 * v.Cin_s / 64;
+  const int sp = taps4_fringe_splits(v.N, v.OH, v.OW, v.Ks_out, k_tiles);
+  if (sp == 0) return JPDSE_OK;
+  FastBatch fb = {};
+  float* slab = reinterpret_cast<float*>(ws);
+  const int rect[2][4] = {{OHc, 0, v.OH - OHc, v.OW}, {0, OWc, OHc, v.OW - OWc}};     // oh0, ow0, rows, cols
+  for (int q = 0; q < 2; ++q) {
+    const int oh0 = rect[q][0], ow0 = rect[q][1], rows = rect[q][2], cols = rect[q][3];
+    if (rows <= 0 || cols <= 0) continue;
+    FastArgs g = {};
+    g.X = v.X;
+    g.B = v.B;
+    g.bias = v.bias;
+    g.Y = v.Y;
+    g.M = v.N * rows * cols;
+    g.OH = rows;
+    g.OW = cols;
+    g.IH = v.IH;
+    g.IW = v.IW;
+    g.Cs = v.Cin_s;
+    g.R = g.S = 4;
+    g.sy = g.sx = 1;
+    g.py = v.py - oh0;
+    g.px = v.px - ow0;
+    g.reflect = 0;
+    g.Kout = v.Kout;
+    g.Ks = v.Ks_out;
+    g.b_rows = v.Ks_out;
+    g.out_sn = a.out_sn;
+    g.out_sh = a.out_sh;
+    g.out_sw = a.out_sw;
+    g.out_base = ((long long)oh0 * v.OW + ow0) * v.Ks_out;
+    g.act = v.act;
+    g.slope = v.slope;
+    g.splits = sp;
+    g.no_finish = 1;
+    g.partial = slab;
+    g.b_stride = v.ktot;
+    g.b_tap_r = v.tap_r;
+    g.b_tap_s = v.tap_s;
+    slab += (size_t)sp * g.M * v.Ks_out;
+    fb.p[fb.n++] = g;
+  }
+  if (int rc = launch_fast_batch(fb, s)) return rc;
+  for (int q = 0; q < fb.n; ++q) {
+    const long long total_vec = (long long)fb.p[q].M * (fb.p[q].Ks / 8);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(ew_blocks(total_vec)), dim3(256), 0, s, fb.p[q], total_vec);
+  }
+  return check_launch("taps4 fringe finish");
+}
+
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
 // gradient of the zero-padded ones): LDS-resident input halo, see gemm_halo.h
 static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_out) {
@@ -1862,6 +2000,29 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       r.slope = d->slope;
       r.mom = mom;
       return launch_rows(r, d->stride, s);
+    }
+    if (d->pad_mode != JPDSE_PAD_REFLECT && p.Lk_fwd == d->S * p.Cs && mom == nullptr &&
+        taps4_shape_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks, (long long)d->N * d->H * d->W * p.Cs, (long long)p.Ks * 16 * p.Cs)) {
+      Taps4View v = {};
+      v.X = reinterpret_cast<const bf16_t*>(x);
+      v.B = reinterpret_cast<const bf16_t*>(pack);
+      v.bias = bias;
+      v.Y = reinterpret_cast<bf16_t*>(y);
+      v.N = d->N;
+      v.IH = d->H;
+      v.IW = d->W;
+      v.Cin_s = p.Cs;
+      v.OH = p.OH;
+      v.OW = p.OW;
+      v.py = v.px = d->pad;
+      v.Kout = d->K;
+      v.Ks_out = p.Ks;
+      v.ktot = (long long)d->R * p.Lk_fwd;
+      v.tap_r = p.Lk_fwd;
+      v.tap_s = p.Cs;
+      v.act = d->act;
+      v.slope = d->slope;
+      return launch_taps4(v, ws, s);
     }
     if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks)) {
       HaloArgs h = {};
@@ -2350,6 +2511,30 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   }
   if constexpr (sizeof(T) == 2) {
     if (taps_dgrad2_ok(d, p, mask, addend, mom)) return launch_taps_dgrad2(d, p, dy, pack, dx, s);
+    if (!refl && p.nph == 1 && st == 1 && mask == nullptr && addend == nullptr && mom == nullptr && p.ph[0].cnth == d->H &&
+        p.ph[0].cntw == d->W && p.ph[0].Lk == p.ph[0].Uw * p.Ks &&
+        taps4_shape_ok(p.ph[0].Uh, p.ph[0].Uw, 1, d->H, d->W, p.Ks, p.Cs, (long long)d->N * p.OH * p.OW * p.Ks, (long long)p.Cs * 16 * p.Ks)) {
+      const Phase& f = p.ph[0];
+      Taps4View v = {};
+      v.X = reinterpret_cast<const bf16_t*>(dy);
+      v.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
+      v.Y = reinterpret_cast<bf16_t*>(dx);
+      v.N = d->N;
+      v.IH = p.OH;
+      v.IW = p.OW;
+      v.Cin_s = p.Ks;
+      v.OH = d->H;
+      v.OW = d->W;
+      v.py = (f.Uh - 1) - f.i0h;
+      v.px = (f.Uw - 1) - f.i0w;
+      v.Kout = d->C;
+      v.Ks_out = p.Cs;
+      v.ktot = (long long)f.Uh * f.Lk;
+      v.tap_r = f.Lk;
+      v.tap_s = p.Ks;
+      v.act = JPDSE_ACT_NONE;
+      return launch_taps4(v, ws, s);
+    }
   }
   bool fast = false;
   int nlive_phases = 0;
@@ -3067,7 +3252,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_moments_fused = enable != 32 && enable != 6;   // 32: InstanceNorm moments always in their own pass (A/B); 6 keeps the generic kernels' rounding points
   g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
   g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
-  g_taps_enabled = enable != 35;     // 35: stride-2 data gradients on the merged-phase fast kernel instead of the tap-program halo kernel (A/B)
+  g_taps4_enabled = enable != 36 && enable != 6;   // 36: 4x4 stride-1 layers on the fast kernel alone (A/B)
+  g_taps_enabled = enable != 35 && enable != 6;   // 35: stride-2 data gradients on the merged-phase fast kernel instead of the tap-program halo kernel (A/B); 6 keeps the generic kernels' summation order (tap outer, slab inner)
   g_rows_enabled = enable != 29 && enable != 3;   // 29: 64-channel 3x3 layers on the halo / fast kernels instead of conv_rows (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
   g_nine_sched = enable == 21 ? 0 : (enable == 22 ? 1 : (enable == 24 ? 2 : 3));   // 21 / 22 / 24: unpipelined loop forms of the nine-tap weight gradient (A/B); default 3 = software-pipelined fragment reads   // 21 / 22: DMA issue placement of the nine-tap weight gradient (A/B)
@@ -3191,6 +3377,12 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   if (p.ES == 2 && d->pad_mode == JPDSE_PAD_REFLECT && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1) {
     const size_t ring = (size_t)8 * d->N * (2 * (d->W + 2) + 2 * d->H) * p.Cs * 4;   // ring-strip slabs, <= 8 splits
     sk = sk > ring ? sk : ring;
+  }
+  if (p.ES == 2 && d->R == 4 && d->S == 4 && d->stride == 1) {          // fringe slabs of the 4x4 tap-program path (forward / data gradient)
+    const size_t f4 = taps4_fringe_bytes(d->N, p.OH, p.OW, p.Ks, 16 * p.Cs / 64);
+    const size_t d4 = taps4_fringe_bytes(d->N, d->H, d->W, p.Cs, 16 * p.Ks / 64);
+    sk = sk > f4 ? sk : f4;
+    sk = sk > d4 ? sk : d4;
   }
   size_t m = fwd > dgrad ? fwd : dgrad;
   if (p.ES == 2 && d->stride == 1 && d->K * d->R * d->S <= 32) {      // Z of the tap-sum forward (tapsum_kernel)

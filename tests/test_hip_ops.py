@@ -108,6 +108,12 @@ CONV_CASES = [
     ('tapsprog_256_512', 1, 8,  128, 256, 512, 3, 2, 1, PAD_ZERO,    ACT_RELU),
     ('tapsprog_64_256',  1, 8,  128, 64,  256, 3, 2, 1, PAD_ZERO,    ACT_NONE),
     ('tapsprog_128_320', 1, 24, 128, 128, 320, 3, 2, 1, PAD_ZERO,    ACT_NONE),
+    # 4x4 stride-1 layers on the tap-program kernel (8 x 32 tiles over the core, 16 taps per slab) + split-K fringe: odd grids
+    # with both fringe rectangles (PatchGAN layer 3: 17 x 33 -> 18 x 34 out, core 16 x 32), a core-only grid (forward 16 x 64,
+    # its data gradient 15 x 63 has both fringes), 64-wide output tile with bias + LeakyReLU, batch 2, 128 / 256-channel inputs
+    ('taps4_l3_small',  2, 17, 33,  256, 512, 4, 1, 2, PAD_ZERO,     ACT_NONE),
+    ('taps4_core_only', 1, 15, 63,  128, 128, 4, 1, 2, PAD_ZERO,     ACT_NONE),
+    ('taps4_n64_lrelu', 2, 9,  40,  128, 64,  4, 1, 2, PAD_ZERO,     ACT_LRELU),
     # filter-in-registers row-streaming kernel (conv_rows.h: 64-channel inputs, 3x3, zero pad): stride 2 with 128 / 64
     # outputs (4 x 1 / 2 x 2 waves), stride 1 likewise; several strips, several bands, bands of 16 rows (steady-state
     # look-ahead), borders on every side; the data gradient of the 64-output cases runs on it too
