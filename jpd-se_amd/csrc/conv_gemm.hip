@@ -1260,14 +1260,14 @@ JPDSE_SWITCH(int, g_halo_single, 1);
 JPDSE_SWITCH(int, g_halo_enabled, 1);
 JPDSE_SWITCH(int, g_halo_abl, 0);
 
-template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false>
+template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false>
 static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   constexpr int BN = 2 * TN * 32;
   constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
   constexpr int lds = (SINGLE ? 1 : 2) * UH * 1024 + 3 * BN * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -1278,7 +1278,7 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE>), dim3(tiles), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM>), dim3(tiles), dim3(512), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
@@ -1296,6 +1296,9 @@ template <int TN, int ABL = 0>
 static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
   HaloArgs a = a0;
   a.xcd_mode = g_halo_xcd;
+  if (a.mom != nullptr) {                 // conv -> InstanceNorm with the moments in this kernel's epilogue (double-buffered form)
+    if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, false, false, true>(a, s);
+  }
 #ifdef JPDSE_DEV
   if (ABL == 0 && g_halo_mf16) {
     if (a.Cs == 64 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, true>(a, s);
@@ -1849,6 +1852,11 @@ static int conv_fwd_moment_slots(const jpdse_conv_desc* d, const ConvPlan& p) {
     const int th = rows_band_height(d->N, p.OH, strips, n_tiles, 256LL * ((d->stride == 1 && WC == 2) ? 2 : 1));
     return (p.OH / th) * strips * (4 / WC);
   }
+  if (d->pad_mode != JPDSE_PAD_REFLECT && p.Lk_fwd == d->S * p.Cs &&
+      taps4_shape_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks, (long long)d->N * d->H * d->W * p.Cs, (long long)p.Ks * 16 * p.Cs))
+    return 0;
+  // halo kernel (double-buffered form: inputs of 128+ channels): one slot per 4 x 64 output patch
+  if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks) && p.Cs > 64 && g_halo_abl == 0) return (p.OH / 4) * (p.OW / 64);
   return 0;
 }
 static bool dgrad2_rows_takes(const jpdse_conv_desc* d, const ConvPlan& p) {
@@ -2047,6 +2055,10 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       h.out_base = 0;
       h.act = d->act;
       h.slope = d->slope;
+      if (mom != nullptr) {
+        h.mom = mom;
+        h.mom_slots = (p.OH / 4) * (p.OW / 64);
+      }
 #ifdef JPDSE_DEV
       if (g_halo_abl && p.Ks > 64) {      // timing-only ablations (scripts/bench_conv.py --fast 11..)
         switch (g_halo_abl) {

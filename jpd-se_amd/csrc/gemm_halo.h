@@ -47,6 +47,8 @@ struct HaloArgs {
   const bf16_t* mask;   // optional fused ReLU backward (see FastArgs::mask)
   const bf16_t* addend; // optional: Y = result + addend
   int xcd_mode;         // 0: block b -> tile b; 1: blocks of one XCD (b % 8) take consecutive tiles; 2: 2 N-tiles x half the patches per XCD
+  float* mom;           // optional (MOM instantiation): InstanceNorm moments of y, one (mean, M2) slot per block and channel
+  int mom_slots;        //   [N][Ks][mom_slots][2], slot = the block's patch index inside its image (common.h; no bias / activation)
 };
 
 // ABL: timing-only ablation bits (results are wrong when non-zero): 1 = no DMA after the prologue,
@@ -58,7 +60,7 @@ struct HaloArgs {
 // MF16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 -- same LDS bytes and MFMA cycles per FLOP, but the chip holds
 // a higher clock on it (MI355X_MICROARCH.md, DVFS item 7).  The fragment rows are then 16 pixels x 4 k-chunks, which
 // needs the swizzle chunk ^ (row & 6) instead of chunk ^ ((row >> 1) & 7) to stay conflict-free at any tap shift.
-template <int TH, int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false>
+template <int TH, int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false>
 __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   constexpr int R = 3, S = 3, TAPS = 9;
   constexpr int NW = 8, WN = 2;                       // waves: TH (=4) x 2
@@ -327,6 +329,52 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     }
   }
 
+  // ---- optional moments of the block's 4 x 64 pixels per channel for the InstanceNorm that follows (ResnetBlock convs):
+  // (mean, M2) of the bf16-rounded values about a per-lane pilot, lane halves merged, then the four row-waves through LDS
+  // with Chan's formula in a fixed order (common.h) -- the norm's own moment kernel (a launch per norm) is not needed
+  if constexpr (MOM && !MF16) {
+    static_assert(FM == 2, "moments are written for the 32x32 accumulator layout");
+    __syncthreads();                                    // the pipeline LDS is dead
+    float* const red = reinterpret_cast<float*>(smem);  // [TH][BN][2]
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const float pilot = bf16_round(acc[0][j][0]);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = bf16_round(acc[i][j][e]) - pilot;
+          s1 += v;
+          s2 += v * v;
+        }
+      float mean, m2;                                   // lanes l and l + 32 hold the same column: 32 of the row's 64 pixels each
+      shifted_to_mean_m2(s1, s2, pilot, 32.f, mean, m2);
+      const float mean_o = __shfl_xor(mean, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
+      chan_merge_equal(mean, m2, mean_o, m2_o, 32.f);
+      if (lane < 32) {
+        const int col = wn * TN * 32 + j * 32 + lane;
+        red[(wm * BN + col) * 2] = mean;
+        red[(wm * BN + col) * 2 + 1] = m2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Ks) {
+      float msum = 0.f;
+#pragma unroll
+      for (int r = 0; r < TH; ++r) msum += red[(r * BN + tid) * 2];
+      const float mean = msum * (1.f / TH);
+      float m2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        const float dm = red[(r * BN + tid) * 2] - mean;
+        m2 += red[(r * BN + tid) * 2 + 1] + 64.f * dm * dm;
+      }
+      float* const o = a.mom + (((long long)n * a.Ks + n0 + tid) * a.mom_slots + (th_i * tiles_w + tw_i)) * 2;
+      o[0] = mean;
+      o[1] = m2;
+    }
+  }
   // ---- epilogue: wave wm owns image row oh0+wm (2 x 32 consecutive pixels); staged through LDS so that the
   // global stores are 16-byte channel vectors (see acc_tile_to_lds)
   __syncthreads();

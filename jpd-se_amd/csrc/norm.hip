@@ -415,7 +415,10 @@ __device__ __forceinline__ void exchange_totals(float* red, int* s_ctl, float ts
 template <typename T, int P, int PHASE>
 __global__ __launch_bounds__(256, 4) void inorm_reg_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                              T* __restrict__ y, float* __restrict__ stats, float* partial,
-                                                             unsigned* count, int act, float slope, float eps, FusedGeom g) {
+                                                             unsigned* count, int act, float slope, float eps, FusedGeom g,
+                                                             int mslots = 0) {
+  // PHASE 3: statistics from the per-block (mean, M2) slots a conv epilogue wrote (`partial` = moments[n][c][mslots][2],
+  // common.h): one kernel per norm -- each block merges the slots of its channels itself (Chan's formula, slot order) and applies
   constexpr int VE = Vec16<T>::N;
   __shared__ float red[256 * VE * 2];
   __shared__ int s_ctl[2];
@@ -437,13 +440,37 @@ __global__ __launch_bounds__(256, 4) void inorm_reg_fwd_kernel(const T* __restri
   float aux[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { aux[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
-  if (on) {
+  if (on && PHASE != 3) {
     float v[VE];
     Vec16<T>::load(x + base, v);                      // shift = the image's first pixel, as in the three-kernel form
 #pragma unroll
     for (int e = 0; e < VE; ++e) aux[e] = v[e];
   }
-  if constexpr (PHASE == 2) {
+  if constexpr (PHASE == 3) {
+    const int nch = g.TX * VE;
+    if (tid < nch) {
+      const int ch = cb * nch + tid;
+      float mean = 0.f, var = 0.f;
+      if (ch < g.Cs) {
+        const float2* const src = reinterpret_cast<const float2*>(partial) + ((long long)n * g.Cs + ch) * mslots;
+        float a = 0.f;
+        for (int q = 0; q < mslots; ++q) a += src[q].x;
+        mean = a / (float)mslots;
+        const float ns = (float)g.HW / (float)mslots;
+        float b = 0.f;
+        for (int q = 0; q < mslots; ++q) {
+          const float2 v = src[q];
+          const float dm = v.x - mean;
+          b += v.y + ns * dm * dm;
+        }
+        var = b / (float)g.HW;
+        var = var > 0.f ? var : 0.f;
+      }
+      red[tid * 2] = mean;
+      red[tid * 2 + 1] = var;
+    }
+    __syncthreads();
+  } else if constexpr (PHASE == 2) {
     const float* rows = partial + (long long)grp * g.splits * g.nv;
     const float total = tid < g.nv ? sum_rows<false>(rows + tid, g.splits, g.nv) : 0.f;
     if (tid < g.nv) red[tid] = total;
@@ -475,11 +502,16 @@ __global__ __launch_bounds__(256, 4) void inorm_reg_fwd_kernel(const T* __restri
   const float inv = 1.f / (float)g.HW;
 #pragma unroll
   for (int e = 0; e < VE; ++e) {
-    const float dm = red[(tx * VE + e) * 2] * inv;
-    float var = red[(tx * VE + e) * 2 + 1] * inv - dm * dm;
-    var = var > 0.f ? var : 0.f;
-    mean[e] = aux[e] + dm;
-    rstd[e] = rsqrtf(var + eps);
+    if constexpr (PHASE == 3) {
+      mean[e] = red[(tx * VE + e) * 2];
+      rstd[e] = rsqrtf(red[(tx * VE + e) * 2 + 1] + eps);
+    } else {
+      const float dm = red[(tx * VE + e) * 2] * inv;
+      float var = red[(tx * VE + e) * 2 + 1] * inv - dm * dm;
+      var = var > 0.f ? var : 0.f;
+      mean[e] = aux[e] + dm;
+      rstd[e] = rsqrtf(var + eps);
+    }
   }
   if (on && split == 0 && ty == 0) {
     float* st = stats + ((long long)n * g.Cs + c0) * 2;
@@ -868,6 +900,19 @@ static int inorm_from_moments_t(const jpdse_inorm_desc* d, const void* x, const 
   constexpr int VE = Vec16<T>::N;
   const int HW = d->H * d->W, Cs = cpad(d->C);
   const int NC = d->N * Cs;
+  // tensors the register-held form covers (<= 64 pixel splits, e.g. the ResnetBlock norms) and few slots: ONE kernel, every
+  // block merges its channels' slots itself
+  if (norm_form() != 0 && slots <= 64) {
+    FusedGeom fg;
+    const int P = reg_pick<T, false>(d, false, &fg);
+    if (P == 8) {
+      const dim3 grid((unsigned)((size_t)d->N * fg.col_blocks * fg.splits));
+      hipLaunchKernelGGL((inorm_reg_fwd_kernel<T, 8, 3>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(x),
+                         reinterpret_cast<const T*>(res), reinterpret_cast<T*>(y), stats, const_cast<float*>(mom), nullptr,
+                         d->act, d->slope, d->eps, fg, slots);
+      return check_launch("inorm apply-from-slots fwd");
+    }
+  }
   hipLaunchKernelGGL(finalize_slots_kernel, dim3((NC + 3) / 4), dim3(256), 0, s, mom, stats, NC, slots, HW, d->eps);
   if (int rc = check_launch("inorm finalize from moments")) return rc;
   MomentGeom g = moment_geom(d->N, HW, Cs, VE);

@@ -352,11 +352,22 @@ class HipResnetBlock(nn.Module):
   # kernels being deterministic, bit-identical to the stored-activation path when on (tests/test_hip_configs.py).
   recompute = False
 
+  @staticmethod
+  def _conv_norm(conv, norm, x, residual=None):
+    """conv -> InstanceNorm (+ activation / residual); the norm's moment pass runs in the conv's epilogue when its kernel has
+    one (jpdse_conv_fwd_moments: the halo kernel of the full-width blocks), leaving ONE kernel per norm."""
+    fused = conv.fwd_moments(x)
+    if fused is not None:
+      h, c, mom, slots = fused
+      y, n = norm.fwd_from_moments(h, mom, slots, residual=residual)
+      return y, c, n
+    h, c = conv.fwd(x)
+    y, n = norm.fwd(h, residual=residual)
+    return y, c, n
+
   def _fwd(self, x):
-    h, c1 = self.conv_block[1].fwd(x)
-    h, n1 = self.norm1.fwd(h)
-    h, c2 = self.conv_block[5].fwd(h)
-    y, n2 = self.norm2.fwd(h, residual=x)
+    h, c1, n1 = self._conv_norm(self.conv_block[1], self.norm1, x)
+    y, c2, n2 = self._conv_norm(self.conv_block[5], self.norm2, h, residual=x)
     return y, Ctx(c1, n1, c2, n2)
 
   def fwd(self, x):

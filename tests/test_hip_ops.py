@@ -356,6 +356,8 @@ FUSED_MOMENT_CASES = [
     ('first7x7',  lambda: HipConv2d(39, 64, 7, 1, 3, PAD_REFLECT, apply_bias=False, dtype=BF16, device=DEV), (2, 39, 16, 128)),
     ('down_s2',   lambda: HipConv2d(64, 128, 3, 2, 1, PAD_ZERO, apply_bias=False, dtype=BF16, device=DEV), (2, 64, 32, 128)),
     ('convT_up',  lambda: HipConv2d(128, 64, 3, 2, 1, transposed=True, apply_bias=False, dtype=BF16, device=DEV), (2, 128, 16, 64)),
+    # halo kernel epilogue (ResnetBlock convs) + the one-kernel norm that merges its slots (inorm_reg_fwd_kernel PHASE 3)
+    ('resblock_halo', lambda: HipConv2d(128, 128, 3, 1, 1, PAD_REFLECT, apply_bias=False, dtype=BF16, device=DEV), (2, 128, 8, 128)),
 ]
 
 
@@ -394,6 +396,7 @@ FUSED_MOMENT_FULL = [
     ('first7x7@1024x512', lambda: HipConv2d(39, 64, 7, 1, 3, PAD_REFLECT, apply_bias=False, dtype=BF16, device=DEV), (2, 39, 512, 1024)),
     ('down_s2@1024x512',  lambda: HipConv2d(64, 128, 3, 2, 1, PAD_ZERO, apply_bias=False, dtype=BF16, device=DEV), (2, 64, 512, 1024)),
     ('convT_up@1024x512', lambda: HipConv2d(128, 64, 3, 2, 1, transposed=True, apply_bias=False, dtype=BF16, device=DEV), (2, 128, 256, 512)),
+    ('resblock@1024x512', lambda: HipConv2d(1024, 1024, 3, 1, 1, PAD_REFLECT, apply_bias=False, dtype=BF16, device=DEV), (4, 1024, 32, 64)),
 ]
 
 
