@@ -52,9 +52,9 @@ def pytest_sessionfinish(session, exitstatus):
         a[1], a[2], a[3] = measured, bound, note
     with open(path, 'w') as fh:
       fh.write('# parity report of one `pytest -m gpu` run: worst measured value over the calls of each comparison, next to its bound\n')
-      fh.write('# %-118s %5s %11s %9s %7s  %s\n' % ('test | comparison', 'calls', 'measured', 'bound', 'used', 'worst case'))
+      fh.write('# %-148s %5s %11s %9s %7s  %s\n' % ('test | comparison', 'calls', 'measured', 'bound', 'used', 'worst case'))
       for what in sorted(agg):
         n, m, b, note = agg[what]
-        fh.write('%-120s %5d %11.3e %9.1e %6.1f%%  %s\n' % (what[:120], n, m, b, 100.0 * m / b if b > 0 else 0.0, note))
+        fh.write('%-150s %5d %11.3e %9.1e %6.1f%%  %s\n' % (what[:150], n, m, b, 100.0 * m / b if b > 0 else 0.0, note))
   except OSError:
     pass
