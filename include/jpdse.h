@@ -234,6 +234,8 @@ int jpdse_channel_copy(int32_t dtype, int64_t npix, const void* src, int32_t src
  * base,out / img. */
 int jpdse_concat_channels(int32_t dtype, int64_t npix, const void* base, int32_t cs, const void* img,
                           int32_t img_cs, int32_t c0, int32_t nch, void* out, void* stream);
+/* dst = src, nbytes a multiple of 16, both 16-byte aligned (assembling the batched [fake ; real] VGG19 input: networks.py:124-139) */
+int jpdse_copy(int64_t nbytes, const void* src, void* dst, void* stream);
 /* fill n elements with zero */
 int jpdse_zero(int32_t dtype, int64_t n, void* p, void* stream);
 /* dst = (dst_dtype) src, fp32 <-> bf16, n a multiple of 8: the gradient buckets of the optional bf16 all-reduce

@@ -1511,7 +1511,7 @@ JPDSE_SWITCH(int, g_taps_enabled, 1);       // 35: these layers on the merged-ph
 static bool taps_dgrad2_ok(const jpdse_conv_desc* d, const ConvPlan& p, const void* mask, const void* addend, const float* mom) {
   if (!(g_fast_enabled && g_taps_enabled) || d->dtype != JPDSE_BF16 || d->pad_mode == JPDSE_PAD_REFLECT) return false;
   if (d->stride != 2 || d->R != 3 || d->S != 3 || d->pad != 1 || p.nph != 4) return false;
-  if (mask != nullptr || addend != nullptr || mom != nullptr) return false;
+  if (mom != nullptr) return false;
   if (d->H != 2 * p.OH || d->W != 2 * p.OW || p.OH % 4 != 0 || p.OW % 64 != 0) return false;
   if (p.Ks % 64 != 0 || p.Ks < 128 || p.Cs % 64 != 0) return false;
   // the kernel's loaders carry 32-bit element offsets into dy and into each phase's panel
@@ -1540,8 +1540,11 @@ static int launch_taps_dgrad2_cfg(const TapsArgs& a, int total, hipStream_t s) {
   return check_launch("gemm_taps_kernel");
 }
 
-static int launch_taps_dgrad2(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx, hipStream_t s) {
+static int launch_taps_dgrad2(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx, hipStream_t s,
+                              const void* mask, const void* addend) {
   TapsArgs a = {};
+  a.mask = reinterpret_cast<const bf16_t*>(mask);
+  a.addend = reinterpret_cast<const bf16_t*>(addend);
   a.X = reinterpret_cast<const bf16_t*>(dy);
   a.Y = reinterpret_cast<bf16_t*>(dx);
   a.N = d->N;
@@ -1596,6 +1599,7 @@ struct Taps4View {            // a stride-1 4x4 conv as the kernels see it: forw
   long long ktot;             // panel row stride (elements)
   int tap_r, tap_s;           // panel offsets per filter-row / filter-column step
   int act; float slope;
+  const bf16_t* addend; const bf16_t* mask;   // optional fused operands of a data gradient (Y's addressing)
 };
 
 static bool taps4_shape_ok(int R, int S, int stride, int OH, int OW, int Cin_s, int Ks_out, long long x_elems, long long b_elems) {
@@ -1658,6 +1662,8 @@ static int launch_taps4(const Taps4View& v, void* ws, hipStream_t s) {
   a.out_sw = v.Ks_out;
   a.act = v.act;
   a.slope = v.slope;
+  a.addend = v.addend;
+  a.mask = v.mask;
   a.prog[0].B[0] = v.B;
   a.prog[0].ktot[0] = v.ktot;
   a.prog[0].out_base[0] = 0;
@@ -1710,6 +1716,8 @@ static int launch_taps4(const Taps4View& v, void* ws, hipStream_t s) {
     g.b_stride = v.ktot;
     g.b_tap_r = v.tap_r;
     g.b_tap_s = v.tap_s;
+    g.addend = v.addend;        // applied by splitk_finish_kernel
+    g.mask = v.mask;
     slab += (size_t)sp * g.M * v.Ks_out;
     fb.p[fb.n++] = g;
   }
@@ -2522,8 +2530,8 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     }
   }
   if constexpr (sizeof(T) == 2) {
-    if (taps_dgrad2_ok(d, p, mask, addend, mom)) return launch_taps_dgrad2(d, p, dy, pack, dx, s);
-    if (!refl && p.nph == 1 && st == 1 && mask == nullptr && addend == nullptr && mom == nullptr && p.ph[0].cnth == d->H &&
+    if (taps_dgrad2_ok(d, p, mask, addend, mom)) return launch_taps_dgrad2(d, p, dy, pack, dx, s, mask, addend);
+    if (!refl && p.nph == 1 && st == 1 && mom == nullptr && p.ph[0].cnth == d->H &&
         p.ph[0].cntw == d->W && p.ph[0].Lk == p.ph[0].Uw * p.Ks &&
         taps4_shape_ok(p.ph[0].Uh, p.ph[0].Uw, 1, d->H, d->W, p.Ks, p.Cs, (long long)d->N * p.OH * p.OW * p.Ks, (long long)p.Cs * 16 * p.Ks)) {
       const Phase& f = p.ph[0];
@@ -2545,6 +2553,8 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       v.tap_r = f.Lk;
       v.tap_s = p.Ks;
       v.act = JPDSE_ACT_NONE;
+      v.addend = reinterpret_cast<const bf16_t*>(addend);
+      v.mask = reinterpret_cast<const bf16_t*>(mask);
       return launch_taps4(v, ws, s);
     }
   }

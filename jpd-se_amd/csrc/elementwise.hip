@@ -352,44 +352,52 @@ struct BuilderArgs {
   int n_dst;
   int H, W, nlab, cs, img_cs, c0, nch;
 };
-// One thread per pixel (32-bit index arithmetic: 64-bit divisions cost ~100 instructions each and the first version, one
-// thread per 16-byte vector with four of them, ran at 1.9 TB/s): label and edge are resolved once, every destination's
-// CS / VE vectors are formed in registers and stored back to back (a pixel's 80 or 160 bytes are contiguous).
+// One thread per 16-byte vector, consecutive lanes = consecutive vectors (every store instruction of a wave writes 1 KiB of
+// contiguous bytes; a thread-per-pixel form, whose lanes store 80 bytes apart, ran at 2.1 TB/s), 32-bit index arithmetic with
+// the vector count per pixel a compile-time constant (the first version did four 64-bit divisions per vector: 1.9 TB/s).
 template <typename T, int CV>
-__global__ __launch_bounds__(256) void input_builder_kernel(const BuilderArgs a, unsigned total_pix) {
+__global__ __launch_bounds__(256) void input_builder_kernel(const BuilderArgs a, unsigned total_vec) {
   constexpr int VE = Vec16<T>::N;
-  for (unsigned pix = blockIdx.x * 256u + threadIdx.x; pix < total_pix; pix += gridDim.x * 256u) {
-    const unsigned w = pix % (unsigned)a.W;
-    const unsigned h = (pix / (unsigned)a.W) % (unsigned)a.H;
+  // one vector per thread, no grid-stride loop: behind its three stores (which may alias the label planes as far as the
+  // compiler knows) the next iteration's label load could not start, and the loop ran at memory latency per iteration
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx < total_vec) {
+    const unsigned pix = idx / (unsigned)CV;
+    const int cb = (int)(idx - pix * (unsigned)CV) * VE;
     const int lab = (int)(long long)a.label[pix];
-    const long long me = a.inst[pix];
-    bool edge = false;
-    if (a.nlab < a.cs) {
+    float v[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = (cb + e == lab && lab < a.nlab) ? 1.f : 0.f;
+    if (a.nlab >= cb && a.nlab < cb + VE) {
+      const unsigned w = pix % (unsigned)a.W;
+      const unsigned h = (pix / (unsigned)a.W) % (unsigned)a.H;
+      const long long me = a.inst[pix];
+      bool edge = false;
       if (w > 0) edge |= a.inst[pix - 1] != me;
       if (w < (unsigned)a.W - 1) edge |= a.inst[pix + 1] != me;
       if (h > 0) edge |= a.inst[pix - a.W] != me;
       if (h < (unsigned)a.H - 1) edge |= a.inst[pix + a.W] != me;
+#pragma unroll
+      for (int e = 0; e < VE; ++e)
+        if (cb + e == a.nlab) v[e] = edge ? 1.f : 0.f;
     }
+    const bool has_img = cb + VE > a.c0 && cb < a.c0 + a.nch;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       if (i >= a.n_dst) break;
-      const T* const img = reinterpret_cast<const T*>(a.img[i]);
-      T* const dst = reinterpret_cast<T*>(a.dst[i]) + (size_t)pix * a.cs;
+      float o[VE];
 #pragma unroll
-      for (int c = 0; c < CV; ++c) {
-        const int cb = c * VE;
-        if (cb >= a.cs) break;                    // instantiations that cover narrower tensors
-        float v[VE];
+      for (int e = 0; e < VE; ++e) o[e] = v[e];
+      if (has_img) {
+        const T* const img = reinterpret_cast<const T*>(a.img[i]);
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
           const int ch = cb + e;
-          float x = (ch == lab && lab < a.nlab) ? 1.f : 0.f;
-          if (ch == a.nlab) x = edge ? 1.f : 0.f;
-          if (ch >= a.c0 && ch < a.c0 + a.nch) x = img != nullptr ? ElemOps<T>::ld(img + (size_t)pix * a.img_cs + (ch - a.c0)) : 0.f;
-          v[e] = x;
+          if (ch >= a.c0 && ch < a.c0 + a.nch)
+            o[e] = img != nullptr ? ElemOps<T>::ld(img + (size_t)pix * a.img_cs + (ch - a.c0)) : 0.f;
         }
-        Vec16<T>::store(dst + cb, v);
       }
+      Vec16<T>::store(reinterpret_cast<T*>(a.dst[i]) + (size_t)idx * VE, o);
     }
   }
 }
@@ -412,6 +420,11 @@ __global__ void insert_channels_kernel(T* __restrict__ dst, const T* __restrict_
     }
     *reinterpret_cast<u32x4*>(dst + p * cs + cb) = *reinterpret_cast<const u32x4*>(tmp);
   }
+}
+
+// plain device-to-device copy in 16-byte vectors (assembling a batched tensor from two producers)
+__global__ __launch_bounds__(256) void copy16_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long nvec) {
+  GRID_STRIDE(i, nvec) dst[i] = src[i];
 }
 
 // ---- loss reductions (deterministic two-stage) --------------------------------------------------
@@ -869,20 +882,36 @@ int jpdse_input_builder(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t 
   a.c0 = c0;
   a.nch = nch;
   const long long npix = (long long)N * H * W;
-  JPDSE_REQUIRE(npix < (1LL << 31), "input_builder: more than 2^31 pixels");
   const int cv = cs / (16 / (int)esize(dtype));
-  const int grid = ew_blocks(npix);
-  // CV (vectors per pixel) is a template parameter so that the per-pixel vectors live in registers: 40 channels (the hot
-  // path: 5 bf16 / 10 fp32 vectors); other widths take the 8 / 16-vector instantiations that cover them
-#define JPDSE_BUILDER(T, CVN) hipLaunchKernelGGL((input_builder_kernel<T, CVN>), dim3(grid), dim3(256), 0, as_stream(stream), a, (unsigned)npix)
+  JPDSE_REQUIRE(npix * cv < (1LL << 32), "input_builder: more than 2^32 vectors");
+  const unsigned grid = (unsigned)((npix * cv + 255) / 256);
+  // the vector count per pixel is a template parameter (cheap index arithmetic): 40 storage channels are the hot path
+  // (5 bf16 / 10 fp32 vectors), other widths up to 64 channels have their own instantiation
+#define JPDSE_BUILDER(T, CVN) hipLaunchKernelGGL((input_builder_kernel<T, CVN>), dim3(grid), dim3(256), 0, as_stream(stream), a, (unsigned)(npix * cv))
   if (dtype == JPDSE_BF16) {
-    if (cv == 5) JPDSE_BUILDER(bf16_t, 5);
-    else if (cv <= 8) JPDSE_BUILDER(bf16_t, 8);
-    else return set_error(JPDSE_EINVAL, "input_builder: %d storage channels unsupported (<= 64 in bf16)", cs);
+    switch (cv) {
+      case 1: JPDSE_BUILDER(bf16_t, 1); break;
+      case 2: JPDSE_BUILDER(bf16_t, 2); break;
+      case 3: JPDSE_BUILDER(bf16_t, 3); break;
+      case 4: JPDSE_BUILDER(bf16_t, 4); break;
+      case 5: JPDSE_BUILDER(bf16_t, 5); break;
+      case 6: JPDSE_BUILDER(bf16_t, 6); break;
+      case 7: JPDSE_BUILDER(bf16_t, 7); break;
+      case 8: JPDSE_BUILDER(bf16_t, 8); break;
+      default: return set_error(JPDSE_EINVAL, "input_builder: %d storage channels unsupported (<= 64)", cs);
+    }
   } else {
-    if (cv == 10) JPDSE_BUILDER(float, 10);
-    else if (cv <= 16) JPDSE_BUILDER(float, 16);
-    else return set_error(JPDSE_EINVAL, "input_builder: %d storage channels unsupported (<= 64 in fp32)", cs);
+    switch (cv) {
+      case 2: JPDSE_BUILDER(float, 2); break;
+      case 4: JPDSE_BUILDER(float, 4); break;
+      case 6: JPDSE_BUILDER(float, 6); break;
+      case 8: JPDSE_BUILDER(float, 8); break;
+      case 10: JPDSE_BUILDER(float, 10); break;
+      case 12: JPDSE_BUILDER(float, 12); break;
+      case 14: JPDSE_BUILDER(float, 14); break;
+      case 16: JPDSE_BUILDER(float, 16); break;
+      default: return set_error(JPDSE_EINVAL, "input_builder: %d storage channels unsupported (<= 64)", cs);
+    }
   }
 #undef JPDSE_BUILDER
   return check_launch("input_builder");
@@ -903,6 +932,15 @@ int jpdse_insert_channels(int32_t dtype, int64_t npix, void* dst, int32_t cs, co
     hipLaunchKernelGGL((insert_channels_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, as_stream(stream),
                        mptr<float>(dst), cptr<float>(img), cs, img_cs, c0, nch, v0, nv, total);
   return check_launch("insert_channels");
+}
+
+int jpdse_copy(int64_t nbytes, const void* src, void* dst, void* stream) {
+  JPDSE_REQUIRE(src && dst && nbytes > 0 && nbytes % 16 == 0, "copy: %lld bytes (a positive multiple of 16 is required)", (long long)nbytes);
+  JPDSE_REQUIRE((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) % 16 == 0, "copy: pointers must be 16-byte aligned");
+  const long long nvec = nbytes / 16;
+  hipLaunchKernelGGL(copy16_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, as_stream(stream), reinterpret_cast<const u32x4*>(src),
+                     reinterpret_cast<u32x4*>(dst), nvec);
+  return check_launch("copy");
 }
 
 size_t jpdse_loss_workspace_size(int64_t n) { return kRedBlocks * sizeof(float); }

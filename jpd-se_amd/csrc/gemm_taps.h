@@ -48,6 +48,8 @@ struct TapsArgs {
   long long out_sn, out_sh, out_sw;
   int act;
   float slope;
+  const bf16_t* addend;      // optional, Y's addressing: Y = result + addend (gradient fan-in), then
+  const bf16_t* mask;        // optional, Y's addressing: zeroed where mask <= 0 (ReLU backward of the conv's input)
   int nblk0;                 // blocks [0, nblk0) run prog[0], the rest prog[1]
   TapsProg prog[2];
 };
@@ -238,6 +240,36 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
     acc_tile_to_lds<2, TN>(smem, PITCH, WROWS == 1 ? wm * 64 : wm * 64, wn * TN * 32, n0, lane, acc[q], a.bias, a.Kout, a.act, a.slope);
     __syncthreads();
     const long long blk_base = pr.out_base[q] + n * a.out_sn + (long long)oh0 * a.out_sh + (long long)ow0 * a.out_sw;
+    if (a.addend != nullptr || a.mask != nullptr) {
+      // fused operands loaded for all of the thread's vectors before the first store (gemm_halo.h: behind a store the compiler
+      // cannot hoist them, and the epilogue would pay one memory round trip per vector)
+      constexpr int NV = TH * TW * VPR / 512;
+      static_assert(TH * TW * VPR % 512 == 0, "every thread owns the same number of output vectors");
+      u32x4 addv[NV], mskv[NV];
+#pragma unroll
+      for (int it = 0; it < NV; ++it) {
+        const int idx = tid + 512 * it;
+        const int row = idx / VPR, v = idx - row * VPR;
+        const int r = row / TW, c = row - r * TW;
+        const long long off = blk_base + (long long)r * a.out_sh + (long long)c * a.out_sw + n0 + v * 8;
+        const bool on = n0 + v * 8 < a.Ks;
+        if (on && a.addend != nullptr) addv[it] = *reinterpret_cast<const u32x4*>(a.addend + off);
+        if (on && a.mask != nullptr) mskv[it] = *reinterpret_cast<const u32x4*>(a.mask + off);
+      }
+#pragma unroll
+      for (int it = 0; it < NV; ++it) {
+        const int idx = tid + 512 * it;
+        const int row = idx / VPR, v = idx - row * VPR;
+        if (n0 + v * 8 >= a.Ks) continue;
+        const int r = row / TW, c = row - r * TW;
+        const long long off = blk_base + (long long)r * a.out_sh + (long long)c * a.out_sw + n0 + v * 8;
+        u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);
+        if (a.addend != nullptr) val = add_bf16x8(val, addv[it]);
+        if (a.mask != nullptr) val = relu_mask8(val, mskv[it]);
+        *reinterpret_cast<u32x4*>(a.Y + off) = val;
+      }
+      continue;
+    }
     for (int idx = tid; idx < TH * TW * VPR; idx += 512) {
       const int row = idx / VPR, v = idx - row * VPR;
       if (n0 + v * 8 >= a.Ks) continue;

@@ -343,8 +343,8 @@ class Pix2PixHDModel(BaseModel):
       # fake half of the saved tensors only (Ctx.slice).
       vgg = self.criterionVGG.vgg
       both = Act.empty(2 * B, H, W, fake.C, self.cdtype, dev)
-      both.t[:B].copy_(fake.t)               # two 33 MB device-to-device copies (memory plumbing, no arithmetic)
-      both.t[B:].copy_(real.t)
+      ops.copy_(fake.t, both.t[:B])          # two 33 MB device-to-device copies
+      ops.copy_(real.t, both.t[B:])
       maps, ctxs = vgg.fwd(both, save=not opt.no_vgg_loss)
       vf = [m.batch_slice(0, B) for m in maps]
       vr = [m.batch_slice(B, 2 * B) for m in maps]

@@ -93,6 +93,7 @@ SIGNATURES = {
     'jpdse_channel_sum': (_I32, [_I32, _I64, _I32, _P, _P, _P, _SZ, _P]),
     'jpdse_channel_copy': (_I32, [_I32, _I64, _P, _I32, _I32, _P, _I32, _I32, _I32, _P]),
     'jpdse_concat_channels': (_I32, [_I32, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _P]),
+    'jpdse_copy': (_I32, [_I64, _P, _P, _P]),
     'jpdse_zero': (_I32, [_I32, _I64, _P, _P]),
     'jpdse_cast': (_I32, [_I32, _I32, _I64, _P, _P, _P]),
     'jpdse_quant_loss_workspace_size': (_SZ, []),

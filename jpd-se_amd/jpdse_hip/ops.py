@@ -238,6 +238,14 @@ def add_(a, b):
   return a
 
 
+def copy_(src, dst):
+  """dst = src (contiguous device tensors of equal byte size, a multiple of 16; views of larger tensors are fine)."""
+  nb = src.numel() * src.element_size()
+  assert src.is_contiguous() and dst.is_contiguous() and nb == dst.numel() * dst.element_size()
+  check(lib().jpdse_copy(nb, _p(src), _p(dst), _stream()), 'copy')
+  return dst
+
+
 def zero_(t):
   check(lib().jpdse_zero(code_of(t.dtype), t.numel(), _p(t), _stream()), 'zero')
   return t

@@ -35,4 +35,16 @@ if head:
             write_bytes_per_launch=w * 1e6, launches_averaged=n,
             source='profiles/%s_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; FETCH_SIZE x2 per the gfx950 correction)' % tag)
   json.dump(js, open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'), 'w'), indent=1)
+# norm family (InstanceNorm kernels of norm.hip) per step: the pass ran `--steps 2 --warmup 1` = 3 steps
+norm = [r for r in rows if r[0].startswith(('inorm_', 'moment_kernel', 'finalize_')) ]
+if norm:
+  steps = 3.0
+  nb = sum((f + w) * 1e6 * n for _, _, n, f, w, _ in norm) / steps
+  tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+  js = json.load(open(tpath)) if os.path.exists(tpath) else {}
+  js['norm_family_bytes_per_step'] = nb
+  js['norm_family_kernels'] = sorted({r[0] for r in norm})
+  json.dump(js, open(tpath, 'w'), indent=1)
+  with open(out, 'a') as fh:
+    fh.write('\nInstanceNorm family (inorm_*, moment_kernel, finalize_*): %.1f MB per step memory-side (3 steps in the pass)\n' % (nb / 1e6))
 print(open(out).read()[:3000])

@@ -224,6 +224,10 @@ FUSED_RELU_CASES = [
     ('splitk',        1, 10, 24, 256, 256, 3, 1, 1, PAD_ZERO),
     ('generic_small', 2, 9,  11, 16,  24,  3, 1, 1, PAD_ZERO),
     ('reflect',       1, 12, 20, 64,  64,  3, 1, 1, PAD_REFLECT),
+    # tap-program kernel epilogues (gemm_taps.h): 4x4 stride 1 (core + split-K fringe: the finish kernel applies the operands
+    # there) and the two-set stride-2 data gradient
+    ('taps4_fused',   2, 17, 33, 128, 256, 4, 1, 2, PAD_ZERO),
+    ('tapsprog_fused', 1, 16, 128, 128, 256, 3, 2, 1, PAD_ZERO),
 ]
 
 
