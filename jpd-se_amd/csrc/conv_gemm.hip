@@ -91,3135 +91,13 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "thin_dgrad2_rows.h"
 #include "thin_rows.h"
 #include "thin_in_rows.h"
-namespace jpdse {
+#include "conv_generic.h"
+#include "conv_plan.h"
+#include "conv_launch.h"
+#include "conv_dispatch_fwd.h"
+#include "conv_dispatch_dgrad.h"
+#include "conv_dispatch_wgrad.h"
 
-// ---- MFMA over one 64-byte K chunk --------------------------------------------------------
-template <typename T, int TM, int TN> struct MmaChunk;
-
-template <int TM, int TN> struct MmaChunk<bf16_t, TM, TN> {
-  __device__ static __forceinline__ void run(const char* As, const char* Bs, const int (&a_rd)[TM][2],
-                                             const int (&b_rd)[TN][2], f32x16 (&acc)[TM][TN]) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      s16x8 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(As + a_rd[i][u]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(Bs + b_rd[j][u]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-  }
-};
-
-template <int TM, int TN> struct MmaChunk<float, TM, TN> {
-  __device__ static __forceinline__ void run(const char* As, const char* Bs, const int (&a_rd)[TM][2],
-                                             const int (&b_rd)[TN][2], f32x16 (&acc)[TM][TN]) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + a_rd[i][u]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + b_rd[j][u]);
-      // lanes 0-31 carry k = 4*(2u)+q, lanes 32-63 k = 4*(2u+1)+q: any k permutation is
-      // legal as long as A and B agree.
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q], bf[j][q], acc[i][j], 0, 0, 0);
-    }
-  }
-};
-
-// fp32 only: every kFlushChunks K-chunks the running MFMA accumulator is folded into a second
-// fp32 accumulator and cleared.  A v_mfma_f32_32x32x2_f32 chain is a plain sequential fma chain
-// (rounding error ~ sqrt(chain length)); two-level summation brings a K = 9216 reduction from
-// ~7x torch-CPU's rounding error down to its level, which matters for fp32 parity of gradients
-// through the sign()-discontinuous L1 losses.  bf16 keeps a single accumulator.
-static constexpr int kFlushChunks = 16;
-template <typename T, int TM, int TN> struct TwoLevel {
-  __device__ static __forceinline__ void init(f32x16 (&)[TM][TN]) {}
-  __device__ static __forceinline__ void flush(int, f32x16 (&)[TM][TN], f32x16 (&)[TM][TN]) {}
-  __device__ static __forceinline__ void finish(f32x16 (&)[TM][TN], f32x16 (&)[TM][TN]) {}
-  static constexpr int kMasters = 1;   // dummy storage
-};
-template <int TM, int TN> struct TwoLevel<float, TM, TN> {
-  __device__ static __forceinline__ void init(f32x16 (&m)[TM][TN]) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) m[i][j][e] = 0.f;
-  }
-  __device__ static __forceinline__ void flush(int t, f32x16 (&acc)[TM][TN], f32x16 (&m)[TM][TN]) {
-    if ((t % kFlushChunks) != kFlushChunks - 1) return;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          m[i][j][e] += acc[i][j][e];
-          acc[i][j][e] = 0.f;
-        }
-  }
-  __device__ static __forceinline__ void finish(f32x16 (&acc)[TM][TN], f32x16 (&m)[TM][TN]) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] += m[i][j][e];
-  }
-  static constexpr int kMasters = TM * TN;
-};
-
-template <int TM, int TN, int BMW, int BNW>
-__device__ __forceinline__ void frag_offsets(int lane, int wm, int wn, int (&a_rd)[TM][2], int (&b_rd)[TN][2]) {
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int row = wm * BMW + i * 32 + r;
-    a_rd[i][0] = swz(row, h);
-    a_rd[i][1] = swz(row, 2 + h);
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int row = wn * BNW + j * 32 + r;
-    b_rd[j][0] = swz(row, h);
-    b_rd[j][1] = swz(row, 2 + h);
-  }
-}
-
-// =========================================================================================
-// forward / dgrad GEMM:  Y[m][k] = act( sum_{r,j} A[m][(r,j)] * B[k][(r,j)] + bias[k] )
-// =========================================================================================
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArgs a) {
-  constexpr int NT = 64 * WM * WN;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AV = (BM * 4 + NT - 1) / NT, BV = (BN * 4 + NT - 1) / NT;
-  constexpr int ES = sizeof(T);
-  static_assert((BM * 4) % NT == 0 || BM * 4 < NT, "A tile / threads");
-  static_assert((BN * 4) % NT == 0 || BN * 4 < NT, "B tile / threads");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const As = smem;                // [2][BM*64]
-  char* const Bs = smem + 2 * BM * 64;  // [2][BN*64]
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
-  const int tiles_m = (a.M + BM - 1) / BM;
-  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const char* a_ptr[AV];
-  int a_lds[AV];
-#pragma unroll
-  for (int i = 0; i < AV; ++i) {
-    int v = tid + i * NT;
-    v = v < BM * 4 ? v : BM * 4 - 1;  // surplus threads duplicate the last vector
-    const int row = v >> 2, slot = v & 3;
-    int m = m0 + row;
-    m = m < a.M ? m : a.M - 1;
-    const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
-    const long long off = a.in_base + n * a.in_sn + oh * a.in_sh + ow * a.in_sw;
-    a_ptr[i] = reinterpret_cast<const char*>(a.A) + off * ES + slot * 16;
-    a_lds[i] = swz(row, slot);
-  }
-  const char* b_ptr[BV];
-  int b_lds[BV];
-#pragma unroll
-  for (int i = 0; i < BV; ++i) {
-    int v = tid + i * NT;
-    v = v < BN * 4 ? v : BN * 4 - 1;
-    const int row = v >> 2, slot = v & 3;
-    int br = n0 + row;
-    br = br < a.b_rows ? br : a.b_rows - 1;
-    b_ptr[i] = reinterpret_cast<const char*>(a.B) + (long long)br * a.b_row_stride * ES + slot * 16;
-    b_lds[i] = swz(row, slot);
-  }
-
-  int a_rd[TM][2], b_rd[TN][2];
-  frag_offsets<TM, TN, BM / WM, BN / WN>(lane, wm, wn, a_rd, b_rd);
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  f32x16 master[(sizeof(T) == 4) ? TM : 1][(sizeof(T) == 4) ? TN : 1];
-  using TL = TwoLevel<T, (sizeof(T) == 4) ? TM : 1, (sizeof(T) == 4) ? TN : 1>;
-  if constexpr (sizeof(T) == 4) TL::init(master);
-  const int T_total = a.R * a.cpr;
-  const long long a_row_bytes = a.in_sr * ES;
-  u32x4 areg[AV], breg[BV];
-  // chunk 0
-  {
-#pragma unroll
-    for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4*>(a_ptr[i]);
-#pragma unroll
-    for (int i = 0; i < BV; ++i) breg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i]);
-#pragma unroll
-    for (int i = 0; i < AV; ++i) *reinterpret_cast<u32x4*>(As + a_lds[i]) = areg[i];
-#pragma unroll
-    for (int i = 0; i < BV; ++i) *reinterpret_cast<u32x4*>(Bs + b_lds[i]) = breg[i];
-  }
-  __syncthreads();
-  int r = 0, jc = 0;
-  for (int t = 0; t < T_total; ++t) {
-    const int cur = t & 1;
-    const bool more = (t + 1) < T_total;
-    if (more) {
-      if (++jc == a.cpr) { jc = 0; ++r; }
-      const long long a_off = (long long)r * a_row_bytes + (long long)jc * 64;
-      const long long b_off = (long long)(t + 1) * 64;
-#pragma unroll
-      for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + a_off);
-#pragma unroll
-      for (int i = 0; i < BV; ++i) breg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + b_off);
-    }
-    MmaChunk<T, TM, TN>::run(As + cur * BM * 64, Bs + cur * BN * 64, a_rd, b_rd, acc);
-    if constexpr (sizeof(T) == 4) TL::flush(t, acc, master);
-    if (more) {
-      char* const An = As + (cur ^ 1) * BM * 64;
-      char* const Bn = Bs + (cur ^ 1) * BN * 64;
-#pragma unroll
-      for (int i = 0; i < AV; ++i) *reinterpret_cast<u32x4*>(An + a_lds[i]) = areg[i];
-#pragma unroll
-      for (int i = 0; i < BV; ++i) *reinterpret_cast<u32x4*>(Bn + b_lds[i]) = breg[i];
-    }
-    __syncthreads();
-  }
-
-  if constexpr (sizeof(T) == 4) TL::finish(acc, master);
-  // ---- epilogue: bias + activation, NHWC store through the output addressing -------------
-  long long* const row_off = reinterpret_cast<long long*>(smem);
-  for (int row = tid; row < BM; row += NT) {
-    const int m = m0 + row;
-    long long off = -1;
-    if (m < a.M) {
-      const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
-      off = a.out_base + n * a.out_sn + oh * a.out_sh + ow * a.out_sw;
-    }
-    row_off[row] = off;
-  }
-  __syncthreads();
-  T* const Y = reinterpret_cast<T*>(a.Y);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-    if (col >= a.Ks) continue;
-    const int kk = a.col_mod > 0 ? col % a.col_mod : col;
-    const bool live = a.col_mod > 0 ? kk < a.k_real : col < a.Kout;
-    const float bv = (a.bias != nullptr && live) ? a.bias[kk] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const long long off = row_off[row];
-        if (off < 0) continue;
-        float v = live ? apply_act(acc[i][j][e] + bv, a.act, a.slope) : 0.f;
-        ElemOps<T>::st(Y + off + col, v);
-      }
-    }
-  }
-}
-
-// =========================================================================================
-// weight-gradient GEMM: DW[k][(r,j)] = sum_m DY[m][k] * X[rowbase(m) + r*in_sr + j]
-// Both operands are transposed while being staged (pixels become the 64-byte K rows).
-// =========================================================================================
-template <typename T> struct WgStage;
-
-// bf16: one item = 2 adjacent pixels x 8 channels -> 8 packed (p, p+1) dwords
-template <> struct WgStage<bf16_t> {
-  static constexpr int PIX = 32;
-  template <int ROWS> static constexpr int items() { return (ROWS / 8) * 16; }
-  struct Regs { u32x4 lo, hi; };
-  template <int ROWS>
-  __device__ static __forceinline__ void decode(int id, int& cg, int& pp) { cg = id % (ROWS / 8); pp = id / (ROWS / 8); }
-  __device__ static __forceinline__ void write(char* lds, int cg, int pp, const Regs& rg) {
-    const int slot = pp >> 2, within = (pp & 3) << 2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t lo = rg.lo[e], hi = rg.hi[e];
-      const uint32_t w0 = (lo & 0xffffu) | (hi << 16);
-      const uint32_t w1 = (lo >> 16) | (hi & 0xffff0000u);
-      const int row0 = cg * 8 + 2 * e, row1 = row0 + 1;
-      *reinterpret_cast<uint32_t*>(lds + swz(row0, slot) + within) = w0;
-      *reinterpret_cast<uint32_t*>(lds + swz(row1, slot) + within) = w1;
-    }
-  }
-};
-
-// fp32: one item = 1 pixel x 4 channels -> 4 dwords
-template <> struct WgStage<float> {
-  static constexpr int PIX = 16;
-  template <int ROWS> static constexpr int items() { return (ROWS / 4) * 16; }
-  struct Regs { u32x4 lo; };
-  template <int ROWS>
-  __device__ static __forceinline__ void decode(int id, int& cg, int& pp) { cg = id % (ROWS / 4); pp = id / (ROWS / 4); }
-  __device__ static __forceinline__ void write(char* lds, int cg, int pp, const Regs& rg) {
-    const int slot = pp >> 2, within = (pp & 3) << 2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      *reinterpret_cast<uint32_t*>(lds + swz(cg * 4 + e, slot) + within) = rg.lo[e];
-  }
-};
-
-struct PixCursor {
-  int n, oh, ow;
-  __device__ __forceinline__ void init(int m, int OH, int OW) {
-    ow = m % OW;
-    const int t = m / OW;
-    oh = t % OH;
-    n = t / OH;
-  }
-  __device__ __forceinline__ void advance(int d, int OH, int OW) {
-    ow += d;
-    while (ow >= OW) {
-      ow -= OW;
-      if (++oh == OH) { oh = 0; ++n; }
-    }
-  }
-};
-
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_kernel(const GemmWgradArgs a) {
-  using ST = WgStage<T>;
-  constexpr int NT = 64 * WM * WN;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int ES = sizeof(T);
-  constexpr int PIX = ST::PIX;
-  constexpr int PSTEP = (ES == 2) ? 2 : 1;  // pixels per item
-  constexpr int CW = 16 / ES;               // channels per item
-  constexpr int AI = (ST::template items<BM>() + NT - 1) / NT;
-  constexpr int BI = (ST::template items<BN>() + NT - 1) / NT;
-  static_assert(ST::template items<BM>() % NT == 0 || ST::template items<BM>() < NT, "A items");
-  static_assert(ST::template items<BN>() % NT == 0 || ST::template items<BN>() < NT, "B items");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const As = smem;
-  char* const Bs = smem + 2 * BM * 64;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
-  // blockIdx.x -> (k tile, r, column tile)
-  const int ct = blockIdx.x % a.col_tiles_per_r;
-  const int t1 = blockIdx.x / a.col_tiles_per_r;
-  const int r = t1 % a.R;
-  const int kt = t1 / a.R;
-  const int k0 = kt * BM, j0 = ct * BN;
-  const int c_begin = blockIdx.y * a.chunks_per_split;
-  int c_end = c_begin + a.chunks_per_split;
-  c_end = c_end < a.chunks_total ? c_end : a.chunks_total;
-
-  // per-item state
-  bool a_on[AI], b_on[BI];
-  int a_cg[AI], a_pp[AI], b_cg[BI], b_pp[BI];
-  PixCursor a_cur[AI][PSTEP], b_cur[BI][PSTEP];
-  int a_m[AI], b_m[BI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int id = tid + i * NT;
-    a_on[i] = id < ST::template items<BM>();
-    ST::template decode<BM>(a_on[i] ? id : 0, a_cg[i], a_pp[i]);
-    a_m[i] = c_begin * PIX + a_pp[i] * PSTEP;
-#pragma unroll
-    for (int p = 0; p < PSTEP; ++p) {
-      int m = a_m[i] + p;
-      a_cur[i][p].init(m < a.M ? m : a.M - 1, a.OH, a.OW);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    const int id = tid + i * NT;
-    b_on[i] = id < ST::template items<BN>();
-    ST::template decode<BN>(b_on[i] ? id : 0, b_cg[i], b_pp[i]);
-    b_m[i] = c_begin * PIX + b_pp[i] * PSTEP;
-#pragma unroll
-    for (int p = 0; p < PSTEP; ++p) {
-      int m = b_m[i] + p;
-      b_cur[i][p].init(m < a.M ? m : a.M - 1, a.OH, a.OW);
-    }
-  }
-  // channel offsets (clamped so that every 16-byte load stays inside its pixel / run slack)
-  int a_ch[AI], b_col[BI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    int ch = k0 + a_cg[i] * CW;
-    a_ch[i] = ch < a.Ks ? ch : a.Ks - CW;  // rows >= Ks are never stored
-  }
-#pragma unroll
-  for (int i = 0; i < BI; ++i) b_col[i] = j0 + b_cg[i] * CW;
-
-  int a_rd[TM][2], b_rd[TN][2];
-  frag_offsets<TM, TN, BM / WM, BN / WN>(lane, wm, wn, a_rd, b_rd);
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  f32x16 master[(sizeof(T) == 4) ? TM : 1][(sizeof(T) == 4) ? TN : 1];
-  using TL = TwoLevel<T, (sizeof(T) == 4) ? TM : 1, (sizeof(T) == 4) ? TN : 1>;
-  if constexpr (sizeof(T) == 4) TL::init(master);
-  const T* const DY = reinterpret_cast<const T*>(a.DY);
-  const T* const X = reinterpret_cast<const T*>(a.X);
-  typename ST::Regs areg[AI], breg[BI];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-  auto load_chunk = [&]() {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      if (!a_on[i]) continue;
-#pragma unroll
-      for (int p = 0; p < PSTEP; ++p) {
-        const PixCursor& c = a_cur[i][p];
-        const long long off = a.dy_base + c.n * a.dy_sn + c.oh * a.dy_sh + c.ow * a.dy_sw + a_ch[i];
-        u32x4 v = *reinterpret_cast<const u32x4*>(DY + off);
-        if (a_m[i] + p >= a.M) v = zero4;  // pixels past the end contribute nothing
-        if (p == 0) areg[i].lo = v;
-        else reinterpret_cast<u32x4*>(&areg[i])[PSTEP - 1] = v;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      if (!b_on[i]) continue;
-#pragma unroll
-      for (int p = 0; p < PSTEP; ++p) {
-        const PixCursor& c = b_cur[i][p];
-        const long long off = a.in_base + c.n * a.in_sn + c.oh * a.in_sh + c.ow * a.in_sw +
-                              (long long)r * a.in_sr + b_col[i];
-        u32x4 v = *reinterpret_cast<const u32x4*>(X + off);
-        if (p == 0) breg[i].lo = v;
-        else reinterpret_cast<u32x4*>(&breg[i])[PSTEP - 1] = v;
-      }
-    }
-  };
-  auto advance = [&]() {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      a_m[i] += PIX;
-#pragma unroll
-      for (int p = 0; p < PSTEP; ++p)
-        if (a_m[i] + p < a.M) a_cur[i][p].advance(PIX, a.OH, a.OW);
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      b_m[i] += PIX;
-#pragma unroll
-      for (int p = 0; p < PSTEP; ++p)
-        if (b_m[i] + p < a.M) b_cur[i][p].advance(PIX, a.OH, a.OW);
-    }
-  };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < AI; ++i)
-      if (a_on[i]) ST::write(As + buf * BM * 64, a_cg[i], a_pp[i], areg[i]);
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-      if (b_on[i]) ST::write(Bs + buf * BN * 64, b_cg[i], b_pp[i], breg[i]);
-  };
-
-  if (c_begin < c_end) {
-    load_chunk();
-    store_chunk(0);
-  }
-  __syncthreads();
-  for (int c = c_begin; c < c_end; ++c) {
-    const int cur = (c - c_begin) & 1;
-    const bool more = (c + 1) < c_end;
-    if (more) {
-      advance();
-      load_chunk();
-    }
-    MmaChunk<T, TM, TN>::run(As + cur * BM * 64, Bs + cur * BN * 64, a_rd, b_rd, acc);
-    if constexpr (sizeof(T) == 4) TL::flush(c - c_begin, acc, master);
-    if (more) store_chunk(cur ^ 1);
-    __syncthreads();
-  }
-  if constexpr (sizeof(T) == 4) TL::finish(acc, master);
-
-  // ---- epilogue: scatter the (k, r, j) tile into the fp32 KRSC master-layout gradient (or this split's slab) -----
-  float* const out = a.partial != nullptr ? a.partial + (long long)blockIdx.y * a.slab_stride : a.DW;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = j0 + wn * (BN / WN) + j * 32 + (lane & 31);
-    if (col >= a.run) continue;
-    const int s = col / a.Cs, cc = col - s * a.Cs;
-    if (cc >= a.C) continue;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int k = k0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (k >= a.K) continue;
-        out[(((long long)k * a.R + r) * a.S + s) * a.C + cc] = acc[i][j][e];
-      }
-    }
-  }
-}
-
-// =========================================================================================
-// padding (materialises the padded NHWC input + zeroed slack) and its reflect adjoint
-// =========================================================================================
-// One block per padded row (n, hp): the source row is resolved once, lanes own a channel-vector
-// column and walk the row's pixels -- no integer division in the copy loop.
-template <typename T>
-__global__ __launch_bounds__(256) void pad_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W,
-                                                 int Cs, int pt, int pl, int Hp, int Wp, int mode, int tx_shift,
-                                                 long long total_vec, long long slack_vec) {
-  constexpr int VE = 16 / sizeof(T);
-  const int cv = Cs / VE;
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  const int TX = 1 << tx_shift, TY = 256 >> tx_shift;
-  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> tx_shift;
-  const int rows = N * Hp;
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-    const int n = row / Hp, hp = row - n * Hp;
-    int h = hp - pt;
-    bool row_ok = true;
-    if (mode == JPDSE_PAD_REFLECT) h = h < 0 ? -h : (h >= H ? 2 * (H - 1) - h : h);
-    else row_ok = (h >= 0) & (h < H);
-    const T* srow = src + ((long long)n * H + (row_ok ? h : 0)) * W * Cs;
-    T* drow = dst + (long long)row * Wp * Cs;
-    for (int c = tx; c < cv; c += TX) {
-      for (int wp = ty; wp < Wp; wp += TY) {
-        int w = wp - pl;
-        bool ok = row_ok;
-        if (mode == JPDSE_PAD_REFLECT) w = w < 0 ? -w : (w >= W ? 2 * (W - 1) - w : w);
-        else ok = ok & (w >= 0) & (w < W);
-        u32x4 v = zero4;
-        if (ok) v = *reinterpret_cast<const u32x4*>(srow + (long long)w * Cs + c * VE);
-        *reinterpret_cast<u32x4*>(drow + (long long)wp * Cs + c * VE) = v;
-      }
-    }
-  }
-  if (blockIdx.x == 0)
-    for (long long i = threadIdx.x; i < slack_vec; i += 256) *reinterpret_cast<u32x4*>(dst + (total_vec + i) * VE) = zero4;
-}
-
-// dx[h][w] = sum over the padded-domain aliases of (h,w) of dxp (adjoint of ReflectionPad2d(p))
-template <typename T>
-__global__ void reflect_fold_kernel(const T* __restrict__ dxp, T* __restrict__ dx, int N, int H, int W,
-                                    int Cs, int p, long long total_vec) {
-  constexpr int VE = 16 / sizeof(T);
-  const int cv = Cs / VE;
-  const int Hp = H + 2 * p, Wp = W + 2 * p;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % cv);
-    long long t = idx / cv;
-    const int w = (int)(t % W);
-    t /= W;
-    const int h = (int)(t % H);
-    const int n = (int)(t / H);
-    int hs[3], ws[3], nh = 0, nw = 0;
-    hs[nh++] = h + p;
-    if (h >= 1 && h <= p) hs[nh++] = p - h;
-    if (h <= H - 2 && h >= H - 1 - p) hs[nh++] = p + 2 * (H - 1) - h;
-    ws[nw++] = w + p;
-    if (w >= 1 && w <= p) ws[nw++] = p - w;
-    if (w <= W - 2 && w >= W - 1 - p) ws[nw++] = p + 2 * (W - 1) - w;
-    float accv[VE];
-#pragma unroll
-    for (int e = 0; e < VE; ++e) accv[e] = 0.f;
-    for (int a = 0; a < nh; ++a)
-      for (int b = 0; b < nw; ++b) {
-        float v[VE];
-        Vec16<T>::load(dxp + (((long long)n * Hp + hs[a]) * Wp + ws[b]) * Cs + c * VE, v);
-#pragma unroll
-        for (int e = 0; e < VE; ++e) accv[e] += v[e];
-      }
-    Vec16<T>::store(dx + idx * VE, accv);
-  }
-}
-
-// =========================================================================================
-// filter packing: fp32 KRSC master -> compute-dtype GEMM panels
-// =========================================================================================
-template <typename T>
-__global__ void pack_fwd_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int Ks, int C, int Cs,
-                                int R, int S, int Lk, long long total) {
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(idx % Lk);
-    long long t = idx / Lk;
-    const int r = (int)(t % R);
-    const int k = (int)(t / R);
-    const int s = j / Cs, c = j - s * Cs;
-    float v = 0.f;
-    if (k < K && s < S && c < C) v = w[(((long long)k * R + r) * S + s) * C + c];
-    ElemOps<T>::st(out + idx, v);
-  }
-}
-
-// Toeplitz panel of a stride-1 conv with <= 8 output channels (the 64->3 / 32->3 heads): GEMM column
-// (dl, k) = output pixel ow4*4 + dl, channel k, so that a 32-wide MFMA tile carries 4 pixels x 8 channels
-// instead of 8 channels + 24 dead columns; K-dim = (r, s', c) over the S+3 input pixels the 4 outputs share:
-//   out[(dl*8 + k)][r][s'*Cs + c] = w[k][r][s' - dl][c]   (0 outside the filter)
-template <typename T>
-__global__ void pack_fwd_toep_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int C, int Cs,
-                                     int R, int S, int Lk, long long total) {
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(idx % Lk);
-    long long t = idx / Lk;
-    const int r = (int)(t % R);
-    const int row = (int)(t / R);
-    const int dl = row >> 3, k = row & 7;
-    const int sp = j / Cs, c = j - sp * Cs, s = sp - dl;
-    float v = 0.f;
-    if (k < K && s >= 0 && s < S && c < C) v = w[(((long long)k * R + r) * S + s) * C + c];
-    ElemOps<T>::st(out + idx, v);
-  }
-}
-
-// one stride phase of the data-gradient panel: rows = input channels c, K-dim = (u', w', k)
-template <typename T>
-__global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int Ks, int C, int Cs,
-                                  int R, int S, int st, int qh, int qw, int Uh, int Uw, int Lk,
-                                  long long total) {
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(idx % Lk);
-    long long t = idx / Lk;
-    const int up = (int)(t % Uh);
-    const int c = (int)(t / Uh);
-    const int wp = j / Ks, k = j - wp * Ks;
-    float v = 0.f;
-    if (c < C && k < K && wp < Uw) {
-      const int r = qh + st * (Uh - 1 - up), s = qw + st * (Uw - 1 - wp);
-      v = w[(((long long)k * R + r) * S + s) * C + c];
-    }
-    ElemOps<T>::st(out + idx, v);
-  }
-}
-
-// Fast paths (channel counts that are multiples of 8, i.e. every layer but the network inputs):
-// the forward panel is then the plain compute-dtype cast of the KRSC master (8 elements per lane), and
-// a data-gradient panel is a [k][c] -> [c][k] transpose per filter tap, done through an LDS tile so
-// that both the fp32 reads (along c) and the 16-bit writes (along k) are coalesced.
-template <typename T>
-__global__ void pack_fwd_cast_kernel(const float* __restrict__ w, T* __restrict__ out, long long total8) {
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total8;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(w + idx * 8);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(w + idx * 8 + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ElemOps<T>::st(out + idx * 8 + e, a[e]);
-      ElemOps<T>::st(out + idx * 8 + 4 + e, b[e]);
-    }
-  }
-}
-
-// out[c][up][wp*Ks + k] = w[k][r(up)][s(wp)][c];  grid = (c tiles of 64, k tiles of 64, Uh*Uw taps)
-template <typename T>
-__global__ __launch_bounds__(256) void pack_dgrad_tile_kernel(const float* __restrict__ w, T* __restrict__ out, int K,
-                                                             int Ks, int C, int Cs, int R, int S, int st, int qh,
-                                                             int qw, int Uh, int Uw, int Lk) {
-  __shared__ float tile[64][65];
-  const int c0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int up = blockIdx.z / Uw, wp = blockIdx.z % Uw;
-  const int r = qh + st * (Uh - 1 - up), s = qw + st * (Uw - 1 - wp);
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
-  for (int kk = ty; kk < 64; kk += 4) {
-    const int k = k0 + kk, c = c0 + tx;
-    tile[kk][tx] = (k < K && c < C) ? w[(((long long)k * R + r) * S + s) * C + c] : 0.f;
-  }
-  __syncthreads();
-  for (int cc = ty; cc < 64; cc += 4) {
-    const int c = c0 + cc, k = k0 + tx;
-    if (c < Cs && k < Ks) ElemOps<T>::st(out + ((long long)c * Uh + up) * Lk + wp * Ks + k, tile[tx][cc]);
-  }
-}
-
-// The same transpose for MANY layers / stride phases in one launch (per-layer launches of 8-18 us each added up
-// to 1 ms per optimizer step): block -> table entry by binary search on block0, as in adam_kernel.
-__global__ __launch_bounds__(256) void pack_dgrad_tile_many_kernel(const jpdse_pack_entry* __restrict__ table, int n) {
-  __shared__ float tile[64][65];
-  const long long blk = blockIdx.x;
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (table[mid].block0 <= blk) lo = mid;
-    else hi = mid - 1;
-  }
-  const jpdse_pack_entry e = table[lo];
-  const int id = (int)(blk - e.block0);
-  const int bx = id % e.gx, by = (id / e.gx) % e.gy, bz = id / (e.gx * e.gy);
-  const int c0 = bx * 64, k0 = by * 64;
-  const int up = bz / e.Uw, wp = bz % e.Uw;
-  const int r = e.qh + e.st * (e.Uh - 1 - up), s = e.qw + e.st * (e.Uw - 1 - wp);
-  const int t = threadIdx.x;
-  if ((e.C & 3) == 0) {
-    // 16-byte loads along c (4 per thread), 16-byte stores along k (2 per thread): a quarter of the memory instructions
-    // of the scalar form below (0.34 -> 0.2 ms for the generator's 182 M weights)
-    const int cq = (t & 15) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kk = (t >> 4) + 16 * i;
-      const int k = k0 + kk, c = c0 + cq;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (k < e.K && c < e.C) v = *reinterpret_cast<const f32x4*>(e.w + (((long long)k * e.R + r) * e.S + s) * e.C + c);
-      tile[kk][cq] = v[0];
-      tile[kk][cq + 1] = v[1];
-      tile[kk][cq + 2] = v[2];
-      tile[kk][cq + 3] = v[3];
-    }
-    __syncthreads();
-    bf16_t* const out = reinterpret_cast<bf16_t*>(e.out);
-    const int kq = (t & 7) * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int cc = (t >> 3) + 32 * i;
-      const int c = c0 + cc, k = k0 + kq;
-      if (c < e.Cs && k < e.Ks) {                       // Ks % 8 == 0: the 8 channels are in range together
-        u32x4 pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          pk[j] = (uint32_t)f2bf(tile[kq + 2 * j][cc]) | ((uint32_t)f2bf(tile[kq + 2 * j + 1][cc]) << 16);
-        *reinterpret_cast<u32x4*>(out + ((long long)c * e.Uh + up) * e.Lk + wp * e.Ks + k) = pk;
-      }
-    }
-    return;
-  }
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int kk = ty; kk < 64; kk += 4) {
-    const int k = k0 + kk, c = c0 + tx;
-    tile[kk][tx] = (k < e.K && c < e.C) ? e.w[(((long long)k * e.R + r) * e.S + s) * e.C + c] : 0.f;
-  }
-  __syncthreads();
-  bf16_t* const out = reinterpret_cast<bf16_t*>(e.out);
-  for (int cc = ty; cc < 64; cc += 4) {
-    const int c = c0 + cc, k = k0 + tx;
-    if (c < e.Cs && k < e.Ks) out[((long long)c * e.Uh + up) * e.Lk + wp * e.Ks + k] = f2bf(tile[tx][cc]);
-  }
-}
-
-// dw[i] = sum over b < nslabs of partial[b * stride + i], slabs added in index order (deterministic).  256 threads =
-// 64 consecutive vectors x 4 slab groups, 8 loads in flight per thread; the groups are combined through LDS in a fixed
-// order.  VEC = 4 when the element count and the slab stride are multiples of 4, else 1.
-template <int VEC>
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                         long long nvec, long long stride_vec, int nslabs) {
-  typedef float vec_t __attribute__((ext_vector_type(VEC)));
-  __shared__ vec_t red[4][64];
-  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long long idx = (long long)blockIdx.x * 64 + el;
-  vec_t sum = {};
-  if (idx < nvec) {
-    const vec_t* src = reinterpret_cast<const vec_t*>(partial) + idx;
-    const int per = (nslabs + 3) / 4;
-    const int b0 = grp * per;
-    int b1 = b0 + per;
-    b1 = b1 < nslabs ? b1 : nslabs;
-    int b = b0;
-    for (; b + 8 <= b1; b += 8) {
-      vec_t v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(long long)(b + u) * stride_vec];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) sum += v[u];
-    }
-    for (; b < b1; ++b) sum += src[(long long)b * stride_vec];
-  }
-  red[grp][el] = sum;
-  __syncthreads();
-  if (grp == 0 && idx < nvec) reinterpret_cast<vec_t*>(dw)[idx] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
-}
-
-static int launch_slab_reduce(const float* partial, float* dw, long long n, long long stride, int nslabs, hipStream_t s) {
-  if (n % 4 == 0 && stride % 4 == 0) {
-    const long long nv = n / 4;
-    hipLaunchKernelGGL((slab_reduce_kernel<4>), dim3((unsigned)((nv + 63) / 64)), dim3(256), 0, s, partial, dw, nv, stride / 4, nslabs);
-  } else {
-    hipLaunchKernelGGL((slab_reduce_kernel<1>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, partial, dw, n, stride, nslabs);
-  }
-  return jpdse::check_launch("slab_reduce_kernel");
-}
-
-// =========================================================================================
-// host side: planning and launch
-// =========================================================================================
-static constexpr size_t kSlackBytes = 2048;  // readable, zeroed tail after every padded tensor
-
-static inline int bke(int dtype) { return dtype == JPDSE_BF16 ? 32 : 16; }  // elements per 64-byte chunk
-static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-
-static int validate(const jpdse_conv_desc* d) {
-  JPDSE_REQUIRE(d != nullptr, "conv: null descriptor");
-  JPDSE_REQUIRE(d->dtype == JPDSE_F32 || d->dtype == JPDSE_BF16, "conv: bad dtype %d", d->dtype);
-  JPDSE_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0, "conv: non-positive shape");
-  JPDSE_REQUIRE(d->R > 0 && d->S > 0 && d->R <= 16 && d->S <= 16, "conv: filter %dx%d unsupported", d->R, d->S);
-  JPDSE_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d unsupported", d->stride);
-  JPDSE_REQUIRE(d->R >= d->stride && d->S >= d->stride, "conv: filter smaller than stride");
-  JPDSE_REQUIRE(d->pad >= 0, "conv: negative pad");
-  JPDSE_REQUIRE(d->pad_mode == JPDSE_PAD_ZERO || d->pad_mode == JPDSE_PAD_REFLECT, "conv: bad pad mode");
-  if (d->pad_mode == JPDSE_PAD_REFLECT) {
-    JPDSE_REQUIRE(d->stride == 1, "conv: reflect padding requires stride 1");
-    JPDSE_REQUIRE(d->pad < d->H && d->pad < d->W, "conv: reflect pad %d >= image dim", d->pad);
-  }
-  JPDSE_REQUIRE(d->H + 2 * d->pad >= d->R && d->W + 2 * d->pad >= d->S, "conv: image smaller than filter");
-  return JPDSE_OK;
-}
-
-struct Phase {
-  int qh, qw, Uh, Uw;
-  int i0h, cnth, i0w, cntw;
-  int Lk;
-  size_t pack_off;  // bytes
-};
-
-struct ConvPlan {
-  int ES, BKE;
-  int Cs, Ks, Hp, Wp, OH, OW;
-  int Lk_fwd;
-  // dgrad
-  int nph;
-  Phase ph[4];
-  int PT, PB, PL, PR;  // zero padding of dy
-  int DH, DW;          // padded dy dims
-  size_t dgrad_pack_bytes;
-  size_t xpad_bytes, dypad_bytes, dxp_bytes;
-  size_t splitk_off, splitk_bytes;   // fp32 partial slabs of the split-K fast path (behind the other regions)
-  int toep, Lk_toep;                 // bf16 head (<= 8 output channels, stride 1): extra Toeplitz forward panel
-  int thinf, KP_thin;                // bf16 stride-1 conv on a thin input: extra [R][K][KP] panel (thin_fwd.h)
-  size_t thin_pack_off;
-  size_t fwd_pack_plain_bytes, fwd_pack_bytes;
-};
-
-static void phase_axis(int st, int q, int Rf, int lo, int hi, int& U, int& i0, int& cnt) {
-  U = (Rf - q + st - 1) / st;
-  auto ceil_div = [](int a, int b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); };
-  i0 = ceil_div(lo - q, st);
-  const int i1 = ceil_div(hi - q, st);
-  cnt = i1 - i0;
-  if (cnt < 0) cnt = 0;
-}
-
-// Split-K factor of the fast 256x128 kernel for a GEMM of M rows, Ks output channels and k_tiles
-// 64-wide K-tiles: only when the tiles alone would leave most of the 256 CUs idle.
-JPDSE_SWITCH(int, g_splitk_enabled, 1);   // A/B switches (jpdse_debug_set_fast_path 6 / 5)
-JPDSE_SWITCH(int, g_toep_enabled, 1);
-JPDSE_SWITCH(int, g_thin_out_fast, 1);
-static int splitk_for(int M, int Ks, int k_tiles) {
-  if (!g_splitk_enabled) return 1;
-  // narrow outputs (Ks <= 32: the 512 -> 1 PatchGAN map) only with long reductions
-  if ((Ks <= 64 && !(Ks <= 32 && k_tiles >= 64 && g_thin_out_fast)) || k_tiles < 32 || M <= 0) return 1;
-  const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32);
-  const long long tiles = (long long)((M + 255) / 256) * ((Ks + bn - 1) / bn);
-  if (tiles > 128) return 1;
-  int sp = (int)(256 / tiles);
-  if (sp > k_tiles / 16) sp = k_tiles / 16;
-  if (sp > 8) sp = 8;
-  return sp < 2 ? 1 : sp;
-}
-
-static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
-  p->ES = (int)esize(d->dtype);
-  p->BKE = bke(d->dtype);
-  p->Cs = cpad(d->C);
-  p->Ks = cpad(d->K);
-  p->Hp = d->H + 2 * d->pad;
-  p->Wp = d->W + 2 * d->pad;
-  p->OH = (p->Hp - d->R) / d->stride + 1;
-  p->OW = (p->Wp - d->S) / d->stride + 1;
-  p->Lk_fwd = round_up(d->S * p->Cs, p->BKE);
-  const int st = d->stride;
-  const bool refl = d->pad_mode == JPDSE_PAD_REFLECT;
-  const int lo_h = refl ? 0 : d->pad, hi_h = refl ? p->Hp : d->pad + d->H;
-  const int lo_w = refl ? 0 : d->pad, hi_w = refl ? p->Wp : d->pad + d->W;
-  p->nph = 0;
-  int min_h = 0, max_h = p->OH - 1, min_w = 0, max_w = p->OW - 1;
-  size_t off = 0;
-  for (int qh = 0; qh < st; ++qh)
-    for (int qw = 0; qw < st; ++qw) {
-      Phase& f = p->ph[p->nph++];
-      f.qh = qh;
-      f.qw = qw;
-      phase_axis(st, qh, d->R, lo_h, hi_h, f.Uh, f.i0h, f.cnth);
-      phase_axis(st, qw, d->S, lo_w, hi_w, f.Uw, f.i0w, f.cntw);
-      f.Lk = round_up(f.Uw * p->Ks, p->BKE);
-      f.pack_off = off;
-      off += (size_t)p->Cs * f.Uh * f.Lk * p->ES;
-      off = align_up(off, 256);
-      if (f.cnth > 0 && f.cntw > 0) {
-        min_h = min_h < f.i0h - (f.Uh - 1) ? min_h : f.i0h - (f.Uh - 1);
-        max_h = max_h > f.i0h + f.cnth - 1 ? max_h : f.i0h + f.cnth - 1;
-        min_w = min_w < f.i0w - (f.Uw - 1) ? min_w : f.i0w - (f.Uw - 1);
-        max_w = max_w > f.i0w + f.cntw - 1 ? max_w : f.i0w + f.cntw - 1;
-      }
-    }
-  p->dgrad_pack_bytes = off;
-  p->PT = -min_h;
-  p->PB = max_h - (p->OH - 1);
-  p->PL = -min_w;
-  p->PR = max_w - (p->OW - 1);
-  p->DH = p->OH + p->PT + p->PB;
-  p->DW = p->OW + p->PL + p->PR;
-  p->xpad_bytes = align_up((size_t)d->N * p->Hp * p->Wp * p->Cs * p->ES + kSlackBytes, 256);
-  p->dypad_bytes = align_up((size_t)d->N * p->DH * p->DW * p->Ks * p->ES + kSlackBytes, 256);
-  p->dxp_bytes = refl ? align_up((size_t)d->N * p->Hp * p->Wp * p->Cs * p->ES, 256) : 0;
-  p->fwd_pack_plain_bytes = align_up((size_t)p->Ks * d->R * p->Lk_fwd * p->ES, 256);
-  p->toep = (p->ES == 2 && p->Ks == 8 && st == 1) ? 1 : 0;
-  p->Lk_toep = p->toep ? round_up((d->S + 3) * p->Cs, p->BKE) : 0;
-  p->fwd_pack_bytes = p->fwd_pack_plain_bytes + (p->toep ? align_up((size_t)32 * d->R * p->Lk_toep * p->ES, 256) : 0);
-  p->thinf = (p->ES == 2 && p->Cs % 64 != 0 && p->Cs <= 48 && st <= 2 && (p->Ks == 32 || p->Ks == 64) && d->K == p->Ks) ? 1 : 0;
-  p->KP_thin = p->thinf ? round_up(d->S * p->Cs, 16) + 8 : 0;
-  p->thin_pack_off = p->fwd_pack_bytes;
-  if (p->thinf) p->fwd_pack_bytes += align_up((size_t)d->R * p->Ks * p->KP_thin * 2, 256);
-  if (p->toep) {
-    // the Toeplitz rows of the last pixel group read (S+3)*Cs rounded up to a chunk: keep that inside the slack
-    p->xpad_bytes = align_up(p->xpad_bytes + (size_t)p->BKE * p->ES, 256);
-  }
-  p->splitk_off = p->xpad_bytes > p->dypad_bytes + p->dxp_bytes ? p->xpad_bytes : p->dypad_bytes + p->dxp_bytes;
-  p->splitk_bytes = 0;
-  if (p->ES == 2) {
-    const int sf = splitk_for(d->N * p->OH * p->OW, p->Ks, d->R * d->S * p->Cs / 64);
-    const size_t fwd = sf > 1 ? (size_t)sf * d->N * p->OH * p->OW * p->Ks * 4 : 0;
-    size_t dgr = 0;
-    if (p->nph == 1 && p->ph[0].cnth > 0 && p->ph[0].cntw > 0) {
-      const int Md = d->N * p->ph[0].cnth * p->ph[0].cntw;
-      const int sd = splitk_for(Md, p->Cs, p->ph[0].Uh * p->ph[0].Uw * p->Ks / 64);
-      dgr = sd > 1 ? (size_t)sd * Md * p->Cs * 4 : 0;
-    }
-    p->splitk_bytes = align_up(fwd > dgr ? fwd : dgr, 256);
-  }
-}
-
-template <typename T>
-static int launch_pad(const void* src, void* dst, int N, int H, int W, int Cs, int pt, int pb, int pl, int pr,
-                      int mode, hipStream_t s) {
-  const int Hp = H + pt + pb, Wp = W + pl + pr;
-  const int VE = 16 / (int)sizeof(T);
-  const long long total_vec = (long long)N * Hp * Wp * (Cs / VE);
-  const long long slack_vec = kSlackBytes / 16;
-  int tx_shift = 0;
-  while ((1 << tx_shift) < Cs / VE && tx_shift < 8) ++tx_shift;
-  int grid = N * Hp;
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL((pad_kernel<T>), dim3(grid), dim3(256), 0, s,
-                     reinterpret_cast<const T*>(src), reinterpret_cast<T*>(dst), N, H, W, Cs, pt, pl, Hp, Wp,
-                     mode, tx_shift, total_vec, slack_vec);
-  return check_launch("pad_kernel");
-}
-
-// ---- in-library kernel timer (bench.py "roofline"): hipEvent pairs around the GEMM launches whose
-// (N, K) signature was selected, recorded on the stream the kernel runs on.
-struct GemmProf {
-  bool on = false;
-  int Ks = 0;
-  long long kdim = 0;
-  int used = 0;
-  std::vector<hipEvent_t> ev;   // 2 per launch
-  std::vector<double> flops;
-  std::vector<int> cls;         // 0: forward / data-gradient GEMM; 1: reflect ring strips + fold; 2: weight gradient
-};
-static GemmProf g_prof;
-// regions other than the plain GEMM launches (which record in place): returns the slot or -1
-static int prof_begin(hipStream_t s) {
-  if (!g_prof.on || (size_t)(2 * g_prof.used + 2) > g_prof.ev.size()) return -1;
-  (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  return g_prof.used;
-}
-static void prof_end(int slot, int cls, double flops, hipStream_t s) {
-  if (slot < 0) return;
-  (void)hipEventRecord(g_prof.ev[2 * slot + 1], s);
-  g_prof.flops[slot] = flops;
-  g_prof.cls[slot] = cls;
-  g_prof.used = slot + 1;
-}
-
-template <typename T, int BM, int BN, int WM, int WN>
-static int launch_fwd_cfg(const GemmFwdArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Ks + BN - 1) / BN;
-  const size_t lds = 2 * (BM + BN) * 64;
-  const long long kdim = (long long)a.R * a.cpr * (64 / (int)sizeof(T));
-  const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
-                     (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
-  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_fwd_kernel<T, BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a);
-  if (timed) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
-    g_prof.flops[g_prof.used] = 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
-    g_prof.cls[g_prof.used] = 0;
-    ++g_prof.used;
-  }
-  return check_launch("gemm_fwd_kernel");
-}
-
-template <typename T>
-static int launch_fwd(const GemmFwdArgs& a, hipStream_t s) {
-  if (a.M <= 0) return JPDSE_OK;
-  if (a.Ks > 64) return launch_fwd_cfg<T, 128, 128, 2, 2>(a, s);
-  if (a.Ks > 32) return launch_fwd_cfg<T, 128, 64, 2, 2>(a, s);
-  return launch_fwd_cfg<T, 256, 32, 4, 1>(a, s);
-}
-
-// split count of the generic weight-gradient kernel (shared by the launcher and the workspace query)
-template <typename T, int BM, int BN>
-static int generic_wgrad_splits(const GemmWgradArgs& a, int* chunks_per_split) {
-  const int PIX = WgStage<T>::PIX;
-  const int col_tiles = (a.run + BN - 1) / BN, chunks_total = (a.M + PIX - 1) / PIX;
-  const int tiles = ((a.K + BM - 1) / BM) * a.R * col_tiles;
-  int splits = 1;
-  if (tiles < 512) {
-    splits = (768 + tiles - 1) / tiles;
-    const int max_splits = (chunks_total + 7) / 8;  // >= 8 chunks of work per split
-    if (splits > max_splits) splits = max_splits;
-    if (splits > 64) splits = 64;
-    if (splits < 1) splits = 1;
-  }
-  const int cps = (chunks_total + splits - 1) / splits;
-  if (chunks_per_split) *chunks_per_split = cps;
-  return (chunks_total + cps - 1) / cps;
-}
-
-template <typename T, int BM, int BN, int WM, int WN>
-static int launch_wgrad_cfg(GemmWgradArgs a, float* slabs, hipStream_t s) {
-  const int PIX = WgStage<T>::PIX;
-  a.col_tiles_per_r = (a.run + BN - 1) / BN;
-  a.chunks_total = (a.M + PIX - 1) / PIX;
-  const int tiles = ((a.K + BM - 1) / BM) * a.R * a.col_tiles_per_r;
-  const int splits = generic_wgrad_splits<T, BM, BN>(a, &a.chunks_per_split);
-  const long long n = (long long)a.K * a.R * a.S * a.C;
-  a.partial = splits > 1 ? slabs : nullptr;
-  a.slab_stride = (n + 3) / 4 * 4;
-  const size_t lds = 2 * (BM + BN) * 64;
-  hipLaunchKernelGGL((gemm_wgrad_kernel<T, BM, BN, WM, WN>), dim3(tiles, splits), dim3(64 * WM * WN), lds, s, a);
-  if (int rc = check_launch("gemm_wgrad_kernel")) return rc;
-  return splits > 1 ? launch_slab_reduce(slabs, a.DW, n, a.slab_stride, splits, s) : JPDSE_OK;
-}
-
-template <typename T>
-static size_t generic_wgrad_slab_bytes(const GemmWgradArgs& a) {
-  const int splits = a.K > 64 ? generic_wgrad_splits<T, 128, 128>(a, nullptr)
-                              : (a.K > 32 ? generic_wgrad_splits<T, 64, 128>(a, nullptr) : generic_wgrad_splits<T, 32, 256>(a, nullptr));
-  const long long n = (long long)a.K * a.R * a.S * a.C;
-  return splits > 1 ? (size_t)splits * ((n + 3) / 4 * 4) * sizeof(float) : 0;
-}
-
-template <typename T>
-static int launch_wgrad(const GemmWgradArgs& a, float* slabs, hipStream_t s) {
-  if (a.K > 64) return launch_wgrad_cfg<T, 128, 128, 2, 2>(a, slabs, s);
-  if (a.K > 32) return launch_wgrad_cfg<T, 64, 128, 2, 2>(a, slabs, s);
-  return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, slabs, s);
-}
-
-JPDSE_SWITCH(int, g_fast_xcd, 0);         // 30: N-tiles of an M-tile on one XCD (measured neutral: +5 % on the PatchGAN layer-3 data gradient, -4 % on the 1024 -> 512 ConvTranspose; memory-side fetch is not what bounds these layers)
-template <int WM, int WN, int TM, int TN, int VAR, int STAGES = 3>
-static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int lds = STAGES * (BM + BN) * 128;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<WM, WN, TM, TN, VAR, STAGES>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_fast: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    configured = true;
-  }
-  int total = 0;
-  double flops = 0.0;
-  bool timed = g_prof.on && (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
-  for (int i = 0; i < b.n; ++i) {
-    const FastArgs& a = b.p[i];
-    if ((a.Y == nullptr && !a.no_finish) || ((a.splits > 1 || a.no_finish) && a.partial == nullptr))
-      return set_error(JPDSE_EINVAL, "gemm_fast: problem %d has no output buffer", i);
-    if ((a.x_sh ? a.x_sh : (long long)a.IW * a.Cs) * a.IH >= (1LL << 31))
-      return set_error(JPDSE_EINVAL, "gemm_fast: one image spans >= 2^31 elements (in-image offsets are 32-bit)");
-    if (a.x_extent > 0 && a.OH > 0 && a.OW > 0) {
-      // sub-image problems (the ring strips of the reflect data gradient address rows / columns of a larger tensor through
-      // x_sn / x_sh): the last element the loader can touch must lie inside the tensor -- a wrong stride or base here is
-      // a GPU memory fault, not a wrong number (the round-1 abort)
-      const long long n_img = a.M / ((long long)a.OH * a.OW);
-      const long long sn = a.x_sn ? a.x_sn : (long long)a.IH * a.IW * a.Cs, sh = a.x_sh ? a.x_sh : (long long)a.IW * a.Cs;
-      const long long last = (n_img - 1) * sn + (long long)(a.IH - 1) * sh + (long long)(a.IW - 1) * a.Cs + a.Cs;
-      if (n_img < 1 || last > a.x_extent)
-        return set_error(JPDSE_EINVAL, "gemm_fast: problem %d addresses element %lld of a %lld-element input", i, last, a.x_extent);
-    }
-    b.first_tile[i] = total;
-    b.p[i].xcd_map = (g_fast_xcd && a.splits <= 1 && (a.Ks + BN - 1) / BN >= 2 && (a.M + BM - 1) / BM >= 16) ? 1 : 0;
-    total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN) * (a.splits > 1 ? a.splits : 1);
-    const long long kdim = (long long)a.R * a.S * a.Cs;
-    flops += 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
-    timed = timed && b.n == 1 && a.Ks == g_prof.Ks && kdim == g_prof.kdim;
-  }
-  for (int i = b.n; i < 5; ++i) b.first_tile[i] = total;
-  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, TM, TN, VAR, STAGES>), dim3(total), dim3(64 * WM * WN), lds, s, b);
-  if (b.n == 1 && b.p[0].splits > 1 && !b.p[0].no_finish) {
-    const long long total_vec = (long long)b.p[0].M * (b.p[0].Ks / 8);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(ew_blocks(total_vec)), dim3(256), 0, s, b.p[0], total_vec);
-  }
-  if (timed) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
-    g_prof.flops[g_prof.used] = flops;
-    g_prof.cls[g_prof.used] = 0;
-    ++g_prof.used;
-  }
-  return check_launch("gemm_fast_kernel");
-}
-
-static bool prefer_320(int M, int Ks) {
-  // one round of 320-row tiles beats two rounds of 256-row tiles (e.g. the ResnetBlock data gradient
-  // on the reflect-padded domain: M = 8976 -> 232 tiles instead of 288 on 256 CUs)
-  if (Ks <= 64) return false;
-  const long long nt = (Ks + 127) / 128;
-  const long long t256 = (long long)((M + 255) / 256) * nt, t320 = (long long)((M + 319) / 320) * nt;
-  const long long c256 = ((t256 + 255) / 256) * 256, c320 = ((t320 + 255) / 256) * 320;
-  return c320 < c256;
-}
-
-JPDSE_SWITCH(int, g_fast_small, 20);      // K-tile count up to which the 128-row / 2-stage fast configs are used
-static int launch_fast_batch(FastBatch& b, hipStream_t s) {
-  if (b.n <= 0) return JPDSE_OK;
-  const int Ks = b.p[0].Ks;
-  if (b.n == 1 && b.p[0].splits > 1) {   // split-K
-    if (Ks > 64) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);
-    if (Ks > 32) return launch_fast_cfg<4, 2, 2, 1, 0>(b, s);
-    return launch_fast_cfg<8, 1, 1, 1, 0>(b, s);
-  }
-  for (int i = 0; i < b.n; ++i)
-    if (b.n > 1 && !b.p[i].no_finish) b.p[i].splits = 1;
-  if (b.small_m) {
-    if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);
-    if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);
-  }
-  int kt = 0;
-  for (int i = 0; i < b.n; ++i) {
-    const int k = b.p[i].R * b.p[i].S * (b.p[i].Cs / 64);
-    kt = k > kt ? k : kt;
-  }
-  if (g_fast_small && kt <= g_fast_small && b.p[0].splits <= 1) {
-    // short reductions are prologue / epilogue bound: 128-row tiles, 4 waves, 2 stages = 64 (48) KiB of LDS, so two
-    // (three) blocks share a CU and overlap each other's fill and store phases
-    if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);   // 128 x 128
-    if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);   // 128 x 64
-  }
-  if (b.n == 1 && prefer_320(b.p[0].M, Ks)) return launch_fast_cfg<2, 4, 5, 1, 0, 2>(b, s);   // 320 x 128, 2 stages
-  if (Ks > 64) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // 256 x 128
-  if (Ks > 32) return launch_fast_cfg<4, 2, 2, 1, 0>(b, s);   // 256 x 64
-  return launch_fast_cfg<8, 1, 1, 1, 0>(b, s);                // 256 x 32
-}
-
-static int launch_fast(const FastArgs& a, hipStream_t s) {
-  if (a.M <= 0) return JPDSE_OK;
-  FastBatch b = {};
-  b.p[0] = a;
-  b.n = 1;
-  return launch_fast_batch(b, s);
-}
-
-JPDSE_SWITCH(bool, g_fast_enabled, true);   // jpdse_debug_set_fast_path(0) forces the generic kernels (A/B tests)
-
-// The fast kernel runs ONE 256-row tile per CU (144 KiB of LDS), so its grid should either cover
-// the 256 CUs many times over or be an exact multiple of them; in between (e.g. the 288 tiles of the
-// ResnetBlock data gradient) the generic 128x128 kernel with 3 co-resident blocks per CU wins
-// (measured: scripts/bench_conv.py, profiles/r01_conv_layers_*.log).
-static bool prefer_320(int M, int Ks);
-static bool fast_pays(int M, int Ks, int k_tiles) {
-  if (!g_fast_enabled) return false;
-  if (k_tiles < 8) return false;   // short reductions (stride-2 sub-pixel phases of 2x2 taps x 64 ch) do not fill the 3-stage ring
-  if (Ks <= 32) {
-    // measured: the generic 256x32 kernel beats the 8-wave 256x32 fast config on short reductions; with a long
-    // one (512 -> 1 PatchGAN map, K = 8192) the fast kernel needs no padded copy and streams the input by DMA
-    if (!(g_thin_out_fast && k_tiles >= 64)) return false;
-    return splitk_for(M, Ks, k_tiles) > 1 || (M + 255) / 256 >= 128;
-  }
-  if (splitk_for(M, Ks, k_tiles) > 1) return true;
-  const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32);
-  const long long tiles = (long long)((M + 255) / 256) * ((Ks + bn - 1) / bn);
-  if (prefer_320(M, Ks)) {
-    const long long t320 = (long long)((M + 319) / 320) * ((Ks + 127) / 128);
-    if (t320 % 256 == 0 || t320 % 256 >= 192 || t320 >= 448) return true;   // well-filled rounds
-  }
-  return tiles >= 448 || (tiles >= 256 && tiles % 256 == 0);
-}
-
-JPDSE_SWITCH(int, g_ring_enabled, 1);
-JPDSE_SWITCH(int, g_ring_small, 0);       // 31: ring strips on 128-row tiles, two blocks per CU (measured slower: 873 vs 955 TFLOP/s for the whole data gradient)
-JPDSE_SWITCH(int, g_merge_min_kt, 4);
-JPDSE_SWITCH(int, g_merge_min_tiles, 64);    // merged stride-phase data gradient on the fast kernel from this many 256-row tiles on (26: 384 as in round 1, A/B)
-JPDSE_SWITCH(int, g_halo_single, 1);
-JPDSE_SWITCH(int, g_halo_enabled, 1);
-JPDSE_SWITCH(int, g_halo_abl, 0);
-
-template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false>
-static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
-  constexpr int BN = 2 * TN * 32;
-  constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
-  constexpr int lds = (SINGLE ? 1 : 2) * UH * 1024 + 3 * BN * 128;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    configured = true;
-  }
-  const int tiles = a.N * (a.OH / 4) * (a.OW / 64) * ((a.Ks + BN - 1) / BN);
-  const long long kdim = 9LL * a.Cs;
-  const int M = a.N * a.OH * a.OW;
-  const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
-                     (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
-  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM>), dim3(tiles), dim3(512), lds, s, a);
-  if (timed) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
-    g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
-    g_prof.cls[g_prof.used] = 0;
-    ++g_prof.used;
-  }
-  return check_launch("gemm_halo_kernel");
-}
-
-JPDSE_SWITCH(int, g_halo_xcd, 0);
-JPDSE_SWITCH(int, g_halo_stag, 0);
-JPDSE_SWITCH(int, g_halo_pipe, 0);      // 25: software-pipelined fragment reads (A/B)      // 23: waves 4..7 issue their DMA group after the MFMA cluster (A/B)
-JPDSE_SWITCH(int, g_halo_mf16, 0);     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
-template <int TN, int ABL = 0>
-static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
-  HaloArgs a = a0;
-  a.xcd_mode = g_halo_xcd;
-  if (a.mom != nullptr) {                 // conv -> InstanceNorm with the moments in this kernel's epilogue (double-buffered form)
-    if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, false, false, true>(a, s);
-  }
-#ifdef JPDSE_DEV
-  if (ABL == 0 && g_halo_mf16) {
-    if (a.Cs == 64 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, true>(a, s);
-    return launch_halo_cfg_impl<TN, 0, false, true>(a, s);
-  }
-  if (ABL == 0 && g_halo_stag) return launch_halo_cfg_impl<TN, 0, false, false, true>(a, s);
-  if (ABL == 0 && g_halo_pipe == 1 && a.Cs != 64) return launch_halo_cfg_impl<TN, 0, false, false, false, true>(a, s);
-  if (ABL == 0 && g_halo_pipe == 1 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, false, false, true>(a, s);
-#endif
-  if (a.Cs == 64 && ABL == 0 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true>(a, s);   // one slab: single patch buffer
-  return launch_halo_cfg_impl<TN, ABL, false>(a, s);
-}
-
-
-
-// band height of the row-streaming kernels: as tall as possible (the filter load and the ring prologue are paid once per block)
-// while the grid still fills the chip (`want` blocks); small problems take 16 / 8 / 4
-static int rows_band_height(int N, int OH, int strips, int n_tiles, long long want, int min_th = 4) {
-  for (int cand = 64; cand >= min_th; cand >>= 1) {
-    if (OH % cand != 0) continue;
-    if ((long long)N * strips * (OH / cand) * n_tiles >= want) return cand;
-  }
-  for (int cand = 16; cand >= min_th; cand >>= 1)
-    if (OH % cand == 0) return cand;
-  return min_th;
-}
-
-// 3x3 convs over 64-channel inputs (stride 1 | 2, zero padding): filter in registers, input rows streamed once (conv_rows.h)
-JPDSE_SWITCH(int, g_rows_enabled, 1);       // 29: these layers on the halo / fast kernels (A/B)
-
-static bool rows_ok(int R, int S, int stride, int reflect, int act, int OH, int OW, int Cs_in, int Ks_out) {
-  return g_fast_enabled && g_rows_enabled && R == 3 && S == 3 && (stride == 1 || stride == 2) && !reflect && Cs_in == 64 &&
-         Ks_out % 64 == 0 && OW % 64 == 0 && OH % 4 == 0 &&
-         (act == JPDSE_ACT_NONE || act == JPDSE_ACT_RELU || act == JPDSE_ACT_LRELU);
-}
-
-template <int STRIDE, int WC, bool FUSED>
-static int launch_rows_cfg(RowsArgs a, hipStream_t s) {
-  typedef RowsGeom<STRIDE, WC> G;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_kernel<STRIDE, WC, FUSED>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "conv_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
-    configured = true;
-  }
-  a.n_tiles = a.Ks / (32 * WC);
-  a.strips = a.OW / 64;
-  a.TH = rows_band_height(a.N, a.OH, a.strips, a.n_tiles, 256LL * ((STRIDE == 1 && WC == 2) ? 2 : 1));
-  const int th = a.TH;
-  a.bands = a.OH / th;
-  a.mom_slots = a.bands * a.strips * (4 / WC);
-  const long long blocks = (long long)a.N * a.bands * a.strips * a.n_tiles;
-  if (blocks > 0x7fffffffLL) return set_error(JPDSE_EINVAL, "conv_rows: grid too large");
-  hipLaunchKernelGGL((conv_rows_kernel<STRIDE, WC, FUSED>), dim3((unsigned)blocks), dim3(256), G::LDS, s, a);
-  return check_launch("conv_rows_kernel");
-}
-
-static int launch_rows(const RowsArgs& a, int stride, hipStream_t s) {
-  const bool fused = a.mask != nullptr || a.addend != nullptr;
-  const bool wide = a.Ks % 128 == 0;
-  if (stride == 1) {
-    if (wide) return fused ? launch_rows_cfg<1, 4, true>(a, s) : launch_rows_cfg<1, 4, false>(a, s);
-    return fused ? launch_rows_cfg<1, 2, true>(a, s) : launch_rows_cfg<1, 2, false>(a, s);
-  }
-  if (wide) return fused ? launch_rows_cfg<2, 4, true>(a, s) : launch_rows_cfg<2, 4, false>(a, s);
-  return fused ? launch_rows_cfg<2, 2, true>(a, s) : launch_rows_cfg<2, 2, false>(a, s);
-}
-
-
-// data gradient of the 64 -> 128 3x3 stride-2 conv / forward of the 128 -> 64 ConvTranspose2d at full resolution (dgrad2_rows.h)
-static int launch_dgrad2_rows(Dgrad2Args a, hipStream_t s) {
-  typedef Dgrad2Geom G;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_rows_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "dgrad2_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
-    configured = true;
-  }
-  a.strips = a.OW / 64;
-  const int th = rows_band_height(a.N, a.OH, a.strips, 1, 256);
-  a.TH = th;
-  a.bands = a.OH / th;
-  a.mom_slots = a.bands * a.strips;
-  hipLaunchKernelGGL(dgrad2_rows_kernel, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
-  return check_launch("dgrad2_rows_kernel");
-}
-
-
-// 64 -> <= 3 channel heads (7x7 reflect + Tanh; 3x3 zero-pad data gradient of VGG conv1_1) as a row-streaming pass (head_rows.h)
-static bool head_rows_ok(const HeadFwdArgs& a, int cin) {
-  return g_rows_enabled && cin == 64 && a.K <= 3 && a.Ks_out == 8 && a.OW % 128 == 0 && a.OH % 8 == 0 && a.OH == a.H && a.OW == a.W;
-}
-template <int R>
-static int launch_head_rows(const HeadFwdArgs& a, hipStream_t s) {
-  typedef HeadRowsGeom<R> G;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_rows_kernel<R>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "head_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
-    configured = true;
-  }
-  const int strips = a.OW / 128;
-  int th = 0;
-  for (int cand = 64; cand >= 8; cand >>= 1) {
-    if (a.OH % cand != 0) continue;
-    if ((long long)a.N * strips * (a.OH / cand) >= 512) { th = cand; break; }
-  }
-  if (th == 0)
-    for (int cand = 16; cand >= 8; cand >>= 1)
-      if (a.OH % cand == 0) { th = cand; break; }
-  const int bands = a.OH / th;
-  hipLaunchKernelGGL((head_rows_kernel<R>), dim3((unsigned)(a.N * bands * strips)), dim3(256), G::LDS, s, a, th, bands, strips);
-  return check_launch("head_rows_kernel");
-}
-
-
-// data gradient of PatchGAN layer 0 with respect to the image channels (thin_dgrad2_rows.h)
-static int launch_thin_dgrad2_rows(ThinDgrad2Args a, hipStream_t s) {
-  typedef ThinDgrad2Geom G;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_dgrad2_rows_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_dgrad2_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
-    configured = true;
-  }
-  a.strips = a.W / 256;
-  int th = 0;
-  for (int cand = 64; cand >= 8; cand >>= 1) {
-    if (a.H % cand != 0) continue;
-    if ((long long)a.N * a.strips * (a.H / cand) >= 512) { th = cand; break; }
-  }
-  if (th == 0)
-    for (int cand = 16; cand >= 8; cand >>= 1)
-      if (a.H % cand == 0) { th = cand; break; }
-  a.TH = th;
-  a.bands = a.H / th;
-  hipLaunchKernelGGL(thin_dgrad2_rows_kernel, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
-  return check_launch("thin_dgrad2_rows_kernel");
-}
-
-
-// PatchGAN layer 0 forward (40-channel input, 4x4 stride 2, 64 outputs) as a row-streaming pass (thin_rows.h)
-static int launch_thin_rows(ThinFwdArgs a, hipStream_t s) {
-  typedef ThinRowsGeom G;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_rows_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
-    configured = true;
-  }
-  a.tiles_w = (a.OW + 63) / 64;
-  // band height: fewest (rounds of 512 blocks: two per CU) x (rows per block + the ~4 rows a block pays for its filter load and prologue)
-  int th = 8;
-  long long best = -1;
-  for (int cand = 64; cand >= 8; cand >>= 1) {
-    const long long blocks = (long long)a.N * ((a.OH + cand - 1) / cand) * a.tiles_w;
-    const long long cost = ((blocks + 511) / 512) * (cand + 4);
-    if (best < 0 || cost < best) { best = cost; th = cand; }
-  }
-  const int bands = (a.OH + th - 1) / th;
-  hipLaunchKernelGGL(thin_rows_kernel, dim3((unsigned)(a.N * bands * a.tiles_w)), dim3(256), G::LDS, s, a, th, bands);
-  return check_launch("thin_rows_kernel");
-}
-
-
-// dense 8-channel inputs, 64 outputs, as a row-streaming pass (thin_in_rows.h): the data gradient of the 64 -> 3 7x7 reflect-padded
-// head (padded-domain conv with the interior written straight into dx, then the ring fold) and VGG conv1_1 forward (3x3, zero pad)
-template <int R, bool DUAL>
-static int launch_thin_in_rows(ThinInArgs a, hipStream_t s) {
-  typedef ThinInGeom<R> G;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_in_rows_kernel<R, DUAL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_in_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
-    configured = true;
-  }
-  a.strips = (a.OW + 63) / 64;
-  int th = 8;
-  long long best = -1;
-  for (int cand = 64; cand >= 8; cand >>= 1) {
-    const long long blocks = (long long)a.N * ((a.OH + cand - 1) / cand) * a.strips;
-    const long long cost = ((blocks + 511) / 512) * (cand + 4);
-    if (best < 0 || cost < best) { best = cost; th = cand; }
-  }
-  a.TH = th;
-  a.bands = (a.OH + th - 1) / th;
-  hipLaunchKernelGGL((thin_in_rows_kernel<R, DUAL>), dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
-  if (int rc = check_launch("thin_in_rows_kernel")) return rc;
-  if (DUAL) {
-    const int band = G::PAD + 1;
-    const long long per_img = 2LL * band * a.W + (long long)(a.H - 2 * band) * 2 * band;
-    const long long total_vec = (long long)a.N * per_img * (64 / 8);
-    hipLaunchKernelGGL((reflect_ring_fold_kernel<bf16_t>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, a.DXP, a.DX, a.N, a.H, a.W,
-                       64, G::PAD, total_vec);
-    return check_launch("reflect_ring_fold_kernel");
-  }
-  return JPDSE_OK;
-}
-
-// ---- tap-program halo kernel (gemm_taps.h): all four sub-pixel phases of a stride-2 data gradient / ConvTranspose forward
-JPDSE_SWITCH(int, g_taps_enabled, 1);       // 35: these layers on the merged-phase fast kernel (A/B)
-
-// 3x3 stride-2 (pad 1, even input): phases (0,0) 2x2 taps, (0,1) 2x1, (1,0) 1x2, (1,1) 1x1 over the same dy pixels
-static bool taps_dgrad2_ok(const jpdse_conv_desc* d, const ConvPlan& p, const void* mask, const void* addend, const float* mom) {
-  if (!(g_fast_enabled && g_taps_enabled) || d->dtype != JPDSE_BF16 || d->pad_mode == JPDSE_PAD_REFLECT) return false;
-  if (d->stride != 2 || d->R != 3 || d->S != 3 || d->pad != 1 || p.nph != 4) return false;
-  if (mom != nullptr) return false;
-  if (d->H != 2 * p.OH || d->W != 2 * p.OW || p.OH % 4 != 0 || p.OW % 64 != 0) return false;
-  if (p.Ks % 64 != 0 || p.Ks < 128 || p.Cs % 64 != 0) return false;
-  // the kernel's loaders carry 32-bit element offsets into dy and into each phase's panel
-  if ((long long)d->N * p.OH * p.OW * p.Ks >= (1LL << 31) || (long long)p.Cs * 4 * p.Ks >= (1LL << 31)) return false;
-  for (int i = 0; i < 4; ++i) {
-    const Phase& f = p.ph[i];
-    if (f.cnth != p.OH || f.cntw != p.OW || f.Lk != f.Uw * p.Ks) return false;
-    if (f.Uh != (f.qh == 0 ? 2 : 1) || f.Uw != (f.qw == 0 ? 2 : 1)) return false;
-    if ((f.Uh - 1) - f.i0h != 0 || (f.Uw - 1) - f.i0w != 0) return false;      // every phase starts at dy pixel (oh, ow)
-  }
-  return true;
-}
-
-template <int TN>
-static int launch_taps_dgrad2_cfg(const TapsArgs& a, int total, hipStream_t s) {
-  constexpr int PH = 5, PW = 65;
-  constexpr int lds = 2 * ((PH * PW + 7) / 8) * 1024 + 3 * (2 * TN * 32) * 128;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_taps_kernel<TN, 4, 1, 2, 2, 1, PH, PW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_taps: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    configured = true;
-  }
-  hipLaunchKernelGGL((gemm_taps_kernel<TN, 4, 1, 2, 2, 1, PH, PW>), dim3(total), dim3(512), lds, s, a);
-  return check_launch("gemm_taps_kernel");
-}
-
-static int launch_taps_dgrad2(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx, hipStream_t s,
-                              const void* mask, const void* addend) {
-  TapsArgs a = {};
-  a.mask = reinterpret_cast<const bf16_t*>(mask);
-  a.addend = reinterpret_cast<const bf16_t*>(addend);
-  a.X = reinterpret_cast<const bf16_t*>(dy);
-  a.Y = reinterpret_cast<bf16_t*>(dx);
-  a.N = d->N;
-  a.OH = p.OH;
-  a.OW = p.OW;
-  a.IH = p.OH;
-  a.IW = p.OW;
-  a.Cs = p.Ks;
-  a.py = a.px = 0;
-  a.Kout = d->C;
-  a.Ks = p.Cs;
-  a.b_rows = p.Cs;
-  a.out_sn = (long long)d->H * d->W * p.Cs;
-  a.out_sh = 2LL * d->W * p.Cs;
-  a.out_sw = 2LL * p.Cs;
-  a.act = JPDSE_ACT_NONE;
-  // program 0 = {phase (0,0): 4 taps, phase (1,1): 1 tap}, program 1 = {phase (0,1): 2 taps, phase (1,0): 2 taps}
-  const Phase* byq[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  for (int i = 0; i < 4; ++i) byq[p.ph[i].qh][p.ph[i].qw] = &p.ph[i];
-  const Phase* sets[2][2] = {{byq[0][0], byq[1][1]}, {byq[0][1], byq[1][0]}};
-  constexpr int PW = 65;
-  for (int g = 0; g < 2; ++g) {
-    int t = 0;
-    for (int q = 0; q < 2; ++q) {
-      const Phase& f = *sets[g][q];
-      a.prog[g].B[q] = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
-      a.prog[g].ktot[q] = (long long)f.Uh * f.Lk;
-      a.prog[g].out_base[q] = ((long long)(2 * f.i0h + f.qh - d->pad) * d->W + (2 * f.i0w + f.qw - d->pad)) * p.Cs;
-      for (int u = 0; u < f.Uh; ++u)
-        for (int w = 0; w < f.Uw; ++w) {
-          a.prog[g].tap_off[t] = u * PW + w;
-          a.prog[g].tap_koff[t] = u * f.Lk + w * p.Ks;
-          ++t;
-        }
-    }
-  }
-  const int bn = p.Cs % 128 == 0 ? 128 : 64;
-  a.nblk0 = d->N * (p.OH / 4) * (p.OW / 64) * ((p.Cs + bn - 1) / bn);
-  return bn == 128 ? launch_taps_dgrad2_cfg<2>(a, 2 * a.nblk0, s) : launch_taps_dgrad2_cfg<1>(a, 2 * a.nblk0, s);
-}
-
-// ---- 4x4 stride-1 zero-padded convs and their (single-phase) data gradient on the tap-program kernel: PatchGAN layer 3 of
-// both scales (networks.py:430-449).  Their grids are odd (66 x 130, 34 x 66): the kernel's 8 x 32 tiles cover the CORE
-// (64 x 128: 95 % of the pixels) with the 11 x 35 input patch staged once per 64-channel slab for all 16 taps; the fringe (the
-// last OH % 8 rows, the last OW % 32 columns) runs as two sub-rectangle problems of ONE split-K launch of gemm_fast_kernel
-// (fp32 slabs, fixed summation order) + its finish kernels.
-JPDSE_SWITCH(int, g_taps4_enabled, 1);      // 36: these layers on the fast kernel alone (A/B)
-
-struct Taps4View {            // a stride-1 4x4 conv as the kernels see it: forward, or the data gradient over dy
-  const bf16_t* X; const bf16_t* B; const float* bias; bf16_t* Y;
-  int N, IH, IW, Cin_s, OH, OW, py, px, Kout, Ks_out;
-  long long ktot;             // panel row stride (elements)
-  int tap_r, tap_s;           // panel offsets per filter-row / filter-column step
-  int act; float slope;
-  const bf16_t* addend; const bf16_t* mask;   // optional fused operands of a data gradient (Y's addressing)
-};
-
-static bool taps4_shape_ok(int R, int S, int stride, int OH, int OW, int Cin_s, int Ks_out, long long x_elems, long long b_elems) {
-  return g_fast_enabled && g_taps4_enabled && R == 4 && S == 4 && stride == 1 && OH >= 8 && OW >= 32 && Cin_s % 64 == 0 &&
-         Cin_s >= 128 && Ks_out % 64 == 0 && Ks_out >= 64 && x_elems < (1LL << 31) && b_elems < (1LL << 31);
-}
-
-static int taps4_fringe_splits(int N, int OH, int OW, int Ks_out, int k_tiles) {
-  const int OHc = OH / 8 * 8, OWc = OW / 32 * 32;
-  const long long m_bot = (long long)N * (OH - OHc) * OW, m_right = (long long)N * OHc * (OW - OWc);
-  const long long nt = (Ks_out + 127) / 128;
-  const long long tiles = ((m_bot + 255) / 256 + (m_right + 255) / 256) * nt;
-  if (tiles <= 0) return 0;
-  long long sp = 256 / tiles;
-  if (sp > k_tiles / 8) sp = k_tiles / 8;
-  if (sp > 8) sp = 8;
-  return sp < 1 ? 1 : (int)sp;
-}
-
-static size_t taps4_fringe_bytes(int N, int OH, int OW, int Ks_out, int k_tiles) {
-  const int OHc = OH / 8 * 8, OWc = OW / 32 * 32;
-  const long long m = (long long)N * (OH - OHc) * OW + (long long)N * OHc * (OW - OWc);
-  return (size_t)taps4_fringe_splits(N, OH, OW, Ks_out, k_tiles) * m * Ks_out * sizeof(float);
-}
-
-template <int TN>
-static int launch_taps4_cfg(const TapsArgs& a, int total, hipStream_t s) {
-  constexpr int PH = 11, PW = 35;
-  constexpr int lds = 2 * ((PH * PW + 7) / 8) * 1024 + 3 * (2 * TN * 32) * 128;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_taps_kernel<TN, 16, 0, 0, 0, 2, PH, PW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_taps(4x4): hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    configured = true;
-  }
-  hipLaunchKernelGGL((gemm_taps_kernel<TN, 16, 0, 0, 0, 2, PH, PW>), dim3(total), dim3(512), lds, s, a);
-  return check_launch("gemm_taps_kernel(4x4)");
-}
-
-static int launch_taps4(const Taps4View& v, void* ws, hipStream_t s) {
-  const int OHc = v.OH / 8 * 8, OWc = v.OW / 32 * 32;
-  TapsArgs a = {};
-  a.X = v.X;
-  a.Y = v.Y;
-  a.bias = v.bias;
-  a.N = v.N;
-  a.OH = OHc;
-  a.OW = OWc;
-  a.IH = v.IH;
-  a.IW = v.IW;
-  a.Cs = v.Cin_s;
-  a.py = v.py;
-  a.px = v.px;
-  a.Kout = v.Kout;
-  a.Ks = v.Ks_out;
-  a.b_rows = v.Ks_out;
-  a.out_sn = (long long)v.OH * v.OW * v.Ks_out;
-  a.out_sh = (long long)v.OW * v.Ks_out;
-  a.out_sw = v.Ks_out;
-  a.act = v.act;
-  a.slope = v.slope;
-  a.addend = v.addend;
-  a.mask = v.mask;
-  a.prog[0].B[0] = v.B;
-  a.prog[0].ktot[0] = v.ktot;
-  a.prog[0].out_base[0] = 0;
-  for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) {
-      a.prog[0].tap_off[r * 4 + c] = r * 35 + c;
-      a.prog[0].tap_koff[r * 4 + c] = r * v.tap_r + c * v.tap_s;
-    }
-  const int bn = v.Ks_out % 128 == 0 ? 128 : 64;
-  a.nblk0 = v.N * (OHc / 8) * (OWc / 32) * ((v.Ks_out + bn - 1) / bn);
-  if (int rc = bn == 128 ? launch_taps4_cfg<2>(a, a.nblk0, s) : launch_taps4_cfg<1>(a, a.nblk0, s)) return rc;
-  // fringe: bottom rows [OHc, OH) x all columns, right columns [OWc, OW) x rows [0, OHc)
-  const int k_tiles = 16 * v.Cin_s / 64;
-  const int sp = taps4_fringe_splits(v.N, v.OH, v.OW, v.Ks_out, k_tiles);
-  if (sp == 0) return JPDSE_OK;
-  FastBatch fb = {};
-  float* slab = reinterpret_cast<float*>(ws);
-  const int rect[2][4] = {{OHc, 0, v.OH - OHc, v.OW}, {0, OWc, OHc, v.OW - OWc}};     // oh0, ow0, rows, cols
-  for (int q = 0; q < 2; ++q) {
-    const int oh0 = rect[q][0], ow0 = rect[q][1], rows = rect[q][2], cols = rect[q][3];
-    if (rows <= 0 || cols <= 0) continue;
-    FastArgs g = {};
-    g.X = v.X;
-    g.B = v.B;
-    g.bias = v.bias;
-    g.Y = v.Y;
-    g.M = v.N * rows * cols;
-    g.OH = rows;
-    g.OW = cols;
-    g.IH = v.IH;
-    g.IW = v.IW;
-    g.Cs = v.Cin_s;
-    g.R = g.S = 4;
-    g.sy = g.sx = 1;
-    g.py = v.py - oh0;
-    g.px = v.px - ow0;
-    g.reflect = 0;
-    g.Kout = v.Kout;
-    g.Ks = v.Ks_out;
-    g.b_rows = v.Ks_out;
-    g.out_sn = a.out_sn;
-    g.out_sh = a.out_sh;
-    g.out_sw = a.out_sw;
-    g.out_base = ((long long)oh0 * v.OW + ow0) * v.Ks_out;
-    g.act = v.act;
-    g.slope = v.slope;
-    g.splits = sp;
-    g.no_finish = 1;
-    g.partial = slab;
-    g.b_stride = v.ktot;
-    g.b_tap_r = v.tap_r;
-    g.b_tap_s = v.tap_s;
-    g.addend = v.addend;        // applied by splitk_finish_kernel
-    g.mask = v.mask;
-    slab += (size_t)sp * g.M * v.Ks_out;
-    fb.p[fb.n++] = g;
-  }
-  if (int rc = launch_fast_batch(fb, s)) return rc;
-  for (int q = 0; q < fb.n; ++q) {
-    const long long total_vec = (long long)fb.p[q].M * (fb.p[q].Ks / 8);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(ew_blocks(total_vec)), dim3(256), 0, s, fb.p[q], total_vec);
-  }
-  return check_launch("taps4 fringe finish");
-}
-
-// 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
-// gradient of the zero-padded ones): LDS-resident input halo, see gemm_halo.h
-static bool halo_ok(int R, int S, int stride, int OH, int OW, int Cs_in, int Ks_out) {
-  return g_fast_enabled && g_halo_enabled && R == 3 && S == 3 && stride == 1 && OH % 4 == 0 && OW % 64 == 0 &&
-         Cs_in % 64 == 0 && Ks_out > 32;
-}
-
-// Convs with K*R*S <= 32 outputs-times-taps (the 512 -> 1 PatchGAN map): y[p][k] = sum_taps Z[p + tap][k, tap] with
-// Z[q][(k, tap)] = sum_c x[q][c] * w[k][tap][c] -- a 1x1 GEMM over the INPUT pixels (K*R*S <= 32 columns: one MFMA
-// tile, every input pixel read once, no padded copy) followed by this gather-sum over the taps.  The direct
-// form wastes 31 of 32 MFMA columns and re-reads the input once per tap.
-__global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ Z, const float* __restrict__ bias,
-                                                    bf16_t* __restrict__ y, int N, int H, int W, int OH, int OW,
-                                                    int K, int Ks_out, int R, int S, int pad, int reflect, int zs,
-                                                    int act, float slope, long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over output pixels x Ks_out
-  if (idx >= total) return;
-  const int k = (int)(idx % Ks_out);
-  long long t = idx / Ks_out;
-  const int ow = (int)(t % OW);
-  t /= OW;
-  const int oh = (int)(t % OH), n = (int)(t / OH);
-  float v = 0.f;
-  if (k < K) {
-    v = bias != nullptr ? bias[k] : 0.f;
-    for (int r = 0; r < R; ++r) {
-      int ih = oh + r - pad;
-      if (reflect) ih = ih < 0 ? -ih : (ih >= H ? 2 * (H - 1) - ih : ih);
-      else if ((unsigned)ih >= (unsigned)H) continue;
-      for (int s2 = 0; s2 < S; ++s2) {
-        int iw = ow + s2 - pad;
-        if (reflect) iw = iw < 0 ? -iw : (iw >= W ? 2 * (W - 1) - iw : iw);
-        else if ((unsigned)iw >= (unsigned)W) continue;
-        v += Z[(((long long)n * H + ih) * W + iw) * zs + (k * R + r) * S + s2];
-      }
-    }
-    v = apply_act(v, act, slope);
-  }
-  y[idx] = f2bf(v);
-}
-
-JPDSE_SWITCH(int, g_thin_fwd_enabled, 1);
-// geometry of the thin forward kernel for a layer: TH output rows per block (8, or 4 for stride 2 / when LDS is short)
-struct ThinFwdGeom { int TH, TW, strip_units, w_units, lds; };
-static bool thin_fwd_geom(const jpdse_conv_desc* d, const ConvPlan& p, ThinFwdGeom* g) {
-  if (!(g_fast_enabled && g_thin_fwd_enabled && p.thinf)) return false;
-  const int st = d->stride;
-  g->w_units = (p.Ks * p.KP_thin * 2 + 1023) / 1024;
-  static const int cand[3][2] = {{8, 64}, {4, 64}, {4, 32}};
-  // 8-channel inputs (VGG conv1_1) are output-write bound: the smaller block keeps the epilogue tile at 48 KiB so that
-  // three blocks share a CU
-  for (int c = (p.Cs <= 8 && p.Ks == 64) ? 1 : 0; c < 3; ++c) {
-    const int TH = cand[c][0], TW = cand[c][1];
-    if (TH == 4 && p.Ks != 64) break;                 // 4 rows x 2 column groups needs K = 64 (32 per group)
-    g->strip_units = (((TW - 1) * st + d->S) * p.Cs * 2 + 16 + 1023) / 1024;
-    const int lds = (((TH - 1) * st + d->R) * g->strip_units + 2 * g->w_units) * 1024;
-    const int epi = TH * TW * (p.Ks * 2 + 64);
-    g->TH = TH;
-    g->TW = TW;
-    g->lds = lds > epi ? lds : epi;
-    if (g->lds <= 160 * 1024) return true;
-  }
-  return false;
-}
-
-template <int TN, int TH, int ST, int TW>
-static int launch_thin_fwd(const ThinFwdArgs& a, int lds, hipStream_t s) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<TN, TH, ST, TW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "thin_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
-  hipLaunchKernelGGL((thin_fwd_kernel<TN, TH, ST, TW>), dim3(a.N * a.tiles_h * a.tiles_w), dim3(512), lds, s, a);
-  return check_launch("thin_fwd_kernel");
-}
-
-JPDSE_SWITCH(int, g_head_fwd_enabled, 1);
-static bool head_fwd_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
-  const int ncols = d->K * d->R * d->S;
-  return g_fast_enabled && g_head_fwd_enabled && p.ES == 2 && d->stride == 1 && d->K <= 3 && p.Ks == 8 &&
-         (p.Cs == 64 || p.Cs == 32) && d->R == 7 && d->S == 7 && ncols <= 160 && p.Lk_fwd == d->S * p.Cs;
-}
-
-template <int CIN, int NT = 5, int FR = 7, int FS = 7>
-static int launch_head_fwd(const HeadFwdArgs& a, hipStream_t s) {
-  constexpr int lds = NT * 32 * CIN * 2 + 3 * kHeadMR * CIN * 2 + NT * 32 * kHeadZP * 4 + kHeadTH * 64 * 4 * 4;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fwd_kernel<CIN, NT, FR, FS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "head_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
-  hipLaunchKernelGGL((head_fwd_kernel<CIN, NT, FR, FS>), dim3(a.N * a.tiles_h * a.tiles_w), dim3(64 * NT), lds, s, a);
-  return check_launch("head_fwd_kernel");
-}
-
-JPDSE_SWITCH(int, g_tapsum_enabled, 1);
-static bool tapsum_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
-  return g_fast_enabled && g_tapsum_enabled && p.ES == 2 && d->stride == 1 && d->K * d->R * d->S <= 32 &&
-         p.Cs % 64 == 0 && p.Cs >= 256 && p.Lk_fwd == d->S * p.Cs;
-}
-
-
-// ---- forward moments for the InstanceNorm that follows a conv (jpdse_conv_fwd_moments): which layers write them, and how many
-// slots per image.  These mirror the dispatch order of conv_fwd_t / conv_dgrad_t.
-static bool thin_rows_takes(const jpdse_conv_desc* d, const ConvPlan& p) {
-  return g_rows_enabled && d->stride == 2 && d->R == 4 && d->S == 4 && p.Cs == 40 && p.Ks == 64 && d->K == 64 &&
-         d->pad_mode != JPDSE_PAD_REFLECT && p.KP_thin == 168;
-}
-static bool thin_in_rows_takes(const jpdse_conv_desc* d, const ConvPlan& p) {
-  return g_fast_enabled && g_rows_enabled && p.Cs == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
-         d->pad_mode == JPDSE_PAD_ZERO && p.Ks == 64 && d->K == 64 && p.Lk_fwd == 32;
-}
-JPDSE_SWITCH(int, g_moments_fused, 1);     // 32 (and 6: the rounding-point-preserving comparison mode): no moment epilogues
-static int conv_fwd_moment_slots(const jpdse_conv_desc* d, const ConvPlan& p) {
-  if (!g_moments_fused || d->dtype != JPDSE_BF16 || d->act != JPDSE_ACT_NONE) return 0;
-  if (thin_in_rows_takes(d, p)) return 0;
-  ThinFwdGeom tg;
-  if (thin_fwd_geom(d, p, &tg)) {
-    if (thin_rows_takes(d, p)) return 0;
-    return (p.OH % tg.TH == 0 && p.OW % tg.TW == 0) ? (p.OH / tg.TH) * (p.OW / tg.TW) : 0;
-  }
-  if (head_fwd_ok(d, p) || tapsum_ok(d, p)) return 0;
-  if (rows_ok(d->R, d->S, d->stride, d->pad_mode == JPDSE_PAD_REFLECT, d->act, p.OH, p.OW, p.Cs, p.Ks)) {
-    const int WC = p.Ks % 128 == 0 ? 4 : 2, strips = p.OW / 64, n_tiles = p.Ks / (32 * WC);
-    const int th = rows_band_height(d->N, p.OH, strips, n_tiles, 256LL * ((d->stride == 1 && WC == 2) ? 2 : 1));
-    return (p.OH / th) * strips * (4 / WC);
-  }
-  if (d->pad_mode != JPDSE_PAD_REFLECT && p.Lk_fwd == d->S * p.Cs &&
-      taps4_shape_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks, (long long)d->N * d->H * d->W * p.Cs, (long long)p.Ks * 16 * p.Cs))
-    return 0;
-  // halo kernel (double-buffered form: inputs of 128+ channels): one slot per 4 x 64 output patch
-  if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks) && p.Cs > 64 && g_halo_abl == 0) return (p.OH / 4) * (p.OW / 64);
-  return 0;
-}
-static bool dgrad2_rows_takes(const jpdse_conv_desc* d, const ConvPlan& p) {
-  return d->dtype == JPDSE_BF16 && g_fast_enabled && g_rows_enabled && d->pad_mode != JPDSE_PAD_REFLECT && d->stride == 2 && d->R == 3 &&
-         d->S == 3 && d->pad == 1 && p.Ks == 128 && p.Cs == 64 && d->C == 64 && d->H == 2 * p.OH && d->W == 2 * p.OW &&
-         p.OW % 64 == 0 && p.OH % 4 == 0 && p.nph == 4;
-}
-static int convT_fwd_moment_slots(const jpdse_conv_desc* d, const ConvPlan& p) {
-  if (!g_moments_fused || !dgrad2_rows_takes(d, p)) return 0;
-  const int strips = p.OW / 64;
-  return (p.OH / rows_band_height(d->N, p.OH, strips, 1, 256)) * strips;
-}
-
-template <typename T>
-static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
-                      const float* bias, void* y, void* ws, hipStream_t s, float* mom = nullptr) {
-  // mom != nullptr: the caller asked jpdse_conv_moment_slots first, so the branch taken below is one that writes them
-  if constexpr (sizeof(T) == 2) {
-    if (g_fast_enabled && g_rows_enabled && p.Cs == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
-        d->pad_mode == JPDSE_PAD_ZERO && p.Ks == 64 && d->K == 64 && p.Lk_fwd == 32 &&
-        (d->act == JPDSE_ACT_NONE || d->act == JPDSE_ACT_RELU || d->act == JPDSE_ACT_LRELU)) {
-      ThinInArgs g = {};                       // VGG conv1_1: plain forward panel [k][r][(s, c8) 24 -> 32]
-      g.DY = reinterpret_cast<const bf16_t*>(x);
-      g.P = reinterpret_cast<const bf16_t*>(pack);
-      g.DX = reinterpret_cast<bf16_t*>(y);
-      g.bias = bias;
-      g.act = d->act;
-      g.slope = d->slope;
-      g.N = d->N;
-      g.H = d->H;
-      g.W = d->W;
-      g.OH = p.OH;
-      g.OW = p.OW;
-      g.py = g.px = 1;
-      return launch_thin_in_rows<3, false>(g, s);
-    }
-    ThinFwdGeom tg;
-    if (thin_fwd_geom(d, p, &tg)) {
-      ThinFwdArgs t = {};
-      t.X = reinterpret_cast<const bf16_t*>(x);
-      t.Wt = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + p.thin_pack_off);
-      t.bias = bias;
-      t.Y = reinterpret_cast<bf16_t*>(y);
-      t.N = d->N;
-      t.H = d->H;
-      t.W = d->W;
-      t.OH = p.OH;
-      t.OW = p.OW;
-      t.Cs = p.Cs;
-      t.K = d->K;
-      t.Ks = p.Ks;
-      t.R = d->R;
-      t.S = d->S;
-      t.pad = d->pad;
-      t.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
-      t.act = d->act;
-      t.slope = d->slope;
-      t.KP = p.KP_thin;
-      t.ksteps = (p.KP_thin - 8) / 16;
-      t.strip_units = tg.strip_units;
-      t.w_units = tg.w_units;
-      t.tiles_w = (p.OW + tg.TW - 1) / tg.TW;
-      t.tiles_h = (p.OH + tg.TH - 1) / tg.TH;
-      if (mom != nullptr && !thin_rows_takes(d, p)) {
-        t.mom = mom;
-        t.mom_slots = t.tiles_w * t.tiles_h;
-      }
-      if (g_rows_enabled && d->stride == 2 && d->R == 4 && d->S == 4 && p.Cs == 40 && p.Ks == 64 && d->K == 64 && !t.reflect &&
-          p.KP_thin == 168 && (d->act == JPDSE_ACT_NONE || d->act == JPDSE_ACT_RELU || d->act == JPDSE_ACT_LRELU))
-        return launch_thin_rows(t, s);
-      if (d->stride == 1) {
-        if (tg.TH == 8) return p.Ks == 64 ? launch_thin_fwd<2, 8, 1, 64>(t, tg.lds, s) : launch_thin_fwd<1, 8, 1, 64>(t, tg.lds, s);
-        return tg.TW == 64 ? launch_thin_fwd<1, 4, 1, 64>(t, tg.lds, s) : launch_thin_fwd<1, 4, 1, 32>(t, tg.lds, s);
-      }
-      if (tg.TH == 8) return p.Ks == 64 ? launch_thin_fwd<2, 8, 2, 64>(t, tg.lds, s) : launch_thin_fwd<1, 8, 2, 64>(t, tg.lds, s);
-      return tg.TW == 64 ? launch_thin_fwd<1, 4, 2, 64>(t, tg.lds, s) : launch_thin_fwd<1, 4, 2, 32>(t, tg.lds, s);
-    }
-    if (head_fwd_ok(d, p)) {
-      HeadFwdArgs h = {};
-      h.X = reinterpret_cast<const bf16_t*>(x);
-      h.Wp = reinterpret_cast<const bf16_t*>(pack);
-      h.bias = bias;
-      h.Y = reinterpret_cast<bf16_t*>(y);
-      h.N = d->N;
-      h.H = d->H;
-      h.W = d->W;
-      h.OH = p.OH;
-      h.OW = p.OW;
-      h.K = d->K;
-      h.Ks_out = p.Ks;
-      h.R = d->R;
-      h.S = d->S;
-      h.pad = d->pad;
-      h.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
-      h.act = d->act;
-      h.slope = d->slope;
-      h.tiles_w = (p.OW + 63) / 64;
-      h.tiles_h = (p.OH + kHeadTH - 1) / kHeadTH;
-      if (head_rows_ok(h, p.Cs)) return launch_head_rows<7>(h, s);
-      return p.Cs == 64 ? launch_head_fwd<64>(h, s) : launch_head_fwd<32>(h, s);
-    }
-    if (tapsum_ok(d, p)) {
-      const int cols = d->K * d->R * d->S, zs = (cols + 7) / 8 * 8;
-      FastArgs f = {};
-      f.X = reinterpret_cast<const bf16_t*>(x);
-      f.B = reinterpret_cast<const bf16_t*>(pack);     // row k of the plain panel = [R*S][Cs]: K*R*S rows of Cs
-      f.M = d->N * d->H * d->W;
-      f.OH = d->H;
-      f.OW = d->W;
-      f.IH = d->H;
-      f.IW = d->W;
-      f.Cs = p.Cs;
-      f.R = f.S = 1;
-      f.sy = f.sx = 1;
-      f.Kout = cols;
-      f.Ks = zs;
-      f.b_rows = cols;
-      f.act = JPDSE_ACT_NONE;
-      f.splits = 1;
-      f.no_finish = 1;
-      f.partial = reinterpret_cast<float*>(ws);
-      if (int rc = launch_fast(f, s)) return rc;
-      const long long total = (long long)d->N * p.OH * p.OW * p.Ks;
-      hipLaunchKernelGGL(tapsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, f.partial, bias,
-                         reinterpret_cast<bf16_t*>(y), d->N, d->H, d->W, p.OH, p.OW, d->K, p.Ks, d->R, d->S, d->pad,
-                         d->pad_mode == JPDSE_PAD_REFLECT ? 1 : 0, zs, d->act, d->slope, total);
-      return check_launch("tapsum_kernel");
-    }
-    if (rows_ok(d->R, d->S, d->stride, d->pad_mode == JPDSE_PAD_REFLECT, d->act, p.OH, p.OW, p.Cs, p.Ks)) {
-      RowsArgs r = {};
-      r.X = reinterpret_cast<const bf16_t*>(x);
-      r.B = reinterpret_cast<const bf16_t*>(pack);
-      r.bias = bias;
-      r.Y = reinterpret_cast<bf16_t*>(y);
-      r.N = d->N;
-      r.OH = p.OH;
-      r.OW = p.OW;
-      r.IH = d->H;
-      r.IW = d->W;
-      r.py = r.px = d->pad;
-      r.Kout = d->K;
-      r.Ks = p.Ks;
-      r.b_rows = p.Ks;
-      r.out_sn = (long long)p.OH * p.OW * p.Ks;
-      r.out_sh = (long long)p.OW * p.Ks;
-      r.out_sw = p.Ks;
-      r.out_base = 0;
-      r.act = d->act;
-      r.slope = d->slope;
-      r.mom = mom;
-      return launch_rows(r, d->stride, s);
-    }
-    if (d->pad_mode != JPDSE_PAD_REFLECT && p.Lk_fwd == d->S * p.Cs && mom == nullptr &&
-        taps4_shape_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks, (long long)d->N * d->H * d->W * p.Cs, (long long)p.Ks * 16 * p.Cs)) {
-      Taps4View v = {};
-      v.X = reinterpret_cast<const bf16_t*>(x);
-      v.B = reinterpret_cast<const bf16_t*>(pack);
-      v.bias = bias;
-      v.Y = reinterpret_cast<bf16_t*>(y);
-      v.N = d->N;
-      v.IH = d->H;
-      v.IW = d->W;
-      v.Cin_s = p.Cs;
-      v.OH = p.OH;
-      v.OW = p.OW;
-      v.py = v.px = d->pad;
-      v.Kout = d->K;
-      v.Ks_out = p.Ks;
-      v.ktot = (long long)d->R * p.Lk_fwd;
-      v.tap_r = p.Lk_fwd;
-      v.tap_s = p.Cs;
-      v.act = d->act;
-      v.slope = d->slope;
-      return launch_taps4(v, ws, s);
-    }
-    if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks)) {
-      HaloArgs h = {};
-      h.X = reinterpret_cast<const bf16_t*>(x);
-      h.B = reinterpret_cast<const bf16_t*>(pack);
-      h.bias = bias;
-      h.Y = reinterpret_cast<bf16_t*>(y);
-      h.N = d->N;
-      h.OH = p.OH;
-      h.OW = p.OW;
-      h.IH = d->H;
-      h.IW = d->W;
-      h.Cs = p.Cs;
-      h.py = h.px = d->pad;
-      h.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
-      h.Kout = d->K;
-      h.Ks = p.Ks;
-      h.b_rows = p.Ks;
-      h.out_sn = (long long)p.OH * p.OW * p.Ks;
-      h.out_sh = (long long)p.OW * p.Ks;
-      h.out_sw = p.Ks;
-      h.out_base = 0;
-      h.act = d->act;
-      h.slope = d->slope;
-      if (mom != nullptr) {
-        h.mom = mom;
-        h.mom_slots = (p.OH / 4) * (p.OW / 64);
-      }
-#ifdef JPDSE_DEV
-      if (g_halo_abl && p.Ks > 64) {      // timing-only ablations (scripts/bench_conv.py --fast 11..)
-        switch (g_halo_abl) {
-          case 1: return launch_halo_cfg<2, 1>(h, s);
-          case 2: return launch_halo_cfg<2, 2>(h, s);
-          case 4: return launch_halo_cfg<2, 4>(h, s);
-          case 9: return launch_halo_cfg<2, 9>(h, s);
-          case 11: return launch_halo_cfg<2, 11>(h, s);
-          case 15: return launch_halo_cfg<2, 15>(h, s);
-          case 16: return launch_halo_cfg<2, 16>(h, s);
-          case 32: return launch_halo_cfg<2, 32>(h, s);
-          case 48: return launch_halo_cfg<2, 48>(h, s);
-          default: break;
-        }
-      }
-#endif
-      return p.Ks > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
-    }
-    if (p.Cs % 64 == 0 && fast_pays(d->N * p.OH * p.OW, p.Ks, d->R * d->S * p.Cs / 64)) {
-      FastArgs f = {};
-      f.X = reinterpret_cast<const bf16_t*>(x);
-      f.B = reinterpret_cast<const bf16_t*>(pack);
-      f.bias = bias;
-      f.Y = reinterpret_cast<bf16_t*>(y);
-      f.M = d->N * p.OH * p.OW;
-      f.OH = p.OH;
-      f.OW = p.OW;
-      f.IH = d->H;
-      f.IW = d->W;
-      f.Cs = p.Cs;
-      f.R = d->R;
-      f.S = d->S;
-      f.sy = f.sx = d->stride;
-      f.py = f.px = d->pad;
-      f.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
-      f.Kout = d->K;
-      f.Ks = p.Ks;
-      f.b_rows = p.Ks;
-      f.out_sn = (long long)p.OH * p.OW * p.Ks;
-      f.out_sh = (long long)p.OW * p.Ks;
-      f.out_sw = p.Ks;
-      f.out_base = 0;
-      f.act = d->act;
-      f.slope = d->slope;
-      f.splits = splitk_for(f.M, p.Ks, d->R * d->S * p.Cs / 64);
-      f.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + p.splitk_off);
-      return launch_fast(f, s);
-    }
-  }
-  // generic path: staged through the workspace, the GEMM loaders rely on the zeroed slack behind it
-  if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-    return rc;
-  const void* xin = ws;
-  if (p.toep && g_fast_enabled && g_toep_enabled && p.OW % 4 == 0) {
-    // head: 4 output pixels x 8 channels per 32-wide GEMM row (see pack_fwd_toep_kernel); the [M/4][32]
-    // result IS the NHWC output
-    GemmFwdArgs a = {};
-    a.A = xin;
-    a.B = reinterpret_cast<const char*>(pack) + p.fwd_pack_plain_bytes;
-    a.bias = bias;
-    a.Y = y;
-    a.M = d->N * p.OH * (p.OW / 4);
-    a.OH = p.OH;
-    a.OW = p.OW / 4;
-    a.Kout = 32;
-    a.Ks = 32;
-    a.R = d->R;
-    a.cpr = p.Lk_toep / p.BKE;
-    a.b_rows = 32;
-    a.b_row_stride = (long long)d->R * p.Lk_toep;
-    a.in_sn = (long long)p.Hp * p.Wp * p.Cs;
-    a.in_sh = (long long)p.Wp * p.Cs;
-    a.in_sw = 4LL * p.Cs;
-    a.in_sr = (long long)p.Wp * p.Cs;
-    a.in_base = 0;
-    a.out_sn = (long long)p.OH * p.OW * p.Ks;
-    a.out_sh = (long long)p.OW * p.Ks;
-    a.out_sw = 4LL * p.Ks;
-    a.out_base = 0;
-    a.act = d->act;
-    a.slope = d->slope;
-    a.col_mod = 8;
-    a.k_real = d->K;
-    return launch_fwd<T>(a, s);
-  }
-  GemmFwdArgs a = {};
-  a.A = xin;
-  a.B = pack;
-  a.bias = bias;
-  a.Y = y;
-  a.M = d->N * p.OH * p.OW;
-  a.OH = p.OH;
-  a.OW = p.OW;
-  a.Kout = d->K;
-  a.Ks = p.Ks;
-  a.R = d->R;
-  a.cpr = p.Lk_fwd / p.BKE;
-  a.b_rows = p.Ks;
-  a.b_row_stride = (long long)d->R * p.Lk_fwd;
-  a.in_sn = (long long)p.Hp * p.Wp * p.Cs;
-  a.in_sh = (long long)d->stride * p.Wp * p.Cs;
-  a.in_sw = (long long)d->stride * p.Cs;
-  a.in_sr = (long long)p.Wp * p.Cs;
-  a.in_base = 0;
-  a.out_sn = (long long)p.OH * p.OW * p.Ks;
-  a.out_sh = (long long)p.OW * p.Ks;
-  a.out_sw = p.Ks;
-  a.out_base = 0;
-  a.act = d->act;
-  a.slope = d->slope;
-  return launch_fwd<T>(a, s);
-}
-
-// Reflect-padded 3x3 stride-1 data gradient = zero-padded data gradient (halo kernel, written to dx)
-// + the ring of the padded domain folded back: padded row -1 -> image row 1, row H -> H-2, column -1 -> 1,
-// column W -> W-2.  The four ring strips are small split-K GEMMs (fp32 slabs, FastArgs::no_finish); this
-// kernel sums their slabs and adds them into dx.  One thread = 8 channels of one target pixel; targets are
-// enumerated without duplicates: rows {1, H-2} completely, columns {1, W-2} without those two rows.
-struct RingFoldArgs {
-  bf16_t* dx;
-  const float* top; const float* bot; const float* left; const float* right;   // slabs [splits][M_q][Cs]
-  int splits_tb, splits_lr;
-  int N, H, W, Cs;
-};
-__device__ __forceinline__ void ring_acc(float (&acc)[8], const float* slab, int splits, long long slab_elems,
-                                         long long row, int Cs, int c0) {
-  // slabs are read four at a time before they are added (same order): one L2 round trip per split otherwise
-  const float* base = slab + row * Cs + c0;
-  int sp = 0;
-  for (; sp + 4 <= splits; sp += 4) {
-    float4 lo[4], hi[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float4* src = reinterpret_cast<const float4*>(base + (sp + u) * slab_elems);
-      lo[u] = src[0];
-      hi[u] = src[1];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc[0] += lo[u].x; acc[1] += lo[u].y; acc[2] += lo[u].z; acc[3] += lo[u].w;
-      acc[4] += hi[u].x; acc[5] += hi[u].y; acc[6] += hi[u].z; acc[7] += hi[u].w;
-    }
-  }
-  for (; sp < splits; ++sp) {
-    const float4* src = reinterpret_cast<const float4*>(base + sp * slab_elems);
-    const float4 lo = src[0], hi = src[1];
-    acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w;
-    acc[4] += hi.x; acc[5] += hi.y; acc[6] += hi.z; acc[7] += hi.w;
-  }
-}
-__global__ __launch_bounds__(256) void ring_fold_kernel(const RingFoldArgs a, long long total_vec) {
-  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (v >= total_vec) return;
-  const int cv = a.Cs >> 3;
-  const int c0 = (int)(v % cv) * 8;
-  long long t = v / cv;
-  const int per_n = 2 * a.W + 2 * (a.H - 2);
-  const int n = (int)(t / per_n);
-  int e = (int)(t - (long long)n * per_n);
-  const long long Mtb = (long long)a.N * (a.W + 2), Mlr = (long long)a.N * a.H;
-  float acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  int i_row, j_col;
-  if (e < 2 * a.W) {                      // row targets
-    const bool is_top = e < a.W;
-    const int j = is_top ? e : e - a.W;
-    i_row = is_top ? 1 : a.H - 2;
-    j_col = j;
-    const float* slab = is_top ? a.top : a.bot;
-    const long long rb = (long long)n * (a.W + 2);
-    ring_acc(acc, slab, a.splits_tb, Mtb * a.Cs, rb + j + 1, a.Cs, c0);
-    if (j == 1) ring_acc(acc, slab, a.splits_tb, Mtb * a.Cs, rb, a.Cs, c0);                  // corner b = 0
-    if (j == a.W - 2) ring_acc(acc, slab, a.splits_tb, Mtb * a.Cs, rb + a.W + 1, a.Cs, c0);  // corner b = W+1
-    if (j == 1) ring_acc(acc, a.left, a.splits_lr, Mlr * a.Cs, (long long)n * a.H + i_row, a.Cs, c0);
-    if (j == a.W - 2) ring_acc(acc, a.right, a.splits_lr, Mlr * a.Cs, (long long)n * a.H + i_row, a.Cs, c0);
-  } else {                                // column targets, rows other than 1 and H-2
-    e -= 2 * a.W;
-    const bool is_left = e < a.H - 2;
-    int i = is_left ? e : e - (a.H - 2);  // index into the H-2 remaining rows
-    i = i == 0 ? 0 : i + 1;               // rows 0, 2, 3, ..., H-3, H-1
-    if (i >= a.H - 2) i += 1;
-    i_row = i;
-    j_col = is_left ? 1 : a.W - 2;
-    ring_acc(acc, is_left ? a.left : a.right, a.splits_lr, Mlr * a.Cs, (long long)n * a.H + i, a.Cs, c0);
-  }
-  bf16_t* dst = a.dx + (((long long)n * a.H + i_row) * a.W + j_col) * a.Cs + c0;
-  float cur[8];
-  Vec16<bf16_t>::load(dst, cur);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) cur[q] += acc[q];
-  Vec16<bf16_t>::store(dst, cur);
-}
-
-// dx = (dx + addend) * (mask > 0), 16-byte vectors: the unfused form of the data-gradient epilogue extras
-// (either pointer may be null)
-template <typename T>
-__global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask, long long total_vec,
-                                 const T* __restrict__ addend = nullptr) {
-  constexpr int VE = Vec16<T>::N;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total_vec;
-       i += (long long)gridDim.x * blockDim.x) {
-    float v[VE], m[VE];
-    Vec16<T>::load(dx + i * VE, v);
-    if (addend != nullptr) {
-      Vec16<T>::load(addend + i * VE, m);
-#pragma unroll
-      for (int e = 0; e < VE; ++e) v[e] += m[e];
-    }
-    if (mask != nullptr) {
-      Vec16<T>::load(mask + i * VE, m);
-#pragma unroll
-      for (int e = 0; e < VE; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
-    }
-    Vec16<T>::store(dx + i * VE, v);
-  }
-}
-
-template <typename T>
-static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx,
-                        void* ws, hipStream_t s, const void* mask = nullptr, const void* addend = nullptr, float* mom = nullptr) {
-  char* wsb = reinterpret_cast<char*>(ws);
-  void* dyp = wsb;
-  void* dxp = wsb + p.dypad_bytes;
-  const bool refl = d->pad_mode == JPDSE_PAD_REFLECT;
-  const int st = d->stride;
-  if constexpr (sizeof(T) == 2) {
-    if (!refl && p.nph == 1 && st == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W &&
-        rows_ok(p.ph[0].Uh, p.ph[0].Uw, 1, 0, JPDSE_ACT_NONE, d->H, d->W, p.Ks, p.Cs) && p.ph[0].Lk == 3 * p.Ks) {
-      const Phase& f = p.ph[0];
-      RowsArgs r = {};
-      r.X = reinterpret_cast<const bf16_t*>(dy);
-      r.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
-      r.Y = reinterpret_cast<bf16_t*>(dx);
-      r.N = d->N;
-      r.OH = d->H;
-      r.OW = d->W;
-      r.IH = p.OH;
-      r.IW = p.OW;
-      r.py = (f.Uh - 1) - f.i0h;
-      r.px = (f.Uw - 1) - f.i0w;
-      r.Kout = d->C;
-      r.Ks = p.Cs;
-      r.b_rows = p.Cs;
-      r.out_sn = (long long)d->H * d->W * p.Cs;
-      r.out_sh = (long long)d->W * p.Cs;
-      r.out_sw = p.Cs;
-      r.out_base = 0;
-      r.act = JPDSE_ACT_NONE;
-      r.mask = reinterpret_cast<const bf16_t*>(mask);
-      r.addend = reinterpret_cast<const bf16_t*>(addend);
-      return launch_rows(r, 1, s);
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    if (!refl && p.nph == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W &&
-        halo_ok(p.ph[0].Uh, p.ph[0].Uw, st, d->H, d->W, p.Ks, p.Cs)) {
-      const Phase& f = p.ph[0];
-      HaloArgs h = {};
-      h.X = reinterpret_cast<const bf16_t*>(dy);
-      h.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
-      h.bias = nullptr;
-      h.Y = reinterpret_cast<bf16_t*>(dx);
-      h.N = d->N;
-      h.OH = d->H;
-      h.OW = d->W;
-      h.IH = p.OH;
-      h.IW = p.OW;
-      h.Cs = p.Ks;
-      h.py = (f.Uh - 1) - f.i0h;
-      h.px = (f.Uw - 1) - f.i0w;
-      h.reflect = 0;
-      h.Kout = d->C;
-      h.Ks = p.Cs;
-      h.b_rows = p.Cs;
-      h.out_sn = (long long)d->H * d->W * p.Cs;
-      h.out_sh = (long long)d->W * p.Cs;
-      h.out_sw = p.Cs;
-      h.out_base = 0;
-      h.act = JPDSE_ACT_NONE;
-      h.mask = reinterpret_cast<const bf16_t*>(mask);
-      h.addend = reinterpret_cast<const bf16_t*>(addend);
-      return p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    if (refl && g_ring_enabled && d->R == 3 && d->S == 3 && st == 1 && d->pad == 1 && d->H >= 8 &&
-        halo_ok(3, 3, 1, d->H, d->W, p.Ks, p.Cs) && p.ph[0].Lk == 3 * p.Ks) {
-      // (1) zero-padded data gradient straight into dx
-      HaloArgs h = {};
-      h.X = reinterpret_cast<const bf16_t*>(dy);
-      h.B = reinterpret_cast<const bf16_t*>(pack);
-      h.Y = reinterpret_cast<bf16_t*>(dx);
-      h.N = d->N;
-      h.OH = d->H;
-      h.OW = d->W;
-      h.IH = d->H;
-      h.IW = d->W;
-      h.Cs = p.Ks;
-      h.py = h.px = 1;
-      h.Kout = d->C;
-      h.Ks = p.Cs;
-      h.b_rows = p.Cs;
-      h.out_sn = (long long)d->H * d->W * p.Cs;
-      h.out_sh = (long long)d->W * p.Cs;
-      h.out_sw = p.Cs;
-      h.act = JPDSE_ACT_NONE;
-      h.addend = reinterpret_cast<const bf16_t*>(addend);
-      if (int rc = p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s)) return rc;
-      // (2) the four ring strips of the reflect-padded domain as split-K GEMMs into fp32 slabs
-      const int H = d->H, W = d->W, Ks = p.Ks, Lk = p.ph[0].Lk;
-      const bf16_t* dyb = reinterpret_cast<const bf16_t*>(dy);
-      const bf16_t* pk = reinterpret_cast<const bf16_t*>(pack);
-      const int Mtb = d->N * (W + 2), Mlr = d->N * H;
-      const int nt = (p.Cs + 127) / 128;
-      // the strips have few rows (N (W + 2) and N H); developer mode 31 tries 128-row tiles (two blocks per CU): slower
-      const int bm = g_ring_small ? 128 : 256;
-      const int tiles = 2 * ((Mtb + bm - 1) / bm) * nt + 2 * ((Mlr + bm - 1) / bm) * nt;
-      const int kt = 3 * Ks / 64;
-      int sp = (g_ring_small ? 512 : 256) / tiles;
-      if (sp > kt / 8) sp = kt / 8;
-      if (sp > 8) sp = 8;
-      if (sp < 1) sp = 1;
-      float* slab = reinterpret_cast<float*>(wsb);
-      const size_t tb_elems = (size_t)sp * Mtb * p.Cs, lr_elems = (size_t)sp * Mlr * p.Cs;
-      FastBatch rb = {};
-      rb.small_m = g_ring_small;
-      for (int q = 0; q < 4; ++q) {
-        FastArgs g = {};
-        const bool row_strip = q < 2;         // 0 top, 1 bottom, 2 left, 3 right
-        g.X = dyb + (q == 1 ? (long long)(H - 1) * W * Ks : (q == 3 ? (long long)(W - 1) * Ks : 0));
-        g.x_sn = (long long)H * W * Ks;
-        g.x_sh = (long long)W * Ks;
-        g.x_extent = (long long)d->N * H * W * Ks - (g.X - dyb);
-        g.IH = row_strip ? 1 : H;
-        g.IW = row_strip ? W : 1;
-        g.Cs = Ks;
-        g.R = row_strip ? 1 : 3;
-        g.S = row_strip ? 3 : 1;
-        g.sy = g.sx = 1;
-        g.py = row_strip ? 0 : 1;
-        g.px = row_strip ? 2 : 0;
-        g.OH = row_strip ? 1 : H;
-        g.OW = row_strip ? W + 2 : 1;
-        g.M = row_strip ? Mtb : Mlr;
-        // panel [c][u'][w'][k] with u' = 2 - r, w' = 2 - s: top r=0 -> u'=2, bottom u'=0, left s=0 -> w'=2, right w'=0
-        g.B = pk + (q == 0 ? 2LL * Lk : (q == 2 ? 2LL * Ks : 0));
-        g.b_stride = 3LL * Lk;
-        g.b_tap_r = Lk;
-        g.b_tap_s = Ks;
-        g.Kout = d->C;
-        g.Ks = p.Cs;
-        g.b_rows = p.Cs;
-        g.act = JPDSE_ACT_NONE;
-        g.splits = sp;
-        g.no_finish = 1;
-        g.partial = slab + (q == 0 ? 0 : (q == 1 ? tb_elems : (q == 2 ? 2 * tb_elems : 2 * tb_elems + lr_elems)));
-        rb.p[rb.n++] = g;
-      }
-      const int pslot = (p.Cs == g_prof.Ks && 9LL * p.Ks == g_prof.kdim) ? prof_begin(s) : -1;
-      if (int rc = launch_fast_batch(rb, s)) return rc;
-      // (3) fold the ring into rows 1 / H-2 and columns 1 / W-2 of dx
-      RingFoldArgs rf = {};
-      rf.dx = reinterpret_cast<bf16_t*>(dx);
-      rf.top = rb.p[0].partial;
-      rf.bot = rb.p[1].partial;
-      rf.left = rb.p[2].partial;
-      rf.right = rb.p[3].partial;
-      rf.splits_tb = rf.splits_lr = sp;
-      rf.N = d->N;
-      rf.H = H;
-      rf.W = W;
-      rf.Cs = p.Cs;
-      const long long tv = (long long)d->N * (2 * W + 2 * (H - 2)) * (p.Cs / 8);
-      hipLaunchKernelGGL(ring_fold_kernel, dim3(ew_blocks(tv)), dim3(256), 0, s, rf, tv);
-      int rc = check_launch("ring_fold_kernel");
-      if (rc == JPDSE_OK && mask != nullptr) {
-        const long long total_vec = (long long)d->N * H * W * (p.Cs / 8);
-        hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, reinterpret_cast<T*>(dx),
-                           reinterpret_cast<const T*>(mask), total_vec);
-        rc = check_launch("relu_mask_kernel");
-      }
-      prof_end(pslot, 1, 0.0, s);
-      return rc;
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    // few INPUT channels (VGG conv1_1: 3 <- 64): the data gradient is itself a conv with <= 3 output channels; the
-    // single-phase dgrad panel [c][u'][w'][k] is exactly the "plain forward panel" head_fwd_kernel expects
-    if (g_fast_enabled && g_head_fwd_enabled && !refl && st == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && d->C <= 3 &&
-        p.Cs == 8 && p.Ks == 64 && p.nph == 1 && p.ph[0].Lk == 3 * p.Ks && mask == nullptr && addend == nullptr) {
-      HeadFwdArgs h = {};
-      h.X = reinterpret_cast<const bf16_t*>(dy);
-      h.Wp = reinterpret_cast<const bf16_t*>(pack);
-      h.Y = reinterpret_cast<bf16_t*>(dx);
-      h.N = d->N;
-      h.H = p.OH;
-      h.W = p.OW;
-      h.OH = d->H;
-      h.OW = d->W;
-      h.K = d->C;
-      h.Ks_out = p.Cs;
-      h.R = 3;
-      h.S = 3;
-      h.pad = 1;
-      h.act = JPDSE_ACT_NONE;
-      h.tiles_w = (d->W + 63) / 64;
-      h.tiles_h = (d->H + kHeadTH - 1) / kHeadTH;
-      if (head_rows_ok(h, 64)) return launch_head_rows<3>(h, s);
-      return launch_head_fwd<64, 3, 3, 3>(h, s);
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    if (g_fast_enabled && g_rows_enabled && !refl && st == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && p.Ks == 128 && p.Cs == 64 &&
-        d->C == 64 && d->H == 2 * p.OH && d->W == 2 * p.OW && p.OW % 64 == 0 && p.OH % 4 == 0 && p.nph == 4 &&
-        mask == nullptr && addend == nullptr) {
-      Dgrad2Args g = {};
-      g.DY = reinterpret_cast<const bf16_t*>(dy);
-      for (int i = 0; i < 4; ++i) g.P[i] = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + p.ph[i].pack_off);
-      g.DX = reinterpret_cast<bf16_t*>(dx);
-      g.N = d->N;
-      g.OH = p.OH;
-      g.OW = p.OW;
-      g.mom = mom;
-      return launch_dgrad2_rows(g, s);
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    if (g_fast_enabled && g_rows_enabled && !refl && st == 2 && d->R == 4 && d->S == 4 && d->pad == 2 && p.Cs == 8 && d->C <= 3 &&
-        p.Ks == 64 && d->H % 8 == 0 && d->W % 256 == 0 && p.OH == d->H / 2 + 1 && p.OW == d->W / 2 + 1 && p.nph == 4 &&
-        p.ph[0].Lk == 128 && mask == nullptr && addend == nullptr) {
-      ThinDgrad2Args g = {};
-      g.DY = reinterpret_cast<const bf16_t*>(dy);
-      for (int i = 0; i < 4; ++i) g.P[i] = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + p.ph[i].pack_off);
-      g.DX = reinterpret_cast<bf16_t*>(dx);
-      g.N = d->N;
-      g.OH = p.OH;
-      g.OW = p.OW;
-      g.H = d->H;
-      g.W = d->W;
-      g.K = d->C;
-      return launch_thin_dgrad2_rows(g, s);
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    if (g_fast_enabled && g_rows_enabled && refl && st == 1 && d->R == 7 && d->S == 7 && d->pad == 3 && p.Ks == 8 && p.Cs == 64 &&
-        d->C == 64 && d->H >= 8 && d->W >= 8 && p.nph == 1 && p.ph[0].Lk == 64 && mask == nullptr && addend == nullptr) {
-      ThinInArgs g = {};
-      g.DY = reinterpret_cast<const bf16_t*>(dy);
-      g.P = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + p.ph[0].pack_off);
-      g.DX = reinterpret_cast<bf16_t*>(dx);
-      g.DXP = reinterpret_cast<bf16_t*>(dxp);
-      g.N = d->N;
-      g.H = d->H;
-      g.W = d->W;
-      g.OH = d->H + 6;
-      g.OW = d->W + 6;
-      g.py = g.px = 6;
-      g.act = JPDSE_ACT_NONE;
-      return launch_thin_in_rows<7, true>(g, s);
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    if (taps_dgrad2_ok(d, p, mask, addend, mom)) return launch_taps_dgrad2(d, p, dy, pack, dx, s, mask, addend);
-    if (!refl && p.nph == 1 && st == 1 && mom == nullptr && p.ph[0].cnth == d->H &&
-        p.ph[0].cntw == d->W && p.ph[0].Lk == p.ph[0].Uw * p.Ks &&
-        taps4_shape_ok(p.ph[0].Uh, p.ph[0].Uw, 1, d->H, d->W, p.Ks, p.Cs, (long long)d->N * p.OH * p.OW * p.Ks, (long long)p.Cs * 16 * p.Ks)) {
-      const Phase& f = p.ph[0];
-      Taps4View v = {};
-      v.X = reinterpret_cast<const bf16_t*>(dy);
-      v.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
-      v.Y = reinterpret_cast<bf16_t*>(dx);
-      v.N = d->N;
-      v.IH = p.OH;
-      v.IW = p.OW;
-      v.Cin_s = p.Ks;
-      v.OH = d->H;
-      v.OW = d->W;
-      v.py = (f.Uh - 1) - f.i0h;
-      v.px = (f.Uw - 1) - f.i0w;
-      v.Kout = d->C;
-      v.Ks_out = p.Cs;
-      v.ktot = (long long)f.Uh * f.Lk;
-      v.tap_r = f.Lk;
-      v.tap_s = p.Ks;
-      v.act = JPDSE_ACT_NONE;
-      v.addend = reinterpret_cast<const bf16_t*>(addend);
-      v.mask = reinterpret_cast<const bf16_t*>(mask);
-      return launch_taps4(v, ws, s);
-    }
-  }
-  bool fast = false;
-  int nlive_phases = 0;
-  if constexpr (sizeof(T) == 2) {
-    // all stride phases go into ONE launch of the fast kernel: judge the merged grid
-    fast = p.Ks % 64 == 0;
-    long long tiles = 0;
-    int kt_max = 0, nlive = 0, m_single = 0;
-    const int bn = p.Cs > 64 ? 128 : (p.Cs > 32 ? 64 : 32);
-    for (int i = 0; i < p.nph; ++i) {
-      if (p.ph[i].cnth <= 0 || p.ph[i].cntw <= 0) continue;
-      const int Mi = d->N * p.ph[i].cnth * p.ph[i].cntw;
-      tiles += (long long)((Mi + 255) / 256) * ((p.Cs + bn - 1) / bn);
-      const int kt = p.ph[i].Uh * p.ph[i].Uw * p.Ks / 64;
-      kt_max = kt > kt_max ? kt : kt_max;
-      m_single = Mi;
-      ++nlive;
-    }
-    nlive_phases = nlive;
-    if (nlive == 1) fast = fast && fast_pays(m_single, p.Cs, kt_max);
-    else fast = fast && g_fast_enabled && p.Cs > 32 && kt_max >= g_merge_min_kt && tiles >= g_merge_min_tiles;   // few tiles / short K loops: generic wins
-  }
-  FastBatch batch = {};
-  int rc = JPDSE_OK;
-  if (!fast) {
-    rc = launch_pad<T>(dy, dyp, d->N, p.OH, p.OW, p.Ks, p.PT, p.PB, p.PL, p.PR, JPDSE_PAD_ZERO, s);
-    if (rc) return rc;
-  }
-  for (int i = 0; i < p.nph; ++i) {
-    const Phase& f = p.ph[i];
-    if (f.cnth <= 0 || f.cntw <= 0) continue;
-    if constexpr (sizeof(T) == 2) {
-      if (fast) {
-        FastArgs g = {};
-        g.X = reinterpret_cast<const bf16_t*>(dy);
-        g.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
-        g.bias = nullptr;
-        g.M = d->N * f.cnth * f.cntw;
-        g.OH = f.cnth;
-        g.OW = f.cntw;
-        g.IH = p.OH;
-        g.IW = p.OW;
-        g.Cs = p.Ks;
-        g.R = f.Uh;
-        g.S = f.Uw;
-        g.sy = g.sx = 1;
-        g.py = (f.Uh - 1) - f.i0h;
-        g.px = (f.Uw - 1) - f.i0w;
-        g.reflect = 0;
-        g.Kout = d->C;
-        g.Ks = p.Cs;
-        g.b_rows = p.Cs;
-        if (refl) {
-          g.Y = reinterpret_cast<bf16_t*>(dxp);
-          g.out_sn = (long long)p.Hp * p.Wp * p.Cs;
-          g.out_sh = (long long)st * p.Wp * p.Cs;
-          g.out_sw = (long long)st * p.Cs;
-          g.out_base = ((long long)(st * f.i0h + f.qh) * p.Wp + (st * f.i0w + f.qw)) * p.Cs;
-        } else {
-          g.Y = reinterpret_cast<bf16_t*>(dx);
-          g.out_sn = (long long)d->H * d->W * p.Cs;
-          g.out_sh = (long long)st * d->W * p.Cs;
-          g.out_sw = (long long)st * p.Cs;
-          g.out_base = ((long long)(st * f.i0h + f.qh - d->pad) * d->W + (st * f.i0w + f.qw - d->pad)) * p.Cs;
-        }
-        g.act = JPDSE_ACT_NONE;
-        g.slope = 0.f;
-        g.mask = refl ? nullptr : reinterpret_cast<const bf16_t*>(mask);
-        g.addend = refl ? nullptr : reinterpret_cast<const bf16_t*>(addend);
-        g.splits = nlive_phases == 1 ? splitk_for(g.M, p.Cs, f.Uh * f.Uw * p.Ks / 64) : 1;
-        g.partial = reinterpret_cast<float*>(wsb + p.splitk_off);
-        batch.p[batch.n++] = g;
-        continue;
-      }
-    }
-    GemmFwdArgs a = {};
-    a.A = dyp;
-    a.B = reinterpret_cast<const char*>(pack) + f.pack_off;
-    a.bias = nullptr;
-    a.M = d->N * f.cnth * f.cntw;
-    a.OH = f.cnth;
-    a.OW = f.cntw;
-    a.Kout = d->C;
-    a.Ks = p.Cs;
-    a.R = f.Uh;
-    a.cpr = f.Lk / p.BKE;
-    a.b_rows = p.Cs;
-    a.b_row_stride = (long long)f.Uh * f.Lk;
-    a.in_sn = (long long)p.DH * p.DW * p.Ks;
-    a.in_sh = (long long)p.DW * p.Ks;
-    a.in_sw = p.Ks;
-    a.in_sr = (long long)p.DW * p.Ks;
-    a.in_base = ((long long)(f.i0h + p.PT - (f.Uh - 1)) * p.DW + (f.i0w + p.PL - (f.Uw - 1))) * p.Ks;
-    if (refl) {
-      a.Y = dxp;
-      a.out_sn = (long long)p.Hp * p.Wp * p.Cs;
-      a.out_sh = (long long)st * p.Wp * p.Cs;
-      a.out_sw = (long long)st * p.Cs;
-      a.out_base = ((long long)(st * f.i0h + f.qh) * p.Wp + (st * f.i0w + f.qw)) * p.Cs;
-    } else {
-      a.Y = dx;
-      a.out_sn = (long long)d->H * d->W * p.Cs;
-      a.out_sh = (long long)st * d->W * p.Cs;
-      a.out_sw = (long long)st * p.Cs;
-      a.out_base = ((long long)(st * f.i0h + f.qh - d->pad) * d->W + (st * f.i0w + f.qw - d->pad)) * p.Cs;
-    }
-    a.act = JPDSE_ACT_NONE;
-    a.slope = 0.f;
-    rc = launch_fwd<T>(a, s);
-    if (rc) return rc;
-  }
-  if (batch.n > 0) {
-    rc = launch_fast_batch(batch, s);
-    if (rc) return rc;
-  }
-  if (refl) {
-    const int VE = 16 / (int)sizeof(T);
-    const long long total_vec = (long long)d->N * d->H * d->W * (p.Cs / VE);
-    hipLaunchKernelGGL((reflect_fold_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s,
-                       reinterpret_cast<const T*>(dxp), reinterpret_cast<T*>(dx), d->N, d->H, d->W, p.Cs, d->pad,
-                       total_vec);
-    rc = check_launch("reflect_fold_kernel");
-  }
-  if (rc == JPDSE_OK && (mask != nullptr || addend != nullptr) && !(fast && !refl)) {
-    const int VE = 16 / (int)sizeof(T);
-    const long long total_vec = (long long)d->N * d->H * d->W * (p.Cs / VE);
-    hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, reinterpret_cast<T*>(dx),
-                       reinterpret_cast<const T*>(mask), total_vec, reinterpret_cast<const T*>(addend));
-    rc = check_launch("relu_mask_kernel");
-  }
-  return rc;
-}
-
-// (tile, split) partition of the fast weight-gradient kernel
-template <int BM, int BN>
-static void fast_wgrad_partition(FastWgArgs* a, int lds) {
-  const int blocks_per_cu = lds <= 80 * 1024 ? 2 : 1;
-  a->chunks_total = (a->M + 63) / 64;
-  const int tiles = ((a->Ks + BM - 1) / BM) * (a->run_mode ? a->R : a->R * a->S) *
-                    (((a->run_mode ? a->run_len : a->Cs) + BN - 1) / BN);
-  int splits = (256 * blocks_per_cu + tiles / 2) / tiles;      // fill the chip once
-  const int max_splits = a->chunks_total / 8 > 0 ? a->chunks_total / 8 : 1;      // >= 8 chunks per block
-  if (splits > max_splits) splits = max_splits;
-  if (splits > 64) splits = 64;
-  if (splits < 1) splits = 1;
-  a->chunks_per_split = (a->chunks_total + splits - 1) / splits;
-  a->splits = (a->chunks_total + a->chunks_per_split - 1) / a->chunks_per_split;
-  a->slab_stride = ((long long)a->K * a->R * a->S * a->C + 3) / 4 * 4;
-}
-
-template <int WM, int WN, int TM, int TN, int ABL = 0>
-static int launch_wgrad_fast_cfg(FastWgArgs a, float* slabs, size_t* slab_bytes_out, hipStream_t s) {
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int lds = 2 * 64 * 2 * (BM + BN);
-  fast_wgrad_partition<BM, BN>(&a, lds);
-  if (slab_bytes_out != nullptr) {        // workspace query only
-    *slab_bytes_out = a.splits > 1 ? (size_t)a.splits * a.slab_stride * sizeof(float) : 0;
-    return JPDSE_OK;
-  }
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<WM, WN, TM, TN, ABL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_fast: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
-  const int tiles = ((a.Ks + BM - 1) / BM) * (a.run_mode ? a.R : a.R * a.S) *
-                    (((a.run_mode ? a.run_len : a.Cs) + BN - 1) / BN);
-  a.partial = slabs;
-  hipLaunchKernelGGL((wgrad_fast_kernel<WM, WN, TM, TN, ABL>), dim3(tiles * a.splits), dim3(64 * WM * WN), lds, s, a);
-  if (int rc = check_launch("wgrad_fast_kernel")) return rc;
-  return a.splits > 1 ? launch_slab_reduce(slabs, a.DW, (long long)a.K * a.R * a.S * a.C, a.slab_stride, a.splits, s) : JPDSE_OK;
-}
-
-// slab_bytes_out != nullptr: report the slab bytes the launch would need instead of launching (workspace query)
-static int launch_wgrad_fast(const FastWgArgs& a, float* slabs, hipStream_t s, size_t* slab_bytes_out = nullptr) {
-  const int cols = a.run_mode ? a.run_len : a.Cs;
-  const bool m2 = a.Ks >= 128, n2 = cols >= 128;
-  if (a.Ks >= 256 && cols >= 256 && a.Ks % 256 == 0 && cols % 256 == 0 && !a.run_mode)
-    return launch_wgrad_fast_cfg<2, 4, 4, 2>(a, slabs, slab_bytes_out, s);     // 256 x 256, 8 waves
-  if (m2 && n2) return launch_wgrad_fast_cfg<2, 2, 2, 2>(a, slabs, slab_bytes_out, s);
-  if (m2) return launch_wgrad_fast_cfg<2, 2, 2, 1>(a, slabs, slab_bytes_out, s);
-  if (n2) return launch_wgrad_fast_cfg<2, 2, 1, 2>(a, slabs, slab_bytes_out, s);
-  return launch_wgrad_fast_cfg<2, 2, 1, 1>(a, slabs, slab_bytes_out, s);
-}
-
-template <int TM, int NW, int NT, int RR, int WM, int PITCH>
-static int launch_wgrad_thin_pitch(ThinWgArgs a, hipStream_t s);
-
-template <int TM, int NW, int NT, int RR = 1, int WM = 1>
-static int launch_wgrad_thin_cfg(const ThinWgArgs& a, hipStream_t s) {
-  switch (a.st * a.Cs) {      // the pitches of the hot path as compile-time constants
-    case 40: return launch_wgrad_thin_pitch<TM, NW, NT, RR, WM, 40>(a, s);   // 39-channel inputs, stride 1
-    case 80: return launch_wgrad_thin_pitch<TM, NW, NT, RR, WM, 80>(a, s);   // 39-channel inputs, stride 2
-    case 8: return launch_wgrad_thin_pitch<TM, NW, NT, RR, WM, 8>(a, s);     // heads (dy run operand)
-    default: return launch_wgrad_thin_pitch<TM, NW, NT, RR, WM, 0>(a, s);
-  }
-}
-
-static int thin_wgrad_ranges(const ThinWgArgs& a, int RR, int* strips_per_block) {
-  const int chunks_per_row = (a.OW + 63) / 64;
-  const int strips_total = a.N * a.OH * chunks_per_row;
-  const int row_groups = (a.R + RR - 1) / RR;
-  int P = 1024 / row_groups;               // ~4 blocks per CU over the filter-row groups
-  if (P < 1) P = 1;
-  if (P > strips_total) P = strips_total;
-  const int spb = (strips_total + P - 1) / P;
-  if (strips_per_block) *strips_per_block = spb;
-  return (strips_total + spb - 1) / spb;
-}
-static size_t thin_wgrad_slab_bytes(const ThinWgArgs& a, int RR) {
-  const long long n = ((long long)a.K * a.R * a.S * a.C + 3) / 4 * 4;
-  return (size_t)thin_wgrad_ranges(a, RR, nullptr) * n * sizeof(float);
-}
-
-template <int TM, int NW, int NT, int RR, int WM, int PITCH>
-static int launch_wgrad_thin_pitch(ThinWgArgs a, hipStream_t s) {
-  const int pitch = a.st * a.Cs;
-  a.x_units = (126 * pitch + 64 * NW * NT + 1023) / 1024;
-  const int lds = 2 * (TM * WM * 64 * 64 + RR * a.x_units * 1024);
-  if (lds > 64 * 1024) return set_error(JPDSE_ELAUNCH, "wgrad_thin: strip of %d B does not fit", lds);
-  a.chunks_per_row = (a.OW + 63) / 64;
-  a.strips_total = a.N * a.OH * a.chunks_per_row;
-  a.row_groups = (a.R + RR - 1) / RR;
-  a.ranges = thin_wgrad_ranges(a, RR, &a.strips_per_block);
-  a.slab_stride = ((long long)a.K * a.R * a.S * a.C + 3) / 4 * 4;
-  if (a.partial == nullptr) return set_error(JPDSE_EWORKSPACE, "wgrad_thin: no slab workspace");
-  // block -> (pixel range, filter-row group): the row groups of ONE pixel range read the same dy strips and nearly the
-  // same input rows; they get consecutive slots of one XCD (blocks b, b + 8, ... share an XCD: observed dispatch,
-  // speed only), so its L2 serves them -- as a (ranges, row_groups) grid they ran far apart in time and every row
-  // group re-fetched x and dy from beyond L2 (7x the algorithmic bytes on the first 7x7 conv)
-  const int blocks = ((a.ranges + 7) / 8) * 8 * a.row_groups;
-  if constexpr (RR > 1) {      // heads: roles swapped, transposed output
-    hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR, PITCH, true>), dim3(blocks), dim3(64 * WM * NW), lds, s, a);
-  } else {
-    hipLaunchKernelGGL((wgrad_thin_kernel<TM, WM, NW, NT, RR, PITCH, false>), dim3(blocks), dim3(64 * WM * NW), lds, s, a);
-  }
-  if (int rc = check_launch("wgrad_thin_kernel")) return rc;
-  return launch_slab_reduce(a.partial, a.DW, (long long)a.K * a.R * a.S * a.C, a.slab_stride, a.ranges, s);
-}
-
-static bool wgrad_thin_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
-  const int n_tiles = (d->S * p.Cs + 31) / 32;
-  return g_fast_enabled && p.Cs % 64 != 0 && (p.Ks == 32 || p.Ks == 64) && n_tiles <= 12 &&
-         (126 * d->stride * p.Cs + 64 * 12) <= 20 * 1024;
-}
-
-static int launch_wgrad_thin(const ThinWgArgs& a, hipStream_t s) {
-  const int n_tiles = (a.S * a.Cs + 31) / 32;
-  if (a.Ks == 64) {
-    if (n_tiles <= 6) return launch_wgrad_thin_cfg<2, 2, 3>(a, s);
-    if (n_tiles <= 9) return launch_wgrad_thin_cfg<2, 3, 3>(a, s);
-    return launch_wgrad_thin_cfg<2, 4, 3>(a, s);
-  }
-  if (n_tiles <= 6) return launch_wgrad_thin_cfg<1, 2, 3>(a, s);
-  if (n_tiles <= 9) return launch_wgrad_thin_cfg<1, 3, 3>(a, s);
-  return launch_wgrad_thin_cfg<1, 4, 3>(a, s);
-}
-
-// ---- all-taps weight gradient of the narrow high-resolution layers (wgrad_taps.h) -----------------
-// config id: 0 none; 1: 3x3 s2 K%128 C%64; 2: 3x3 s1 K%64 C%64; 3: 4x4 s2 K%128 C%64; 4: 3x3 s2 K%256 C%128
-JPDSE_SWITCH(int, g_wgrad_taps_enabled, 1);
-static int wgrad_taps_cfg(const jpdse_conv_desc* d, const ConvPlan& p) {
-  if (!g_fast_enabled || !g_wgrad_taps_enabled || p.ES != 2 || d->R != d->S) return 0;
-  if ((long long)d->N * p.OH * ((p.OW + 63) / 64) < 32) return 0;
-  if ((long long)d->N * p.OH * p.OW * p.Ks >= (1LL << 31) || (long long)d->N * d->H * d->W * p.Cs >= (1LL << 31)) return 0;
-  // 3x3 stride 2 with wide outputs, any width: the down-sampling convs 128 -> 256 ... 512 -> 1024 and, with the roles of
-  // x and dy swapped by the caller, the ConvTranspose2d layers 1024 -> 512 ... 128 -> 64 (round 1 sent the wide ones to
-  // the per-tap kernel, whose stream-K partial tiles met in fp32 atomics)
-  if (d->R == 3 && d->stride == 2 && p.Ks % 256 == 0 && p.Cs % 64 == 0) return 4;
-  if (p.Ks > 256 || p.Cs > 128) return 0;
-  if (d->R == 3 && d->stride == 2 && p.Ks % 128 == 0 && p.Cs % 64 == 0) return 1;
-  if (d->R == 3 && d->stride == 1 && p.Ks % 64 == 0 && p.Ks <= 128 && p.Cs % 64 == 0) return 2;
-  if (d->R == 4 && d->stride == 2 && p.Ks % 128 == 0 && p.Cs % 64 == 0) return 3;
-  return 0;
-}
-
-struct TapsGeom { int BM, BN, T, NROW, lds, blocks_per_cu; };
-static TapsGeom taps_geom(int cfg) {
-  switch (cfg) {
-    case 1: return {128, 64, 9, 3, 2 * (64 * 256 + 49 * 1024), 1};
-    case 2: return {64, 64, 9, 3, 2 * (64 * 128 + 25 * 1024), 2};
-    case 3: return {128, 64, 8, 2, 2 * (64 * 256 + 33 * 1024), 1};
-    default: return {256, 64, 3, 1, 2 * (64 * 512 + 17 * 1024), 1};
-  }
-}
-
-static void taps_partition(const jpdse_conv_desc* d, const ConvPlan& p, int cfg, TapsWgArgs* a) {
-  const TapsGeom g = taps_geom(cfg);
-  a->chunks_per_row = (p.OW + 63) / 64;
-  a->chunks_total = d->N * p.OH * a->chunks_per_row;
-  a->k_tiles = p.Ks / g.BM;
-  a->r_groups = (d->R + g.NROW - 1) / g.NROW;
-  a->c_tiles = p.Cs / g.BN;
-  const int tiles = a->k_tiles * a->r_groups * a->c_tiles;
-  int bpt = 256 * g.blocks_per_cu / tiles;
-  if (bpt < 1) bpt = 1;
-  if (bpt > a->chunks_total) bpt = a->chunks_total;
-  a->chunks_per_block = (a->chunks_total + bpt - 1) / bpt;
-  a->blocks_per_tile = (a->chunks_total + a->chunks_per_block - 1) / a->chunks_per_block;
-}
-
-static size_t wgrad_taps_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
-  const int cfg = wgrad_taps_cfg(d, p);
-  if (!cfg) return 0;
-  TapsWgArgs a = {};
-  taps_partition(d, p, cfg, &a);
-  const TapsGeom g = taps_geom(cfg);
-  return (size_t)a.k_tiles * a.r_groups * a.c_tiles * a.blocks_per_tile * g.T * g.BM * g.BN * sizeof(float);
-}
-
-template <int TMW, int WM, int WN, int S, int NROW, int ST>
-static int launch_wgrad_taps_cfg(const TapsWgArgs& a, int lds, hipStream_t s) {
-  constexpr int BM = WM * TMW * 32, BN = WN * 32;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<TMW, WM, WN, S, NROW, ST>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_taps: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
-  const int blocks = a.k_tiles * a.r_groups * a.c_tiles * a.blocks_per_tile;
-  hipLaunchKernelGGL((wgrad_taps_kernel<TMW, WM, WN, S, NROW, ST>), dim3(blocks), dim3(64 * WM * WN), lds, s, a);
-  if (int rc = check_launch("wgrad_taps_kernel")) return rc;
-  const long long total = (long long)a.K * a.R * a.S * a.C;
-  hipLaunchKernelGGL((wgrad_taps_reduce_kernel<BM, BN, S, NROW>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s,
-                     a, total);
-  return check_launch("wgrad_taps_reduce_kernel");
-}
-
-static int launch_wgrad_taps(const jpdse_conv_desc* d, const ConvPlan& p, int cfg, const void* x, const void* dy,
-                             float* dw, void* ws, hipStream_t s) {
-  TapsWgArgs a = {};
-  a.X = reinterpret_cast<const bf16_t*>(x);
-  a.DY = reinterpret_cast<const bf16_t*>(dy);
-  a.partial = reinterpret_cast<float*>(ws);
-  a.DW = dw;
-  a.N = d->N;
-  a.IH = d->H;
-  a.IW = d->W;
-  a.OH = p.OH;
-  a.OW = p.OW;
-  a.Cs = p.Cs;
-  a.C = d->C;
-  a.Ks = p.Ks;
-  a.K = d->K;
-  a.R = d->R;
-  a.S = d->S;
-  a.pad = d->pad;
-  a.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
-  taps_partition(d, p, cfg, &a);
-  const int lds = taps_geom(cfg).lds;
-  switch (cfg) {
-    case 1: return launch_wgrad_taps_cfg<1, 4, 2, 3, 3, 2>(a, lds, s);
-    case 2: return launch_wgrad_taps_cfg<1, 2, 2, 3, 3, 1>(a, lds, s);
-    case 3: return launch_wgrad_taps_cfg<1, 4, 2, 4, 2, 2>(a, lds, s);
-    default: return launch_wgrad_taps_cfg<2, 4, 2, 3, 1, 2>(a, lds, s);
-  }
-}
-
-// ---- all-nine-taps weight gradient of the wide 3x3 stride-1 layers (wgrad_nine.h): no atomics, no partial tiles ----
-JPDSE_SWITCH(int, g_wgrad_nine_enabled, 1);
-static bool wgrad_nine_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
-  return g_fast_enabled && g_wgrad_nine_enabled && p.ES == 2 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
-         p.OW % 64 == 0 && p.Ks % 64 == 0 && p.Cs % 64 == 0 && d->H >= 2 && d->W >= 8 &&
-         (long long)d->N * d->H * d->W * (p.Ks > p.Cs ? p.Ks : p.Cs) < (1LL << 31);
-}
-
-static void nine_partition(const jpdse_conv_desc* d, const ConvPlan& p, NineWgArgs* a) {
-  a->strips = d->W / 64;
-  a->chunks_total = d->N * a->strips * d->H;
-  a->k_tiles = p.Ks / 64;
-  a->c_tiles = p.Cs / 64;
-  const int tiles = a->k_tiles * a->c_tiles;
-  int splits = 1;
-  if (tiles < 192) {                         // fewer tiles than CUs: cut the pixel range (fp32 slabs + fixed-order reduce)
-    splits = 256 / tiles;
-    const int max_splits = a->chunks_total / 4 > 0 ? a->chunks_total / 4 : 1;    // >= 4 chunks per block
-    if (splits > max_splits) splits = max_splits;
-    if (splits > 32) splits = 32;
-    if (splits < 1) splits = 1;
-  }
-  a->chunks_per_split = (a->chunks_total + splits - 1) / splits;
-  a->splits = (a->chunks_total + a->chunks_per_split - 1) / a->chunks_per_split;
-  a->xcd_map = (a->k_tiles % 4 == 0 && a->c_tiles % 8 == 0 && tiles % 256 == 0) ? 1 : 0;
-}
-
-static size_t wgrad_nine_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
-  if (!wgrad_nine_ok(d, p)) return 0;
-  NineWgArgs a = {};
-  nine_partition(d, p, &a);
-  return a.splits > 1 ? (size_t)a.splits * d->K * 9 * d->C * sizeof(float) : 0;
-}
-
-JPDSE_SWITCH(int, g_nine_sched, 3);
-template <bool REFLECT, int SCHED>
-static int launch_wgrad_nine_cfg(const NineWgArgs& a, hipStream_t s) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_nine_kernel<REFLECT, SCHED, 0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kNineLds);
-    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_nine: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
-  const int blocks = a.k_tiles * a.c_tiles * a.splits;
-  const int pslot = (a.Ks == g_prof.Ks && 9LL * a.Cs == g_prof.kdim) ? prof_begin(s) : -1;
-  hipLaunchKernelGGL((wgrad_nine_kernel<REFLECT, SCHED, 0>), dim3(blocks), dim3(512), kNineLds, s, a);
-  if (int rc = check_launch("wgrad_nine_kernel")) return rc;
-  if (a.splits > 1) {
-    const long long n4 = (long long)a.K * 9 * a.C / 4;
-    hipLaunchKernelGGL(wgrad_nine_reduce_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, a.partial, a.DW, n4, a.splits);
-    if (int rc = check_launch("wgrad_nine_reduce_kernel")) return rc;
-  }
-  prof_end(pslot, 2, 2.0 * (double)a.N * a.H * a.W * (double)a.Ks * 9.0 * (double)a.Cs, s);
-  return JPDSE_OK;
-}
-
-static int launch_wgrad_nine(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* dy, float* dw,
-                             void* ws, hipStream_t s) {
-  NineWgArgs a = {};
-  a.X = reinterpret_cast<const bf16_t*>(x);
-  a.DY = reinterpret_cast<const bf16_t*>(dy);
-  a.DW = dw;
-  a.partial = reinterpret_cast<float*>(ws);
-  a.N = d->N;
-  a.H = d->H;
-  a.W = d->W;
-  a.Cs = p.Cs;
-  a.C = d->C;
-  a.Ks = p.Ks;
-  a.K = d->K;
-  nine_partition(d, p, &a);
-  if (a.splits > 1 && ((long long)d->K * 9 * d->C) % 4 != 0)
-    return set_error(JPDSE_EINVAL, "wgrad_nine: K*9*C = %lld is not a multiple of 4", (long long)d->K * 9 * d->C);
-  if (d->pad_mode != JPDSE_PAD_REFLECT) return launch_wgrad_nine_cfg<false, 3>(a, s);
-#ifdef JPDSE_DEV
-  if (g_nine_sched == 0) return launch_wgrad_nine_cfg<true, 0>(a, s);
-  if (g_nine_sched == 1) return launch_wgrad_nine_cfg<true, 1>(a, s);
-  if (g_nine_sched == 2) return launch_wgrad_nine_cfg<true, 2>(a, s);
-#endif
-  return launch_wgrad_nine_cfg<true, 3>(a, s);
-}
-
-// heads with <= 8 output channels on a 32- / 64-channel input, stride 1 (64->3, 32->3 7x7)
-static bool wgrad_head_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
-  return g_fast_enabled && p.Ks == 8 && d->stride == 1 && (p.Cs == 32 || p.Cs == 64) && d->S * 8 <= 64 && d->R <= 7 &&
-         d->R == d->S;
-}
-
-static int launch_wgrad_head(const ThinWgArgs& a, hipStream_t s) {
-  // 2 waves x 1 run tile (S*8 <= 64 columns), all R <= 7 filter rows per block
-  return a.Ks == 64 ? launch_wgrad_thin_cfg<1, 2, 1, 7, 2>(a, s) : launch_wgrad_thin_cfg<1, 2, 1, 7>(a, s);
-}
-
-// Workspace layout of the weight-gradient paths: [0, front) = padded copy of x (+ tap-expanded dy of the narrow-output
-// layers), [front, ...) = the fp32 slabs of the split reductions (slab_reduce_kernel).  The all-taps kernels (wgrad_taps,
-// wgrad_nine) make no copies and put their slabs at offset 0.
-static size_t wgrad_front_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
-  const size_t kexp_s = (size_t)round_up(d->K * d->R * d->S, 64);
-  size_t dz = (p.Ks == 8 && kexp_s <= 256) ? align_up((size_t)d->N * p.Hp * p.Wp * kexp_s * 2, 256) : 0;
-  if (p.Ks == 8 && d->stride == 1) {      // zero-padded dy of the head weight gradient (wgrad_thin.h, transposed)
-    const size_t dyp = align_up((size_t)d->N * (p.OH + 2 * (d->R - 1)) * (p.OW + 2 * (d->S - 1)) * 8 * 2 + kSlackBytes, 256);
-    dz = dz > dyp ? dz : dyp;
-  }
-  return align_up(p.xpad_bytes + dz, 256);
-}
-
-template <typename T>
-static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* dy, float* dw,
-                        void* ws, hipStream_t s, size_t* slab_bytes_out = nullptr) {
-  // slab_bytes_out != nullptr: dry run for jpdse_conv_workspace_size -- follows the dispatch below and reports the slab
-  // bytes of the path that would run, launching nothing
-  float* const slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + wgrad_front_bytes(d, p));
-  const bool dry = slab_bytes_out != nullptr;
-  if (dry) *slab_bytes_out = 0;
-  if constexpr (sizeof(T) == 2) {
-    const int kexp = d->K * d->R * d->S, kexp_s = round_up(kexp, 64);
-    if (g_fast_enabled && !wgrad_head_ok(d, p) && p.Ks == 8 && d->stride == 1 && p.Cs % 64 == 0 && kexp_s <= 256) {
-      // few output channels: dense 1x1 weight gradient over the tap-expanded dy (see expand_dy_taps_kernel)
-      bf16_t* dz = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(ws) + p.xpad_bytes);
-      FastWgArgs f = {};
-      f.X = reinterpret_cast<const bf16_t*>(ws);
-      f.DY = dz;
-      f.DW = dw;
-      f.M = d->N * p.Hp * p.Wp;
-      f.OH = p.Hp;
-      f.OW = p.Wp;
-      f.IH = p.Hp;
-      f.IW = p.Wp;
-      f.Cs = p.Cs;
-      f.C = d->C;
-      f.Ks = kexp_s;
-      f.K = kexp;
-      f.R = f.S = 1;
-      f.sy = f.sx = 1;
-      f.py = f.px = 0;
-      f.reflect = 0;
-      if (dry) return launch_wgrad_fast(f, nullptr, s, slab_bytes_out);
-      if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-        return rc;
-      const long long tv = (long long)d->N * p.Hp * p.Wp * (kexp_s / 8);
-      hipLaunchKernelGGL(expand_dy_taps_kernel, dim3(ew_blocks(tv)), dim3(256), 0, s,
-                         reinterpret_cast<const bf16_t*>(dy), dz, p.OH, p.OW, p.Ks, d->K, d->R, d->S, p.Hp, p.Wp,
-                         kexp_s, tv);
-      if (int rc = check_launch("expand_dy_taps_kernel")) return rc;
-      return launch_wgrad_fast(f, slabs, s);
-    }
-    if (const int tcfg = wgrad_taps_cfg(d, p)) return dry ? JPDSE_OK : launch_wgrad_taps(d, p, tcfg, x, dy, dw, ws, s);
-    if (wgrad_nine_ok(d, p) && ((long long)d->K * 9 * d->C) % 4 == 0)
-      return dry ? JPDSE_OK : launch_wgrad_nine(d, p, x, dy, dw, ws, s);
-    if (wgrad_head_ok(d, p)) {
-      // roles swapped (see wgrad_thin.h): A = padded input, run operand = dy zero-padded by (R-1, S-1); both
-      // paddings are resolved by the loader
-      ThinWgArgs t = {};
-      t.XP = reinterpret_cast<const bf16_t*>(dy);
-      t.DY = reinterpret_cast<const bf16_t*>(x);
-      t.DW = dw;
-      t.N = d->N;
-      t.OH = p.Hp;
-      t.OW = p.Wp;
-      t.Hp = p.OH + 2 * (d->R - 1);
-      t.Wp = p.OW + 2 * (d->S - 1);
-      t.Cs = 8;
-      t.C = d->K;
-      t.Ks = p.Cs;
-      t.K = d->C;
-      t.R = d->R;
-      t.S = d->S;
-      t.st = 1;
-      t.unpadded = 1;
-      t.RH = p.OH;
-      t.RW = p.OW;
-      t.r_pad = d->R - 1;            // square filters on this path (R == S checked by wgrad_head_ok)
-      t.r_reflect = 0;
-      t.AH = d->H;
-      t.AW = d->W;
-      t.a_pad = d->pad;
-      t.a_reflect = d->pad_mode == JPDSE_PAD_REFLECT;
-      t.transposed = 1;
-      t.partial = slabs;
-      if (dry) {
-        *slab_bytes_out = thin_wgrad_slab_bytes(t, 7);
-        return JPDSE_OK;
-      }
-      return launch_wgrad_head(t, s);
-    }
-    if (wgrad_thin_ok(d, p)) {
-      // thin inputs (40-channel network inputs): input strips staged once (wgrad_thin.h)
-      ThinWgArgs t = {};
-      t.XP = reinterpret_cast<const bf16_t*>(x);
-      t.DY = reinterpret_cast<const bf16_t*>(dy);
-      t.DW = dw;
-      t.N = d->N;
-      t.OH = p.OH;
-      t.OW = p.OW;
-      t.Hp = p.Hp;
-      t.Wp = p.Wp;
-      t.Cs = p.Cs;
-      t.C = d->C;
-      t.Ks = p.Ks;
-      t.K = d->K;
-      t.R = d->R;
-      t.S = d->S;
-      t.st = d->stride;
-      t.partial = slabs;
-      if (dry) {
-        *slab_bytes_out = thin_wgrad_slab_bytes(t, 1);
-        return JPDSE_OK;
-      }
-      if (d->stride == 2) {
-        // padding resolved by the loader (no padded copy): pays for the stride-2 layers (PatchGAN layer 0)
-        t.unpadded = 1;
-        t.RH = d->H;
-        t.RW = d->W;
-        t.r_pad = d->pad;
-        t.r_reflect = d->pad_mode == JPDSE_PAD_REFLECT;
-        t.AH = p.OH;
-        t.AW = p.OW;
-      } else {
-        // 7x7 stride-1 first convs: 7 filter rows re-read every strip, the per-lane padding arithmetic costs more
-        // than one pass of pad_kernel (measured 0.65 vs 0.84 ms)
-        if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-          return rc;
-        t.XP = reinterpret_cast<const bf16_t*>(ws);
-        t.x_limit = (long long)d->N * p.Hp * p.Wp * p.Cs + (long long)(kSlackBytes / 2);
-      }
-      return launch_wgrad_thin(t, s);
-    }
-    // the fast kernel's loader uses 32-bit element offsets
-    const bool fits32 = (long long)d->N * p.OH * p.OW * p.Ks < (1LL << 31) &&
-                        (long long)d->N * p.Hp * p.Wp * p.Cs < (1LL << 31);
-    if (g_fast_enabled && p.Ks % 64 == 0 && fits32) {
-      FastWgArgs f = {};
-      f.DY = reinterpret_cast<const bf16_t*>(dy);
-      f.DW = dw;
-      f.M = d->N * p.OH * p.OW;
-      f.OH = p.OH;
-      f.OW = p.OW;
-      f.Cs = p.Cs;
-      f.C = d->C;
-      f.Ks = p.Ks;
-      f.K = d->K;
-      f.R = d->R;
-      f.S = d->S;
-      f.sy = f.sx = d->stride;
-      if (p.Cs % 64 == 0) {
-        f.X = reinterpret_cast<const bf16_t*>(x);
-        f.IH = d->H;
-        f.IW = d->W;
-        f.py = f.px = d->pad;
-        f.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
-      } else {
-        // run mode over the materially padded input (40-channel network inputs, 8-channel images)
-        if (!dry)
-          if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-            return rc;
-        f.X = reinterpret_cast<const bf16_t*>(ws);
-        f.IH = p.Hp;
-        f.IW = p.Wp;
-        f.py = f.px = 0;
-        f.reflect = 0;
-        f.run_mode = 1;
-        f.run_len = d->S * p.Cs;
-      }
-      return launch_wgrad_fast(f, slabs, s, slab_bytes_out);
-    }
-  }
-  // always staged through the workspace: the GEMM loaders rely on the zeroed slack behind it
-  if (!dry)
-    if (int rc = launch_pad<T>(x, ws, d->N, d->H, d->W, p.Cs, d->pad, d->pad, d->pad, d->pad, d->pad_mode, s))
-      return rc;
-  const void* xin = ws;
-  GemmWgradArgs a = {};
-  a.X = xin;
-  a.DY = dy;
-  a.DW = dw;
-  a.M = d->N * p.OH * p.OW;
-  a.OH = p.OH;
-  a.OW = p.OW;
-  a.K = d->K;
-  a.Ks = p.Ks;
-  a.C = d->C;
-  a.Cs = p.Cs;
-  a.R = d->R;
-  a.S = d->S;
-  a.run = d->S * p.Cs;
-  a.in_sn = (long long)p.Hp * p.Wp * p.Cs;
-  a.in_sh = (long long)d->stride * p.Wp * p.Cs;
-  a.in_sw = (long long)d->stride * p.Cs;
-  a.in_sr = (long long)p.Wp * p.Cs;
-  a.in_base = 0;
-  a.dy_sn = (long long)p.OH * p.OW * p.Ks;
-  a.dy_sh = (long long)p.OW * p.Ks;
-  a.dy_sw = p.Ks;
-  a.dy_base = 0;
-  if (dry) {
-    *slab_bytes_out = generic_wgrad_slab_bytes<T>(a);
-    return JPDSE_OK;
-  }
-  return launch_wgrad<T>(a, slabs, s);
-}
-
-}  // namespace jpdse
 
 using namespace jpdse;
 
