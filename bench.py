@@ -89,11 +89,14 @@ def make_opt(args, device_index):
 def cpu_baseline(args, budget_s=60.0):
   """The oracle (a port: kind 'port') on this box's host cores, SURVEY.md 8(d): fp32, batch 1.  A batch-1 conv graph does
   not scale to every hardware thread of a large host (round 2 ran it on all 128 and got LESS than the survey's 8-core probe),
-  so the thread count is swept first -- one 512x256 step each at {8, 16, 32, 64, all} threads after a warm-up step -- and the
-  fastest is kept; with it, one 1024x512 step (the headline size) is timed when the projection fits the budget, else the
+  so the thread count is swept first -- one 512x256 step each at {8, 16, 32, 64, all} threads after a warm-up step, stopping once a
+  count is 1.5x slower than the best so far -- and the fastest is kept; with it, one 1024x512 step (the headline size) is timed when the projection fits the budget, else the
   512x256 figure is quoted.  `sample` says which, and which thread count won.  Bounded: about `budget_s` seconds."""
   from oracle.ctu_cpu import model as omodel
-  ncpu = os.cpu_count() or torch.get_num_threads()
+  try:
+    ncpu = len(os.sched_getaffinity(0))          # the cores this process may use, not the host's (a 16-core share of 256)
+  except (AttributeError, OSError):
+    ncpu = os.cpu_count() or torch.get_num_threads()
   opt = omodel.default_opt(netG=args.netG, ngf=64 if args.netG == 'global' else 32, use_compressed=True)
   torch.manual_seed(1234)
   ora = omodel.OracleTrainer(opt)
@@ -113,6 +116,9 @@ def cpu_baseline(args, budget_s=60.0):
   for i, c in enumerate(cands):
     if sweep and time.perf_counter() - t_start > 0.6 * budget_s:
       break
+    if sweep and sweep[max(sweep)] > 1.5 * min(sweep.values()):
+      break                                     # already past the knee: more threads only oversubscribe (round 3: 256 threads took
+                                                # 214 s for the step that 8 threads do in 1.3 s)
     torch.set_num_threads(c)
     sweep[c] = one(256, 512, 2 + i)
   best = min(sweep, key=sweep.get)
