@@ -11,11 +11,19 @@ static void fast_wgrad_partition(FastWgArgs* a, int lds) {
   a->chunks_total = (a->M + 63) / 64;
   const int tiles = ((a->Ks + BM - 1) / BM) * (a->run_mode ? a->R : a->R * a->S) *
                     (((a->run_mode ? a->run_len : a->Cs) + BN - 1) / BN);
-  int splits = (256 * blocks_per_cu + tiles / 2) / tiles;      // fill the chip once
+  // Split count by a small cost model instead of "fill the chip once" (round 3): rounds of resident blocks x (chunks per block
+  // + a fixed per-block cost of ~6 chunk times for prologue, epilogue and the 256 KB tile store) + the slab reduction a
+  // split costs (~4 + 2 per slab).  "Fill once" chose 2 splits for 144 tiles -- 288 blocks = two rounds, the second with 32
+  // blocks -- plus a 113 MB reduction, where one unsplit round is shorter (LocalEnhancer trunk: M = 2048 pixels).
   const int max_splits = a->chunks_total / 8 > 0 ? a->chunks_total / 8 : 1;      // >= 8 chunks per block
-  if (splits > max_splits) splits = max_splits;
-  if (splits > 64) splits = 64;
-  if (splits < 1) splits = 1;
+  const long long slots = 256LL * blocks_per_cu;
+  int splits = 1;
+  long long best = -1;
+  for (int sp = 1; sp <= max_splits && sp <= 64; ++sp) {
+    const long long rounds = ((long long)tiles * sp + slots - 1) / slots;
+    const long long cost = rounds * ((a->chunks_total + sp - 1) / sp + 6) + (sp > 1 ? 4 + 2 * sp : 0);
+    if (best < 0 || cost < best) { best = cost; splits = sp; }
+  }
   a->chunks_per_split = (a->chunks_total + splits - 1) / splits;
   a->splits = (a->chunks_total + a->chunks_per_split - 1) / a->chunks_per_split;
   a->slab_stride = ((long long)a->K * a->R * a->S * a->C + 3) / 4 * 4;
@@ -49,8 +57,10 @@ static int launch_wgrad_fast_cfg(FastWgArgs a, float* slabs, size_t* slab_bytes_
 static int launch_wgrad_fast(const FastWgArgs& a, float* slabs, hipStream_t s, size_t* slab_bytes_out = nullptr) {
   const int cols = a.run_mode ? a.run_len : a.Cs;
   const bool m2 = a.Ks >= 128, n2 = cols >= 128;
+  // 256 x 256 tiles, 8 waves, one block per CU.  (Round 3 tried 128 x 128 tiles, two blocks per CU, for the short reductions
+  // of the LocalEnhancer trunk -- 144 large tiles cover 56 % of the chip -- and measured it 0.45 ms per step SLOWER.)
   if (a.Ks >= 256 && cols >= 256 && a.Ks % 256 == 0 && cols % 256 == 0 && !a.run_mode)
-    return launch_wgrad_fast_cfg<2, 4, 4, 2>(a, slabs, slab_bytes_out, s);     // 256 x 256, 8 waves
+    return launch_wgrad_fast_cfg<2, 4, 4, 2>(a, slabs, slab_bytes_out, s);
   if (m2 && n2) return launch_wgrad_fast_cfg<2, 2, 2, 2>(a, slabs, slab_bytes_out, s);
   if (m2) return launch_wgrad_fast_cfg<2, 2, 2, 1>(a, slabs, slab_bytes_out, s);
   if (n2) return launch_wgrad_fast_cfg<2, 2, 1, 2>(a, slabs, slab_bytes_out, s);
