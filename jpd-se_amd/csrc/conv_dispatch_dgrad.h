@@ -175,11 +175,61 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.addend = reinterpret_cast<const bf16_t*>(addend);
       return p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
     }
+    // the same for grids of 8 x 32 patches (W = 32): tap-program kernel, nine taps, split-K over the dy channel slabs
+    if (!refl && p.nph == 1 && st == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W && p.ph[0].Lk == p.ph[0].Uw * p.Ks &&
+        taps9_shape_ok(p.ph[0].Uh, p.ph[0].Uw, 1, d->H, d->W, p.Ks, p.Cs, (long long)d->N * p.OH * p.OW * p.Ks, (long long)p.Cs * 9 * p.Ks)) {
+      const Phase& f = p.ph[0];
+      Taps4View v = {};
+      v.X = reinterpret_cast<const bf16_t*>(dy);
+      v.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
+      v.Y = reinterpret_cast<bf16_t*>(dx);
+      v.N = d->N;
+      v.IH = p.OH;
+      v.IW = p.OW;
+      v.Cin_s = p.Ks;
+      v.OH = d->H;
+      v.OW = d->W;
+      v.py = (f.Uh - 1) - f.i0h;
+      v.px = (f.Uw - 1) - f.i0w;
+      v.Kout = d->C;
+      v.Ks_out = p.Cs;
+      v.ktot = (long long)f.Uh * f.Lk;
+      v.tap_r = f.Lk;
+      v.tap_s = p.Ks;
+      v.act = JPDSE_ACT_NONE;
+      v.addend = reinterpret_cast<const bf16_t*>(addend);
+      v.mask = reinterpret_cast<const bf16_t*>(mask);
+      return launch_taps9(v, reinterpret_cast<float*>(wsb + p.splitk_off), s);
+    }
   }
   if constexpr (sizeof(T) == 2) {
+    const bool ring_halo = halo_ok(3, 3, 1, d->H, d->W, p.Ks, p.Cs);
+    const bool ring_taps = !ring_halo && taps9_shape_ok(3, 3, 1, d->H, d->W, p.Ks, p.Cs, (long long)d->N * d->H * d->W * p.Ks,
+                                                        (long long)p.Cs * 9 * p.Ks);
     if (refl && g_ring_enabled && d->R == 3 && d->S == 3 && st == 1 && d->pad == 1 && d->H >= 8 &&
-        halo_ok(3, 3, 1, d->H, d->W, p.Ks, p.Cs) && p.ph[0].Lk == 3 * p.Ks) {
-      // (1) zero-padded data gradient straight into dx
+        (ring_halo || ring_taps) && p.ph[0].Lk == 3 * p.Ks) {
+      // (1) zero-padded data gradient straight into dx: halo kernel, or the nine-tap program on 8 x 32 patches (W = 32)
+      if (ring_taps) {
+        Taps4View v = {};
+        v.X = reinterpret_cast<const bf16_t*>(dy);
+        v.B = reinterpret_cast<const bf16_t*>(pack);
+        v.Y = reinterpret_cast<bf16_t*>(dx);
+        v.N = d->N;
+        v.IH = d->H;
+        v.IW = d->W;
+        v.Cin_s = p.Ks;
+        v.OH = d->H;
+        v.OW = d->W;
+        v.py = v.px = 1;
+        v.Kout = d->C;
+        v.Ks_out = p.Cs;
+        v.ktot = 3LL * p.ph[0].Lk;
+        v.tap_r = p.ph[0].Lk;
+        v.tap_s = p.Ks;
+        v.act = JPDSE_ACT_NONE;
+        v.addend = reinterpret_cast<const bf16_t*>(addend);
+        if (int rc = launch_taps9(v, reinterpret_cast<float*>(wsb + p.splitk_off), s)) return rc;
+      }
       HaloArgs h = {};
       h.X = reinterpret_cast<const bf16_t*>(dy);
       h.B = reinterpret_cast<const bf16_t*>(pack);
@@ -199,7 +249,8 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.out_sw = p.Cs;
       h.act = JPDSE_ACT_NONE;
       h.addend = reinterpret_cast<const bf16_t*>(addend);
-      if (int rc = p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s)) return rc;
+      if (ring_halo)
+        if (int rc = p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s)) return rc;
       // (2) the four ring strips of the reflect-padded domain as split-K GEMMs into fp32 slabs
       const int H = d->H, W = d->W, Ks = p.Ks, Lk = p.ph[0].Lk;
       const bf16_t* dyb = reinterpret_cast<const bf16_t*>(dy);

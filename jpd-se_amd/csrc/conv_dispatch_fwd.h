@@ -166,6 +166,30 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       v.slope = d->slope;
       return launch_taps4(v, ws, s);
     }
+    if (p.Lk_fwd == d->S * p.Cs && mom == nullptr &&
+        taps9_shape_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks, (long long)d->N * d->H * d->W * p.Cs, (long long)p.Ks * 9 * p.Cs)) {
+      Taps4View v = {};
+      v.X = reinterpret_cast<const bf16_t*>(x);
+      v.B = reinterpret_cast<const bf16_t*>(pack);
+      v.bias = bias;
+      v.Y = reinterpret_cast<bf16_t*>(y);
+      v.N = d->N;
+      v.IH = d->H;
+      v.IW = d->W;
+      v.Cin_s = p.Cs;
+      v.OH = p.OH;
+      v.OW = p.OW;
+      v.py = v.px = d->pad;
+      v.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
+      v.Kout = d->K;
+      v.Ks_out = p.Ks;
+      v.ktot = (long long)d->R * p.Lk_fwd;
+      v.tap_r = p.Lk_fwd;
+      v.tap_s = p.Cs;
+      v.act = d->act;
+      v.slope = d->slope;
+      return launch_taps9(v, reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + p.splitk_off), s);
+    }
     if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks)) {
       HaloArgs h = {};
       h.X = reinterpret_cast<const bf16_t*>(x);

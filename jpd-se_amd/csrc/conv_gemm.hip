@@ -152,6 +152,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_moments_fused = enable != 32 && enable != 6;   // 32: InstanceNorm moments always in their own pass (A/B); 6 keeps the generic kernels' rounding points
   g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
   g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
+  g_taps9_enabled = enable != 38 && enable != 6;   // 38: 3x3 layers with 32-pixel-wide grids on the split-K fast kernel (A/B)
   g_taps4_enabled = enable != 36 && enable != 6;   // 36: 4x4 stride-1 layers on the fast kernel alone (A/B)
   g_taps_enabled = enable != 35 && enable != 6;   // 35: stride-2 data gradients on the merged-phase fast kernel instead of the tap-program halo kernel (A/B); 6 keeps the generic kernels' summation order (tap outer, slab inner)
   g_rows_enabled = enable != 29 && enable != 3;   // 29: 64-channel 3x3 layers on the halo / fast kernels instead of conv_rows (A/B)
@@ -283,6 +284,12 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
     const size_t d4 = taps4_fringe_bytes(d->N, d->H, d->W, p.Cs, 16 * p.Ks / 64);
     sk = sk > f4 ? sk : f4;
     sk = sk > d4 ? sk : d4;
+  }
+  if (p.ES == 2 && d->R == 3 && d->S == 3 && d->stride == 1) {          // split-K slabs of the nine-tap program (8 x 32 grids), forward / data gradient
+    const size_t f9 = (size_t)taps9_splits(d->N, p.OH, p.OW, p.Cs, p.Ks) * d->N * p.OH * p.OW * p.Ks * 4;
+    const size_t d9 = (size_t)taps9_splits(d->N, d->H, d->W, p.Ks, p.Cs) * d->N * d->H * d->W * p.Cs * 4;
+    const size_t t9 = p.splitk_off + (f9 > d9 ? f9 : d9);
+    sk = sk > t9 ? sk : t9;
   }
   size_t m = fwd > dgrad ? fwd : dgrad;
   if (p.ES == 2 && d->stride == 1 && d->K * d->R * d->S <= 32) {      // Z of the tap-sum forward (tapsum_kernel)

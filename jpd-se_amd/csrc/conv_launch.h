@@ -609,6 +609,7 @@ struct Taps4View {            // a stride-1 4x4 conv as the kernels see it: forw
   int tap_r, tap_s;           // panel offsets per filter-row / filter-column step
   int act; float slope;
   const bf16_t* addend; const bf16_t* mask;   // optional fused operands of a data gradient (Y's addressing)
+  int reflect;                                // 3x3 view only: mirrored instead of zero padding
 };
 
 static bool taps4_shape_ok(int R, int S, int stride, int OH, int OW, int Cin_s, int Ks_out, long long x_elems, long long b_elems) {
@@ -740,6 +741,105 @@ static int launch_taps4(const Taps4View& v, void* ws, hipStream_t s) {
     hipLaunchKernelGGL(splitk_finish_kernel, dim3(ew_blocks(total_vec)), dim3(256), 0, s, fb.p[q], total_vec);
   }
   return check_launch("taps4 fringe finish");
+}
+
+// ---- 3x3 stride-1 convs whose grid does not tile into the halo kernel's 4 x 64 patches but into 8 x 32 ones (W = 32: the
+// 1024-channel ResnetBlocks of the LocalEnhancer trunk at 16 x 32 pixels, BASELINE config 3): the tap-program kernel with nine
+// taps, zero or mirrored padding in the patch loader, and -- few tiles, K = 9216 -- split-K over the channel slabs.
+JPDSE_SWITCH(int, g_taps9_enabled, 1);      // 38: these layers on the split-K fast kernel (A/B)
+
+static bool taps9_shape_ok(int R, int S, int stride, int OH, int OW, int Cin_s, int Ks_out, long long x_elems, long long b_elems) {
+  return g_fast_enabled && g_taps9_enabled && R == 3 && S == 3 && stride == 1 && OH % 8 == 0 && OW % 32 == 0 && OW % 64 != 0 &&
+         Cin_s % 64 == 0 && Cin_s >= 128 && Ks_out % 64 == 0 && x_elems < (1LL << 31) && b_elems < (1LL << 31);
+}
+
+static int taps9_splits(int N, int OH, int OW, int Cin_s, int Ks_out) {
+  const int sp = splitk_for(N * OH * OW, Ks_out, 9 * Cin_s / 64);      // the split-K fast path's choice: its workspace region is reused
+  const int cc = Cin_s / 64;
+  return sp > cc / 2 ? (cc / 2 > 0 ? cc / 2 : 1) : sp;                 // >= 2 slabs (18 tap steps) per block
+}
+
+template <int TN>
+static int launch_taps9_cfg(const TapsArgs& a, int total, hipStream_t s) {
+  constexpr int PH = 10, PW = 34;
+  constexpr int lds = 2 * ((PH * PW + 7) / 8) * 1024 + 3 * (2 * TN * 32) * 128;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_taps_kernel<TN, 9, 0, 0, 0, 2, PH, PW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_taps(3x3): hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  if (int rc = check_tile_grid("gemm_taps(3x3)", a.N, a.OH, a.OW, 8, 32, a.Cs, (long long)a.N * a.IH * a.IW * a.Cs,
+                               (long long)a.N * a.OH * a.OW * a.Ks)) return rc;
+  const int sp = a.splits > 1 ? a.splits : 1;
+  if (total != sp * a.N * (a.OH / 8) * (a.OW / 32) * ((a.Ks + 2 * TN * 32 - 1) / (2 * TN * 32)) || (sp > 1 && a.partial == nullptr))
+    return set_error(JPDSE_EINVAL, "gemm_taps(3x3): %d blocks do not match the tile grid x %d splits", total, sp);
+  hipLaunchKernelGGL((gemm_taps_kernel<TN, 9, 0, 0, 0, 2, PH, PW>), dim3(total), dim3(512), lds, s, a);
+  return check_launch("gemm_taps_kernel(3x3)");
+}
+
+// `slabs`: fp32 workspace of >= splits * N OH OW * Ks_out floats (the plan's split-K region)
+static int launch_taps9(const Taps4View& v, float* slabs, hipStream_t s) {
+  TapsArgs a = {};
+  a.X = v.X;
+  a.Y = v.Y;
+  a.bias = v.bias;
+  a.N = v.N;
+  a.OH = v.OH;
+  a.OW = v.OW;
+  a.IH = v.IH;
+  a.IW = v.IW;
+  a.Cs = v.Cin_s;
+  a.py = v.py;
+  a.px = v.px;
+  a.reflect = v.reflect;
+  a.Kout = v.Kout;
+  a.Ks = v.Ks_out;
+  a.b_rows = v.Ks_out;
+  a.out_sn = (long long)v.OH * v.OW * v.Ks_out;
+  a.out_sh = (long long)v.OW * v.Ks_out;
+  a.out_sw = v.Ks_out;
+  a.act = v.act;
+  a.slope = v.slope;
+  a.addend = v.addend;
+  a.mask = v.mask;
+  a.prog[0].B[0] = v.B;
+  a.prog[0].ktot[0] = v.ktot;
+  a.prog[0].out_base[0] = 0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      a.prog[0].tap_off[r * 3 + c] = r * 34 + c;
+      a.prog[0].tap_koff[r * 3 + c] = r * v.tap_r + c * v.tap_s;
+    }
+  const int bn = v.Ks_out % 128 == 0 ? 128 : 64;
+  const int tiles = v.N * (v.OH / 8) * (v.OW / 32) * ((v.Ks_out + bn - 1) / bn);
+  a.splits = taps9_splits(v.N, v.OH, v.OW, v.Cin_s, v.Ks_out);
+  a.partial = a.splits > 1 ? slabs : nullptr;
+  a.nblk0 = tiles * (a.splits > 1 ? a.splits : 1);
+  if (int rc = bn == 128 ? launch_taps9_cfg<2>(a, a.nblk0, s) : launch_taps9_cfg<1>(a, a.nblk0, s)) return rc;
+  if (a.splits <= 1) return JPDSE_OK;
+  FastArgs f = {};                                  // what splitk_finish_kernel reads
+  f.Y = v.Y;
+  f.bias = v.bias;
+  f.M = v.N * v.OH * v.OW;
+  f.OH = v.OH;
+  f.OW = v.OW;
+  f.Kout = v.Kout;
+  f.Ks = v.Ks_out;
+  f.out_sn = a.out_sn;
+  f.out_sh = a.out_sh;
+  f.out_sw = a.out_sw;
+  f.out_base = 0;
+  f.act = v.act;
+  f.slope = v.slope;
+  f.splits = a.splits;
+  f.partial = slabs;
+  f.addend = v.addend;
+  f.mask = v.mask;
+  const long long total_vec = (long long)f.M * (f.Ks / 8);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3(ew_blocks(total_vec)), dim3(256), 0, s, f, total_vec);
+  return check_launch("taps9 split-K finish");
 }
 
 // 3x3 stride-1 convs whose output grid tiles into 4 x 64 patches (ResnetBlocks, VGG19, and the data
@@ -875,6 +975,9 @@ static int conv_fwd_moment_slots(const jpdse_conv_desc* d, const ConvPlan& p) {
   }
   if (d->pad_mode != JPDSE_PAD_REFLECT && p.Lk_fwd == d->S * p.Cs &&
       taps4_shape_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks, (long long)d->N * d->H * d->W * p.Cs, (long long)p.Ks * 16 * p.Cs))
+    return 0;
+  if (p.Lk_fwd == d->S * p.Cs &&
+      taps9_shape_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks, (long long)d->N * d->H * d->W * p.Cs, (long long)p.Ks * 9 * p.Cs))
     return 0;
   // halo kernel (double-buffered form: inputs of 128+ channels): one slot per 4 x 64 output patch
   if (halo_ok(d->R, d->S, d->stride, p.OH, p.OW, p.Cs, p.Ks) && p.Cs > 64 && g_halo_abl == 0) return (p.OH / 4) * (p.OW / 64);

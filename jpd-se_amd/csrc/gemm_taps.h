@@ -50,12 +50,20 @@ struct TapsArgs {
   float slope;
   const bf16_t* addend;      // optional, Y's addressing: Y = result + addend (gradient fan-in), then
   const bf16_t* mask;        // optional, Y's addressing: zeroed where mask <= 0 (ReLU backward of the conv's input)
+  int reflect;               // 1: patch pixels outside the image are mirrored (ReflectionPad2d), 0: zeros
+  // split-K over the channel slabs (one program only; few tiles, long reductions: the 1024-channel ResnetBlocks of the
+  // LocalEnhancer trunk at 16 x 32 pixels): block (tile, split) runs slabs [CC split / splits, CC (split + 1) / splits) and stores
+  // its fp32 tile into slab `split` of `partial` ([splits][N OH OW][Ks]); splitk_finish_kernel (gemm_fast.h) sums the slabs in
+  // index order and applies bias / activation / addend / mask
+  int splits;
+  float* partial;
   int nblk0;                 // blocks [0, nblk0) run prog[0], the rest prog[1]
   TapsProg prog[2];
 };
 
 template <int TN, int T0, int T1, int WROWS, int PH, int PW>
 __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg& pr, int bid, char* smem) {
+  // (bid is reduced to the tile index below when the launch is split over channel slabs)
   constexpr int NT = T0 + T1, NSETS = T1 > 0 ? 2 : 1;
   constexpr int NW = 8, WN = 2;
   constexpr int TH = 4 * WROWS, TW = 64 / WROWS;
@@ -78,6 +86,9 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
   const int wm = wid / WN, wn = wid % WN;
   const int tiles_w = a.OW / TW, tiles_h = a.OH / TH;
   const int tiles_m = a.N * tiles_h * tiles_w;
+  const int ntiles = tiles_m * ((a.Ks + BN - 1) / BN);
+  const int split = a.splits > 1 ? bid / ntiles : 0;
+  if (a.splits > 1) bid -= split * ntiles;
   const int tile_m = bid % tiles_m, tile_n = bid / tiles_m;
   const int tw_i = tile_m % tiles_w, t1 = tile_m / tiles_w;
   const int th_i = t1 % tiles_h, n = t1 / tiles_h;
@@ -99,8 +110,13 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
     const int swz_p = p;                              // the swizzle uses the LDS pixel index, also for clamped lanes
     p = p < NP ? p : NP - 1;
     const int hr = p / PW, wc = p - hr * PW;
-    const int ih = oh0 - a.py + hr, iw = ow0 - a.px + wc;
-    const bool ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
+    int ih = oh0 - a.py + hr, iw = ow0 - a.px + wc;
+    bool ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
+    if (a.reflect) {
+      ih = ih < 0 ? -ih : (ih >= a.IH ? 2 * (a.IH - 1) - ih : ih);
+      iw = iw < 0 ? -iw : (iw >= a.IW ? 2 * (a.IW - 1) - iw : iw);
+      ok = ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);     // patch rows beyond one reflection: not read by any tap
+    }
     const int chunk = (lslot ^ (swz_p >> 1)) & 7;
     h_off[i] = ok ? ((n * a.IH + ih) * a.IW + iw) * a.Cs + chunk * 8 : -1;
     h_lds[i] = ug * 1024;
@@ -143,7 +159,9 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[q][i][j][e] = 0.f;
 
-  const int CC = a.Cs >> 6;
+  const int CC_all = a.Cs >> 6;
+  const int s_begin = a.splits > 1 ? CC_all * split / a.splits : 0;
+  const int CC = a.splits > 1 ? CC_all * (split + 1) / a.splits : CC_all;      // slabs [s_begin, CC)
 
   auto issue_patch_unit = [&](int i, int slab) {      // i: compile-time after unrolling at the call sites
     char* const dst = halo0 + (slab & 1) * HALO + h_lds[i];
@@ -161,9 +179,9 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
   // prologue: whole patch of slab 0, then weight tiles 0 and 1 (NT >= 2)
 #pragma unroll
   for (int i = 0; i < HU; ++i)
-    if (i < n_hu) issue_patch_unit(i, 0);
-  issue_b(0, 0, 0);
-  issue_b(1, 0, 1);
+    if (i < n_hu) issue_patch_unit(i, s_begin);
+  issue_b(0, s_begin, 0);
+  issue_b(1, s_begin, 1);
 
   // One (slab, tap) step.  SM = slab % 3 and TAP are compile-time: ring stage (SM * NT + TAP) % 3, accumulator set, the
   // patch units of the next slab to prefetch and the tap two steps ahead are constants; `more` (another slab follows) and
@@ -217,7 +235,7 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
   };
 
   // slabs in groups of three (the ring stage of a step repeats every 3 steps; NT is not a multiple of 3 in general)
-  for (int slab0 = 0; slab0 < CC; slab0 += 3) {
+  for (int slab0 = s_begin; slab0 < CC; slab0 += 3) {
 #pragma unroll
     for (int sm = 0; sm < 3; ++sm) {
       const int slab = slab0 + sm;
@@ -229,6 +247,26 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
     }
   }
 
+  // ---- split-K: the fp32 accumulators go to this split's slab as they are (row m = the pixel's linear index)
+  if (a.splits > 1) {
+    float* const slab = a.partial + (long long)split * ((long long)a.N * a.OH * a.OW) * a.Ks;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+      if (col >= a.Ks) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);      // 0..63: the wave's pixel inside its 64
+          const int r = WROWS == 1 ? wm : 2 * wm + (rl >> 5), c = WROWS == 1 ? rl : (rl & 31);
+          const long long m = ((long long)n * a.OH + oh0 + r) * a.OW + ow0 + c;
+          slab[m * a.Ks + col] = acc[0][i][j][e];
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue, one accumulator set at a time through the same LDS tile: 16-byte channel vectors to global
   constexpr int PITCH = BN * 2 + 64;
   static_assert(TH * TW * PITCH <= 2 * HALO + 3 * B_STAGE, "epilogue tile fits the pipeline LDS");

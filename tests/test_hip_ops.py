@@ -114,6 +114,12 @@ CONV_CASES = [
     ('taps4_l3_small',  2, 17, 33,  256, 512, 4, 1, 2, PAD_ZERO,     ACT_NONE),
     ('taps4_core_only', 1, 15, 63,  128, 128, 4, 1, 2, PAD_ZERO,     ACT_NONE),
     ('taps4_n64_lrelu', 2, 9,  40,  128, 64,  4, 1, 2, PAD_ZERO,     ACT_LRELU),
+    # 3x3 stride-1 layers whose grid tiles into 8 x 32 patches but not 4 x 64 (W = 32: the LocalEnhancer trunk): nine-tap
+    # program, mirrored / zero padding in the patch loader, split-K over the channel slabs (first case: 2 splits; its data
+    # gradient = interior on the same kernel + ring strips + fold), unsplit, 64-wide output tile on a 96-pixel-wide grid
+    ('taps9_reflect',   2, 16, 32,  256, 256, 3, 1, 1, PAD_REFLECT,  ACT_NONE),
+    ('taps9_zero',      1, 8,  32,  128, 128, 3, 1, 1, PAD_ZERO,     ACT_RELU),
+    ('taps9_n64_w96',   1, 8,  96,  192, 64,  3, 1, 1, PAD_ZERO,     ACT_NONE),
     # filter-in-registers row-streaming kernel (conv_rows.h: 64-channel inputs, 3x3, zero pad): stride 2 with 128 / 64
     # outputs (4 x 1 / 2 x 2 waves), stride 1 likewise; several strips, several bands, bands of 16 rows (steady-state
     # look-ahead), borders on every side; the data gradient of the 64-output cases runs on it too
@@ -228,6 +234,7 @@ FUSED_RELU_CASES = [
     # there) and the two-set stride-2 data gradient
     ('taps4_fused',   2, 17, 33, 128, 256, 4, 1, 2, PAD_ZERO),
     ('tapsprog_fused', 1, 16, 128, 128, 256, 3, 2, 1, PAD_ZERO),
+    ('taps9_fused',   1, 16, 32, 256, 256, 3, 1, 1, PAD_ZERO),       # split-K: the finish kernel applies addend / mask
 ]
 
 
