@@ -21,12 +21,12 @@ for k, (c, d) in sorted(byk.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[2])
 if len(sys.argv) > 3:
   agg = collections.OrderedDict()
   for r in step:
-    n = r['Kernel_Name'].replace('void jpdse::', '').replace('jpdse::', '').split('(')[0][:50]
+    n = r['Kernel_Name'].replace('void jpdse::', '').replace('jpdse::', '').split('(')[0][:66]
     key = (n, r['Grid_Size_X'], r['Grid_Size_Y'])
     a = agg.setdefault(key, [0, 0]); a[0] += 1; a[1] += dur(r)
   print('--- by kernel and grid')
   for k, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[3])]:
-    print('%-52s grid %8s x%3s  x%3d  %8.1f us  avg %7.1f' % (k[0], k[1], k[2], c, d / 1e3, d / 1e3 / c))
+    print('%-68s grid %8s x%3s  x%3d  %8.1f us  avg %7.1f' % (k[0], k[1], k[2], c, d / 1e3, d / 1e3 / c))
 # gaps between consecutive kernels of the step (launch latency the GPU could not hide)
 gaps = []
 for p, q in zip(step[:-1], step[1:]):
