@@ -150,7 +150,7 @@ static int wgrad_taps_cfg(const jpdse_conv_desc* d, const ConvPlan& p) {
   // 3x3 stride 2 with wide outputs, any width: the down-sampling convs 128 -> 256 ... 512 -> 1024 and, with the roles of
   // x and dy swapped by the caller, the ConvTranspose2d layers 1024 -> 512 ... 128 -> 64 (round 1 sent the wide ones to
   // the per-tap kernel, whose stream-K partial tiles met in fp32 atomics)
-  if (d->R == 3 && d->stride == 2 && p.Ks % 256 == 0 && p.Cs % 64 == 0) return 4;
+  if (d->R == 3 && d->stride == 2 && p.Ks % 256 == 0 && p.Cs % 64 == 0) return 4;      // (round 3: the all-nine-taps config 1 on these wide layers measured -3 ... -11 %, +5 % only at 512 -> 1024)
   if (p.Ks > 256 || p.Cs > 128) return 0;
   if (d->R == 3 && d->stride == 2 && p.Ks % 128 == 0 && p.Cs % 64 == 0) return 1;
   if (d->R == 3 && d->stride == 1 && p.Ks % 64 == 0 && p.Ks <= 128 && p.Cs % 64 == 0) return 2;
