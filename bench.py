@@ -59,6 +59,8 @@ def parse():
                   help='A/B only: leave the in-library hipEvent timers off in the timed region (no roofline objects)')
   ap.add_argument('--late-readback', action='store_true',
                   help='A/B only: read the losses back after the optimizer steps, as round 2 did')
+  ap.add_argument('--unfused-d-lrelu', action='store_true',
+                  help="A/B only: the PatchGAN layer-0 LeakyReLU backward as its own pass instead of in layer 1's epilogue")
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                   help='collective backend for N > 1: nccl == RCCL over xGMI (the product path); gloo only to rehearse '
                        'the multi-rank schedule on a box with fewer GPUs than ranks (with --share-gpu)')
@@ -258,6 +260,10 @@ def main():
   L = lib()
   if args.late_readback:
     trainer.model.early_loss_readback = False
+  if args.unfused_d_lrelu:
+    for m in trainer.model.netD.modules():
+      if hasattr(m, 'fuse_lrelu0'):
+        m.fuse_lrelu0 = False
   # In-library kernel timers (hipEvent pairs on the kernels' own stream, inside the timed region).  Every event costs the
   # stream ~3.7 us (measured round 3: 296 events per step = 1.1 ms of a 26.3 ms step), so they cover the FIRST
   # step of the timed region only -- one step holds 36 ResnetBlock GEMM launches, 18 weight gradients, 72 norm calls.

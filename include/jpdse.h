@@ -161,6 +161,14 @@ int jpdse_conv_dgrad_relu(const jpdse_conv_desc* d, const void* dy, const void* 
 int jpdse_conv_dgrad_fused(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack,
                            const void* x, const void* addend, void* dx, void* ws, size_t ws_bytes,
                            void* stream);
+/* LeakyReLU form of the above: dx = r * (x > 0 ? 1 : slope) with r = conv_dgrad(dy) + addend rounded to
+ * the tensor dtype.  `x` (required) is this conv's own input, the OUTPUT of LeakyReLU(slope) -- the chain
+ * Conv2d -> LeakyReLU(0.2) -> Conv2d of NLayerDiscriminator (networks.py:399-404) -- so dx is the
+ * gradient w.r.t. that LeakyReLU's pre-activation; equal, bit for bit, to jpdse_conv_dgrad_fused(x = NULL)
+ * followed by jpdse_act_bwd(JPDSE_ACT_LRELU). */
+int jpdse_conv_dgrad_fused_lrelu(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack,
+                                 const void* x, float slope, const void* addend, void* dx, void* ws,
+                                 size_t ws_bytes, void* stream);
 /* dw (fp32, KRSC master layout) = d(loss)/d(w); overwritten (beta = 0) */
 int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw_krsc,
                      void* ws, size_t ws_bytes, void* stream);

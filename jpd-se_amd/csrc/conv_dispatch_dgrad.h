@@ -85,11 +85,11 @@ __global__ __launch_bounds__(256) void ring_fold_kernel(const RingFoldArgs a, lo
   Vec16<bf16_t>::store(dst, cur);
 }
 
-// dx = (dx + addend) * (mask > 0), 16-byte vectors: the unfused form of the data-gradient epilogue extras
-// (either pointer may be null)
+// dx = (dx + addend) * (mask > 0 ? 1 : slope), 16-byte vectors: the unfused form of the data-gradient epilogue
+// extras (either pointer may be null); the sum is rounded to T before the slope, as the fused epilogues do
 template <typename T>
 __global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask, long long total_vec,
-                                 const T* __restrict__ addend = nullptr) {
+                                 const T* __restrict__ addend = nullptr, float slope = 0.f) {
   constexpr int VE = Vec16<T>::N;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total_vec;
        i += (long long)gridDim.x * blockDim.x) {
@@ -103,7 +103,10 @@ __global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask,
     if (mask != nullptr) {
       Vec16<T>::load(mask + i * VE, m);
 #pragma unroll
-      for (int e = 0; e < VE; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < VE; ++e) {
+        const float r = sizeof(T) == 2 ? bf16_round(v[e]) : v[e];
+        v[e] = m[e] > 0.f ? v[e] : (slope == 0.f ? 0.f : r * slope);
+      }
     }
     Vec16<T>::store(dx + i * VE, v);
   }
@@ -111,14 +114,17 @@ __global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask,
 
 template <typename T>
 static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx,
-                        void* ws, hipStream_t s, const void* mask = nullptr, const void* addend = nullptr, float* mom = nullptr) {
+                        void* ws, hipStream_t s, const void* mask = nullptr, const void* addend = nullptr, float* mom = nullptr,
+                        float mask_slope = 0.f) {
   char* wsb = reinterpret_cast<char*>(ws);
   void* dyp = wsb;
   void* dxp = wsb + p.dypad_bytes;
   const bool refl = d->pad_mode == JPDSE_PAD_REFLECT;
   const int st = d->stride;
+  // LeakyReLU-backward epilogue (mask_slope != 0): only the generic tile kernels and the unfused pass apply it
+  const bool lrelu = mask != nullptr && mask_slope != 0.f;
   if constexpr (sizeof(T) == 2) {
-    if (!refl && p.nph == 1 && st == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W &&
+    if (!lrelu && !refl && p.nph == 1 && st == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W &&
         rows_ok(p.ph[0].Uh, p.ph[0].Uw, 1, 0, JPDSE_ACT_NONE, d->H, d->W, p.Ks, p.Cs) && p.ph[0].Lk == 3 * p.Ks) {
       const Phase& f = p.ph[0];
       RowsArgs r = {};
@@ -146,7 +152,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     }
   }
   if constexpr (sizeof(T) == 2) {
-    if (!refl && p.nph == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W &&
+    if (!lrelu && !refl && p.nph == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W &&
         halo_ok(p.ph[0].Uh, p.ph[0].Uw, st, d->H, d->W, p.Ks, p.Cs)) {
       const Phase& f = p.ph[0];
       HaloArgs h = {};
@@ -176,7 +182,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       return p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
     }
     // the same for grids of 8 x 32 patches (W = 32): tap-program kernel, nine taps, split-K over the dy channel slabs
-    if (!refl && p.nph == 1 && st == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W && p.ph[0].Lk == p.ph[0].Uw * p.Ks &&
+    if (!lrelu && !refl && p.nph == 1 && st == 1 && p.ph[0].cnth == d->H && p.ph[0].cntw == d->W && p.ph[0].Lk == p.ph[0].Uw * p.Ks &&
         taps9_shape_ok(p.ph[0].Uh, p.ph[0].Uw, 1, d->H, d->W, p.Ks, p.Cs, (long long)d->N * p.OH * p.OW * p.Ks, (long long)p.Cs * 9 * p.Ks)) {
       const Phase& f = p.ph[0];
       Taps4View v = {};
@@ -206,7 +212,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     const bool ring_halo = halo_ok(3, 3, 1, d->H, d->W, p.Ks, p.Cs);
     const bool ring_taps = !ring_halo && taps9_shape_ok(3, 3, 1, d->H, d->W, p.Ks, p.Cs, (long long)d->N * d->H * d->W * p.Ks,
                                                         (long long)p.Cs * 9 * p.Ks);
-    if (refl && g_ring_enabled && d->R == 3 && d->S == 3 && st == 1 && d->pad == 1 && d->H >= 8 &&
+    if (!lrelu && refl && g_ring_enabled && d->R == 3 && d->S == 3 && st == 1 && d->pad == 1 && d->H >= 8 &&
         (ring_halo || ring_taps) && p.ph[0].Lk == 3 * p.Ks) {
       // (1) zero-padded data gradient straight into dx: halo kernel, or the nine-tap program on 8 x 32 patches (W = 32)
       if (ring_taps) {
@@ -405,8 +411,8 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     }
   }
   if constexpr (sizeof(T) == 2) {
-    if (taps_dgrad2_ok(d, p, mask, addend, mom)) return launch_taps_dgrad2(d, p, dy, pack, dx, s, mask, addend);
-    if (!refl && p.nph == 1 && st == 1 && mom == nullptr && p.ph[0].cnth == d->H &&
+    if (!lrelu && taps_dgrad2_ok(d, p, mask, addend, mom)) return launch_taps_dgrad2(d, p, dy, pack, dx, s, mask, addend);
+    if (!lrelu && !refl && p.nph == 1 && st == 1 && mom == nullptr && p.ph[0].cnth == d->H &&
         p.ph[0].cntw == d->W && p.ph[0].Lk == p.ph[0].Uw * p.Ks &&
         taps4_shape_ok(p.ph[0].Uh, p.ph[0].Uw, 1, d->H, d->W, p.Ks, p.Cs, (long long)d->N * p.OH * p.OW * p.Ks, (long long)p.Cs * 16 * p.Ks)) {
       const Phase& f = p.ph[0];
@@ -500,6 +506,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         g.act = JPDSE_ACT_NONE;
         g.slope = 0.f;
         g.mask = refl ? nullptr : reinterpret_cast<const bf16_t*>(mask);
+        g.mask_slope = mask_slope;
         g.addend = refl ? nullptr : reinterpret_cast<const bf16_t*>(addend);
         g.splits = nlive_phases == 1 ? splitk_for(g.M, p.Cs, f.Uh * f.Uw * p.Ks / 64) : 1;
         g.partial = reinterpret_cast<float*>(wsb + p.splitk_off);
@@ -559,7 +566,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     const int VE = 16 / (int)sizeof(T);
     const long long total_vec = (long long)d->N * d->H * d->W * (p.Cs / VE);
     hipLaunchKernelGGL((relu_mask_kernel<T>), dim3(ew_blocks(total_vec)), dim3(256), 0, s, reinterpret_cast<T*>(dx),
-                       reinterpret_cast<const T*>(mask), total_vec, reinterpret_cast<const T*>(addend));
+                       reinterpret_cast<const T*>(mask), total_vec, reinterpret_cast<const T*>(addend), mask_slope);
     rc = check_launch("relu_mask_kernel");
   }
   return rc;

@@ -492,6 +492,21 @@ int jpdse_conv_dgrad_fused(const jpdse_conv_desc* d, const void* dy, const void*
                                 : conv_dgrad_t<float>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x, addend);
 }
 
+int jpdse_conv_dgrad_fused_lrelu(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, const void* x,
+                                 float slope, const void* addend, void* dx, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(dy && dgrad_pack && dx && x, "conv_dgrad_fused_lrelu: null pointer");
+  JPDSE_REQUIRE(slope >= 0.f && slope < 1.f, "conv_dgrad_fused_lrelu: slope %g outside [0, 1)", (double)slope);
+  ConvPlan p;
+  make_plan(d, &p);
+  const size_t need = jpdse_conv_workspace_size(d);
+  if (ws == nullptr || ws_bytes < need)
+    return set_error(JPDSE_EWORKSPACE, "conv_dgrad_fused_lrelu: workspace %zu < %zu", ws_bytes, need);
+  return d->dtype == JPDSE_BF16
+             ? conv_dgrad_t<bf16_t>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x, addend, nullptr, slope)
+             : conv_dgrad_t<float>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x, addend, nullptr, slope);
+}
+
 int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,
                      void* stream) {
   if (int rc = validate(d)) return rc;

@@ -42,6 +42,7 @@ struct FastArgs {
   // optional fused ReLU backward: Y is zeroed where mask <= 0 (mask has Y's addressing: the conv's input)
   const bf16_t* mask;
   const bf16_t* addend;   // optional: Y = result + addend (same addressing as Y), before the mask
+  float mask_slope;       // LeakyReLU backward: Y is scaled by this where mask <= 0 (0 = ReLU backward)
   // optional generalisations (0 = the dense defaults): batch stride of X (a sub-image of a larger tensor),
   // B row stride and B offsets per filter-row / filter-column step (a sub-panel of a larger filter panel)
   long long x_sn, x_sh;   // batch / row strides of X in elements
@@ -157,6 +158,21 @@ __device__ __forceinline__ u32x4 relu_mask8(u32x4 v, u32x4 m) {
     const uint32_t klo = (lo - 1u) < 0x7f80u ? 0xffffu : 0u;          // 0 < bits <= +inf
     const uint32_t khi = (hi - 1u) < 0x7f80u ? 0xffff0000u : 0u;
     v[i] &= (klo | khi);
+  }
+  return v;
+}
+
+// LeakyReLU form: values of `v` scaled by `slope` (and rounded to bf16 again) where the matching value of `m` is <= 0
+__device__ __forceinline__ u32x4 lrelu_mask8(u32x4 v, u32x4 m, float slope) {
+  if (slope == 0.f) return relu_mask8(v, m);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t lo = m[i] & 0xffffu, hi = m[i] >> 16;
+    const uint32_t slo = f2bf(__uint_as_float(v[i] << 16) * slope);
+    const uint32_t shi = f2bf(__uint_as_float(v[i] & 0xffff0000u) * slope);
+    const uint32_t rlo = (lo - 1u) < 0x7f80u ? (v[i] & 0xffffu) : slo;
+    const uint32_t rhi = (hi - 1u) < 0x7f80u ? (v[i] >> 16) : shi;
+    v[i] = rlo | (rhi << 16);
   }
   return v;
 }
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
         if (it0 + g >= NV || off < 0 || n0 + v * 8 >= a.Ks) continue;
         u32x4 val = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
         if (a.addend != nullptr) val = add_bf16x8(val, addv[g]);
-        if (a.mask != nullptr) val = relu_mask8(val, mskv[g]);
+        if (a.mask != nullptr) val = lrelu_mask8(val, mskv[g], a.mask_slope);
         *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = val;
       }
     }
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const FastArgs a, lo
     float mk[8];
     Vec16<bf16_t>::load(a.mask + off + c0, mk);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = mk[e] > 0.f ? o[e] : 0.f;
+    for (int e = 0; e < 8; ++e) o[e] = mk[e] > 0.f ? o[e] : (a.mask_slope == 0.f ? 0.f : bf16_round(o[e]) * a.mask_slope);
   }
   Vec16<bf16_t>::store(a.Y + off + c0, o);
 }

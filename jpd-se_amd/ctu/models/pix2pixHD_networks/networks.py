@@ -231,6 +231,7 @@ class NLayerDiscriminator(nn.Module):
     if use_sigmoid:
       raise NotImplementedError('--no_lsgan (sigmoid discriminator) is outside the JPD-SE hot path')
     self.n_layers = n_layers
+    self.fuse_lrelu0 = True     # False: stage 0's LeakyReLU backward as its own pass (tests compare the two forms)
     self.cdtype = dtype_code(compute_dtype)
     kw = dict(dtype=self.cdtype, device=device)
     chans = [input_nc, ndf]
@@ -268,20 +269,27 @@ class NLayerDiscriminator(nn.Module):
     those channels only (needs need_dw False: the generator's pass through D)."""
     d = None
     fused = False           # dfeats[j] already summed into d by the data-gradient epilogue of stage j+1
+    dz0 = False             # d is already the gradient w.r.t. stage 0's pre-activation
     for j in range(len(self._stages) - 1, -1, -1):
       if dfeats[j] is not None and not fused:
         d = dfeats[j] if d is None else ops.add_(d, dfeats[j])
       fused = False
       if d is None:
         continue
+      # stage 1's input is stage 0's LeakyReLU(0.2) output: that activation's backward rides in the epilogue of
+      # stage 1's data gradient (after the feature-matching addend), and stage 0 then starts from dz
+      lrelu0 = dict(relu_input=True, input_slope=self._stages[0].slope) if (j == 1 and self.fuse_lrelu0) else {}
       if j == 0 and dx_channels is not None and need_dx and not need_dw:
-        d = self._stages[0].bwd_input_slice(ctxs[0], d, dx_channels[0], dx_channels[1])
-      elif j > 0 and dfeats[j - 1] is not None:
+        d = self._stages[0].bwd_input_slice(ctxs[0], d, dx_channels[0], dx_channels[1], dy_is_dz=dz0)
+      elif j == 0:
+        d = self._stages[0].bwd(ctxs[0], d, need_dx, need_dw, dy_is_dz=dz0)
+      elif dfeats[j - 1] is not None:
         # the feature-matching gradient of feature j-1 joins in the epilogue of this stage's data gradient
-        d = self._stages[j].bwd(ctxs[j], d, True, need_dw, addend=dfeats[j - 1])
+        d = self._stages[j].bwd(ctxs[j], d, True, need_dw, addend=dfeats[j - 1], **lrelu0)
         fused = True
       else:
-        d = self._stages[j].bwd(ctxs[j], d, need_dx or j > 0, need_dw)
+        d = self._stages[j].bwd(ctxs[j], d, True, need_dw, **lrelu0)
+      dz0 = bool(lrelu0)
     return d
 
 

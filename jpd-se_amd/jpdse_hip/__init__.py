@@ -71,6 +71,7 @@ SIGNATURES = {
     'jpdse_conv_dgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad_relu': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad_fused': (_I32, [_CD, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_conv_dgrad_fused_lrelu': (_I32, [_CD, _P, _P, _P, _F, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_wgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_convT_fwd': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_moment_slots': (_I32, [_CD]),

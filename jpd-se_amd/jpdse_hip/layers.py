@@ -195,11 +195,11 @@ class HipConv2d(nn.Module):
     y, mom = ops.conv_fwd_moments(d, x, dgrad_pack if self.transposed else fwd_pack, slots, self.transposed)
     return y, (Ctx(x) if self.transposed else Ctx(x, None)), mom, slots
 
-  def bwd(self, ctx, dy, need_dx=True, need_dw=True, dy_is_dz=False, relu_input=False, addend=None):
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True, dy_is_dz=False, relu_input=False, addend=None, input_slope=0.0):
     """dy_is_dz: dy is already the gradient w.r.t. the PRE-activation (the caller fused this layer's
-    activation backward upstream); relu_input: the layer's input is a ReLU output and the returned dx
-    is wanted w.r.t. that ReLU's pre-activation (mask fused into the data-gradient epilogue); addend: another
-    gradient w.r.t. the layer's input, summed into dx in the same epilogue."""
+    activation backward upstream); relu_input: the layer's input is a ReLU output (LeakyReLU(input_slope) when
+    input_slope != 0) and the returned dx is wanted w.r.t. that activation's pre-activation (mask fused into the
+    data-gradient epilogue); addend: another gradient w.r.t. the layer's input, summed into dx in the same epilogue."""
     fwd_pack, dgrad_pack = self.packs()
     need_dw = need_dw and self.weight.requires_grad
     if self.transposed:
@@ -221,16 +221,18 @@ class HipConv2d(nn.Module):
         if self.bias.grad.data_ptr() != store.data_ptr():
           self.bias.grad.copy_(store[:self.cout])   # .grad re-homed into a DDP bucket view
       self._fire()
-    return ops.conv_dgrad(d, dz, dgrad_pack, relu_input=x if relu_input else None, addend=addend) if need_dx else None
+    if not need_dx:
+      return None
+    return ops.conv_dgrad(d, dz, dgrad_pack, relu_input=x if relu_input else None, addend=addend, mask_slope=input_slope)
 
-  def bwd_input_slice(self, ctx, dy, c0, c1):
+  def bwd_input_slice(self, ctx, dy, c0, c1, dy_is_dz=False):
     """Data gradient w.r.t. input channels [c0, c1) only (no weight gradient): the conv restricted to those input
     channels has the filter w[:, c0:c1], and its data gradient is that slice of the full one.  Used where only part
     of a concatenated input needs a gradient (PatchGAN layer 0: 3 image channels of the 39-channel input -- the
     full data gradient is 13x the work and 5x the bytes)."""
     assert not self.transposed
     x, y = ctx.items
-    dz = dy if self.act == ACT_NONE else ops.act_bwd(y, dy, self.act, self.slope)
+    dz = dy if (self.act == ACT_NONE or dy_is_dz) else ops.act_bwd(y, dy, self.act, self.slope)
     w = self._master()
     key = (w._version, _weights_epoch[0], w.data_ptr(), self.cdtype, getattr(w, '_jpdse_wver', 0), c0, c1)
     d = ops.conv_desc(self.cdtype, x.N, x.H, x.W, c1 - c0, self.cout, self.k, self.k, self.stride, self.pad,
@@ -324,10 +326,10 @@ class ConvNormAct(object):
     y, c2 = self.norm.fwd(h)
     return y, Ctx(c1, c2)
 
-  def bwd(self, ctx, dy, need_dx=True, need_dw=True, addend=None):
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True, addend=None, **conv_kw):
     c1, c2 = ctx.items
     dh = self.norm.bwd(c2, dy)
-    return self.conv.bwd(c1, dh, need_dx, need_dw, addend=addend)
+    return self.conv.bwd(c1, dh, need_dx, need_dw, addend=addend, **conv_kw)
 
 
 class _Slot(nn.Module):

@@ -118,12 +118,18 @@ def conv_fwd(d, x, fwd_pack, bias, out=None):
   return y
 
 
-def conv_dgrad(d, dy, dgrad_pack, relu_input=None, addend=None):
+def conv_dgrad(d, dy, dgrad_pack, relu_input=None, addend=None, mask_slope=0.0):
   """relu_input: the conv's own input x when it is a ReLU output -- dx is then masked where x <= 0
-  (the ReLU backward fused into the GEMM epilogue).  addend: another gradient w.r.t. the same tensor
-  (skip connection, loss tap), summed in the epilogue: dx = (dgrad + addend) * mask."""
+  (the ReLU backward fused into the GEMM epilogue); with mask_slope != 0 x is a LeakyReLU(mask_slope) output and
+  dx is scaled by the slope there instead.  addend: another gradient w.r.t. the same tensor (skip connection,
+  loss tap), summed in the epilogue: dx = (dgrad + addend) * mask."""
   dx = Act.empty(d.N, d.H, d.W, d.C, d.dtype, dy.t.device)
   ws, n = _conv_ws(d, dy.t.device)
+  if relu_input is not None and mask_slope != 0.0:
+    check(lib().jpdse_conv_dgrad_fused_lrelu(ctypes.byref(d), _p(dy.t), _p(dgrad_pack), _p(relu_input.t), float(mask_slope),
+                                             _p(addend.t if addend is not None else None), _p(dx.t), _p(ws),
+                                             ws.numel(), _stream()), 'conv_dgrad_fused_lrelu')
+    return dx
   if relu_input is not None or addend is not None:
     check(lib().jpdse_conv_dgrad_fused(ctypes.byref(d), _p(dy.t), _p(dgrad_pack),
                                        _p(relu_input.t if relu_input is not None else None),

@@ -122,6 +122,18 @@ def test_discriminator_golden(golden_dir, dtype):
   for k in g.files:
     if k.startswith('g:') and k.endswith('.weight'):
       _ac(params[k[2:]].grad.cpu(), g[k], 5 * tol, 'D grad ' + k[2:])
+  # stage 0's LeakyReLU backward in the epilogue of stage 1's data gradient == the separate pass, bit for bit
+  fused = [dx.t.clone()] + [p.grad.clone() for p in net.parameters()]
+  for m in net.modules():
+    if hasattr(m, 'fuse_lrelu0'):
+      m.fuse_lrelu0 = False
+  dx_u = net.bwd(ctxs, dres, need_dx=True, need_dw=True)
+  torch.cuda.synchronize()
+  for a, b in zip(fused, [dx_u.t] + [p.grad for p in net.parameters()]):
+    assert torch.equal(a, b), 'fused LeakyReLU backward changed a discriminator gradient'
+  for m in net.modules():
+    if hasattr(m, 'fuse_lrelu0'):
+      m.fuse_lrelu0 = True
   # sub-batch backward (used for the fake half of the batched pass) == full backward restricted
   dx0 = net.bwd(ctxs, [[a.batch_slice(0, 1) for a in row] for row in dres], need_dx=True, need_dw=False,
                 batch=(0, 1))

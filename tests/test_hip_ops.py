@@ -269,6 +269,52 @@ def test_conv_dgrad_fused_relu(case, dtype):
   assert_close(to_nchw(dx3), x_leaf.grad + other, RTOL[dtype], name + ' dgrad + addend')
 
 
+LRELU_CASES = [
+    # name, N, H, W, C, K, k, stride, pad, mode -- the discriminator's layer-1 shape family (4x4 stride 2, pad 2, odd
+    # extents: merged-phase tile kernel), a split-K small one, and a generic-path one
+    ('d1_like',      2, 33, 65, 64, 128, 4, 2, 2, PAD_ZERO),
+    ('d1_like_even', 1, 32, 64, 64, 128, 4, 2, 2, PAD_ZERO),
+    ('small_splitk', 1, 9, 9, 64, 128, 4, 2, 2, PAD_ZERO),
+    ('generic',      1, 11, 13, 24, 40, 3, 1, 1, PAD_ZERO),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', LRELU_CASES, ids=[c[0] for c in LRELU_CASES])
+def test_conv_dgrad_fused_lrelu(case, dtype):
+  """jpdse_conv_dgrad_fused_lrelu == data gradient (+ addend) followed by the LeakyReLU backward pass, bit for bit,
+  and close to autograd through conv(leaky_relu(z))."""
+  name, N, H, W, C, K, k, st, pad, mode = case
+  g = G(zlib.crc32(name.encode()) % 1000 + 11)
+  z = quantize_like(torch.randn(N, C, H, W, generator=g), dtype)
+  w = torch.randn(K, C, k, k, generator=g) * (1.0 / (C * k * k) ** 0.5)
+  layer = HipConv2d(C, K, k, st, pad, mode, act=ACT_NONE, apply_bias=False, dtype=dtype, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(w)
+  zr = z.clone().requires_grad_(True)
+  wr = quantize_like(w, dtype)
+  y_ref = _torch_conv(F.leaky_relu(zr, 0.2), wr, None, st, pad, mode, ACT_NONE)
+  gy = quantize_like(torch.randn(y_ref.shape, generator=g), dtype)
+  y_ref.backward(gy)
+  xa = to_act(quantize_like(F.leaky_relu(z, 0.2), dtype), dtype)
+  y, ctx = layer.fwd(xa)
+  dz = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False, relu_input=True, input_slope=0.2)
+  dx = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False)
+  two_pass = ops.act_bwd(xa, dx, ACT_LRELU, 0.2)
+  torch.cuda.synchronize()
+  assert torch.equal(dz.t, two_pass.t), name + ': fused LeakyReLU backward differs from the two-pass form'
+  assert_close(to_nchw(dz), zr.grad, RTOL[dtype], name + ' dgrad with fused LeakyReLU backward')
+  other = quantize_like(torch.randn(z.shape, generator=g), dtype)
+  oa = to_act(other, dtype)
+  dz2 = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False, relu_input=True, input_slope=0.2, addend=oa)
+  dx2 = layer.bwd(ctx, to_act(gy, dtype), need_dx=True, need_dw=False, addend=oa)
+  two_pass2 = ops.act_bwd(xa, dx2, ACT_LRELU, 0.2)
+  torch.cuda.synchronize()
+  assert torch.equal(dz2.t, two_pass2.t), name + ': fused addend + LeakyReLU backward differs from the two-pass form'
+  slope = torch.where(z > 0, torch.ones_like(z), torch.full_like(z, 0.2))
+  assert_close(to_nchw(dz2), zr.grad + other * slope, RTOL[dtype], name + ' dgrad + addend with fused LeakyReLU backward')
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('relu_a', [False, True])
 def test_l1_fwd_bwd_one_pass(dtype, relu_a):
