@@ -85,6 +85,54 @@ __global__ __launch_bounds__(256) void ring_fold_kernel(const RingFoldArgs a, lo
   Vec16<bf16_t>::store(dst, cur);
 }
 
+// The folded frame of dy for the one-launch reflect data gradient (gemm_halo.h, VIRT): per image 2 rows of W + 2 pixels
+// (above row 0 / below row H-1), then 2 columns of H pixels (left of column 0 / right of column W-1):
+//   row frame t, column b-1:  dy[r0][c] + dy[r1][c] with (r0, r1) = (0, 2) | (H-3, H-1); at b = 0 and b = W+1 the corner, summed
+//                             over the column pair (0, 2) | (W-3, W-1) as well
+//   column frame t, row h:    dy[h][c0] + dy[h][c1]
+// fp32 sums, rounded to bf16 once.  One thread = 8 channels of one frame pixel.
+__global__ __launch_bounds__(256) void ring_frame_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ V, int N, int H, int W,
+                                                         int Cs, long long total_vec) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total_vec) return;
+  const int cv = Cs >> 3;
+  const int c0 = (int)(t % cv) * 8;
+  long long q = t / cv;
+  const int per_n = 2 * (W + 2) + 2 * H;
+  const int n = (int)(q / per_n);
+  const int e = (int)(q - (long long)n * per_n);
+  int rows[2], cols[2], nr, nc;
+  if (e < 2 * (W + 2)) {
+    const int top = e < W + 2, b = top ? e : e - (W + 2);
+    rows[0] = top ? 0 : H - 3;
+    rows[1] = top ? 2 : H - 1;
+    nr = 2;
+    if (b == 0) { cols[0] = 0; cols[1] = 2; nc = 2; }
+    else if (b == W + 1) { cols[0] = W - 3; cols[1] = W - 1; nc = 2; }
+    else { cols[0] = b - 1; cols[1] = 0; nc = 1; }
+  } else {
+    const int f = e - 2 * (W + 2);
+    const int left = f < H;
+    rows[0] = left ? f : f - H;
+    rows[1] = 0;
+    nr = 1;
+    cols[0] = left ? 0 : W - 3;
+    cols[1] = left ? 2 : W - 1;
+    nc = 2;
+  }
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int r = 0; r < nr; ++r)
+    for (int c = 0; c < nc; ++c) {
+      float v[8];
+      Vec16<bf16_t>::load(dy + (((long long)n * H + rows[r]) * W + cols[c]) * Cs + c0, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+  Vec16<bf16_t>::store(V + ((long long)n * per_n + e) * Cs + c0, acc);
+}
+
 // dx = (dx + addend) * (mask > 0 ? 1 : slope), 16-byte vectors: the unfused form of the data-gradient epilogue
 // extras (either pointer may be null); the sum is rounded to T before the slope, as the fused epilogues do
 template <typename T>
@@ -255,6 +303,19 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.out_sw = p.Cs;
       h.act = JPDSE_ACT_NONE;
       h.addend = reinterpret_cast<const bf16_t*>(addend);
+      if (ring_halo && g_ring_virt && p.Ks >= 128) {
+        // one launch: the ring rides in the frame of dy (gemm_halo.h, VIRT); the mask, if any, in the same epilogue
+        bf16_t* frame = reinterpret_cast<bf16_t*>(wsb);
+        const long long fv = (long long)d->N * (2 * (d->W + 2) + 2 * d->H) * (p.Ks / 8);
+        const int pslot = (p.Cs == g_prof.Ks && 9LL * p.Ks == g_prof.kdim) ? prof_begin(s) : -1;
+        hipLaunchKernelGGL(ring_frame_kernel, dim3(ew_blocks(fv)), dim3(256), 0, s, h.X, frame, d->N, d->H, d->W, p.Ks, fv);
+        int rc = check_launch("ring_frame_kernel");
+        prof_end(pslot, 1, 0.0, s);
+        if (rc) return rc;
+        h.V = frame;
+        h.mask = reinterpret_cast<const bf16_t*>(mask);
+        return p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
+      }
       if (ring_halo)
         if (int rc = p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s)) return rc;
       // (2) the four ring strips of the reflect-padded domain as split-K GEMMs into fp32 slabs

@@ -150,6 +150,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_fast_enabled = enable != 0;
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_moments_fused = enable != 32 && enable != 6;   // 32: InstanceNorm moments always in their own pass (A/B); 6 keeps the generic kernels' rounding points
+  g_ring_virt = enable != 40 && enable != 6;   // 40: reflect ring as four split-K strip GEMMs + ring_fold_kernel instead of the folded frame (A/B); 6 keeps every product in fp32 until the fold
   g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
   g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
   g_taps9_enabled = enable != 38 && enable != 6;   // 38: 3x3 layers with 32-pixel-wide grids on the split-K fast kernel (A/B)
@@ -277,7 +278,9 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   size_t sk = p.splitk_off + p.splitk_bytes;
   if (p.ES == 2 && d->pad_mode == JPDSE_PAD_REFLECT && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1) {
     const size_t ring = (size_t)8 * d->N * (2 * (d->W + 2) + 2 * d->H) * p.Cs * 4;   // ring-strip slabs, <= 8 splits
+    const size_t frame = (size_t)d->N * (2 * (d->W + 2) + 2 * d->H) * p.Ks * 2;       // folded frame of dy (bf16)
     sk = sk > ring ? sk : ring;
+    sk = sk > frame ? sk : frame;
   }
   if (p.ES == 2 && d->R == 4 && d->S == 4 && d->stride == 1) {          // fringe slabs of the 4x4 tap-program path (forward / data gradient)
     const size_t f4 = taps4_fringe_bytes(d->N, p.OH, p.OW, p.Ks, 16 * p.Cs / 64);

@@ -250,6 +250,7 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
 }
 
 JPDSE_SWITCH(int, g_ring_enabled, 1);
+JPDSE_SWITCH(int, g_ring_virt, 1);        // 40: ring strips as four split-K GEMMs + ring_fold_kernel (the round-1..3 form) instead of the folded frame
 JPDSE_SWITCH(int, g_ring_small, 0);       // 31: ring strips on 128-row tiles, two blocks per CU (measured slower: 873 vs 955 TFLOP/s for the whole data gradient)
 JPDSE_SWITCH(int, g_merge_min_kt, 4);
 JPDSE_SWITCH(int, g_merge_min_tiles, 64);    // merged stride-phase data gradient on the fast kernel from this many 256-row tiles on (26: 384 as in round 1, A/B)
@@ -257,19 +258,22 @@ JPDSE_SWITCH(int, g_halo_single, 1);
 JPDSE_SWITCH(int, g_halo_enabled, 1);
 JPDSE_SWITCH(int, g_halo_abl, 0);
 
-template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false>
+template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false,
+          bool VIRT = false>
 static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   constexpr int BN = 2 * TN * 32;
   constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
   constexpr int lds = (SINGLE ? 1 : 2) * UH * 1024 + 3 * BN * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM, VIRT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
   }
   if (int rc = check_tile_grid("gemm_halo", a.N, a.OH, a.OW, 4, 64, a.Cs, (long long)a.N * a.IH * a.IW * a.Cs, (long long)a.N * a.OH * a.OW * a.Ks)) return rc;
+  if (VIRT && (a.V == nullptr || a.py != 1 || a.px != 1 || a.IH != a.OH || a.IW != a.OW || a.OH < 8 || a.reflect || a.Cs < 128))
+    return set_error(JPDSE_EINVAL, "gemm_halo: folded-frame form needs a frame, pad 1, equal grids, >= 8 rows, >= 128 channels");
   if (MOM && (a.mom == nullptr || a.mom_slots != (a.OH / 4) * (a.OW / 64)))
     return set_error(JPDSE_EINVAL, "gemm_halo: moment epilogue without a moment buffer of %d slots", (a.OH / 4) * (a.OW / 64));
   const int tiles = a.N * (a.OH / 4) * (a.OW / 64) * ((a.Ks + BN - 1) / BN);
@@ -278,7 +282,7 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM>), dim3(tiles), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM, VIRT>), dim3(tiles), dim3(512), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
@@ -296,6 +300,9 @@ template <int TN, int ABL = 0>
 static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
   HaloArgs a = a0;
   a.xcd_mode = g_halo_xcd;
+  if (a.V != nullptr) {                   // reflect data gradient with the folded frame
+    if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, false, false, false, true>(a, s);
+  }
   if (a.mom != nullptr) {                 // conv -> InstanceNorm with the moments in this kernel's epilogue (double-buffered form)
     if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, false, false, true>(a, s);
   }

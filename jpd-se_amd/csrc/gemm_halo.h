@@ -47,6 +47,7 @@ struct HaloArgs {
   const bf16_t* mask;   // optional fused ReLU backward (see FastArgs::mask)
   const bf16_t* addend; // optional: Y = result + addend
   int xcd_mode;         // 0: block b -> tile b; 1: blocks of one XCD (b % 8) take consecutive tiles; 2: 2 N-tiles x half the patches per XCD
+  const bf16_t* V;      // VIRT instantiation: the folded frame of the input (see ring_frame_kernel), [N][2(IW+2) + 2 IH][Cs]
   float* mom;           // optional (MOM instantiation): InstanceNorm moments of y, one (mean, M2) slot per block and channel
   int mom_slots;        //   [N][Ks][mom_slots][2], slot = the block's patch index inside its image (common.h; no bias / activation)
 };
@@ -60,7 +61,16 @@ struct HaloArgs {
 // MF16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 -- same LDS bytes and MFMA cycles per FLOP, but the chip holds
 // a higher clock on it (MI355X_MICROARCH.md, DVFS item 7).  The fragment rows are then 16 pixels x 4 k-chunks, which
 // needs the swizzle chunk ^ (row & 6) instead of chunk ^ ((row >> 1) & 7) to stay conflict-free at any tap shift.
-template <int TH, int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false>
+// VIRT: the data gradient of a REFLECT-padded 3x3 conv in one launch.  The adjoint of the padding adds the padded-domain
+// gradient of row -1 into row 1, of row H into row H-2 (columns alike).  Row -1 of that gradient is the u = 2 taps applied to dy
+// row 0 -- the same taps that output row 1 applies to dy row 2 -- so output row 1 reads, for those taps only, the FRAME row
+// dy[0] + dy[2] instead of dy[2] (bottom: output row H-2, taps u = 0, dy[H-3] + dy[H-1]; columns alike; the corner pixel holds
+// the four-term sum).  The frame (ring_frame_kernel, 2 (W + 2) + 2 H pixels per image) is loaded into the patch positions
+// that hold the zero padding otherwise; the reads that must still see that padding (output row 0 at u = 0, ...) go to a zero
+// pixel in the slack of the patch buffer.  Costs an add and a min per fragment address and tap; replaces the four ring-strip
+// GEMMs + ring_fold_kernel.  Needs py = px = 1, IH = OH, IW = OW, OH >= 8.
+template <int TH, int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false,
+          bool VIRT = false>
 __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   constexpr int R = 3, S = 3, TAPS = 9;
   constexpr int NW = 8, WN = 2;                       // waves: TH (=4) x 2
@@ -73,6 +83,8 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   constexpr int B_UNITS = BN / 8, BU = (B_UNITS + NW - 1) / NW;
   constexpr int HU = (UH + NW - 1) / NW;              // patch units per wave (7 for 50 units / 8 waves)
   static_assert(HU <= TAPS - 2, "patch units of the next slab are spread over taps 0..HU-1");
+  constexpr int PZ = UH * 8 - 1;                      // VIRT: the last slack pixel of a patch buffer is kept zero
+  static_assert(!VIRT || (PZ >= NP && !MF16 && !SINGLE && !MOM), "VIRT needs a slack pixel; written for the plain 32x32 form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo0 = smem;
   constexpr int NBUF = SINGLE ? 1 : 2;
@@ -117,6 +129,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     const int ug = on ? u : 0;
     int p = ug * 8 + lrow;
     const int swz_p = p;                              // the swizzle uses the LDS pixel index, also for clamped lanes
+    const bool slack = p >= NP;
     p = p < NP ? p : NP - 1;
     const int hr = p / PW, wc = p - hr * PW;
     int ih = ((ABL & 32) ? 0 : oh0) - a.py + hr, iw = ((ABL & 32) ? 0 : ow0) - a.px + wc;   // ABL 32: same patch
@@ -129,6 +142,15 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     }
     const int chunk = MF16 ? (lslot ^ (swz_p & 6)) : ((lslot ^ (swz_p >> 1)) & 7);
     h_off[i] = ok ? (((long long)((ABL & 32) ? 0 : n) * a.IH + ih) * a.IW + iw) * a.Cs + chunk * 8 : -1;
+    if constexpr (VIRT) {
+      // padding pixels come from the frame: rows [2][IW + 2] (column index iw + 1), then columns [2][IH]; slack pixels are zeros
+      if (!ok && !slack) {
+        const int fw = a.IW + 2;
+        const int fp = (ih < 0 || ih >= a.IH) ? (ih < 0 ? 0 : fw) + iw + 1 : 2 * fw + (iw < 0 ? 0 : a.IH) + ih;
+        h_off[i] = -2 - (((long long)n * (2 * fw + 2 * a.IH) + fp) * a.Cs + chunk * 8);
+      }
+      if (slack) h_off[i] = -1;
+    }
     h_lds[i] = ug * 1024;
   }
   // ---- weight tile DMA units
@@ -158,6 +180,20 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   int pb[FM];                                         // patch pixel of this lane's row for tap (0,0), per row block
 #pragma unroll
   for (int i = 0; i < FM; ++i) pb[i] = wm * PW + i * FR + (lane & (FR - 1));
+  // VIRT: column of the patch read by this lane's pixel for tap columns 0 and 2 (>= 1000: the zero pixel), per row block
+  int vc0[FM], vc2[FM];
+  bool v_top = false, v_bot = false;
+  if constexpr (VIRT) {
+    v_top = oh0 == 0;
+    v_bot = oh0 + TH == a.OH;
+    const bool left = ow0 == 0, right = ow0 + 64 == a.OW;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int w = i * FR + (lane & (FR - 1));
+      vc0[i] = (left && w == 0) ? 1000 : ((right && w == 62) ? 65 : w);
+      vc2[i] = (right && w == 63) ? 1000 : ((left && w == 1) ? 0 : w + 2);
+    }
+  }
   const int hsel = MF16 ? (lane >> 4) : (lane >> 5);  // k-chunk of this lane inside a k-step
   int b_rd[FN][KS];
 #pragma unroll
@@ -183,6 +219,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   auto issue_patch_unit = [&](int i, int slab) {      // i: compile-time after unrolling at the call sites
     char* const dst = halo0 + (slab & (NBUF - 1)) * HALO + h_lds[i];
     const bf16_t* src = h_off[i] >= 0 ? a.X + h_off[i] + slab * 64 : zero;
+    if constexpr (VIRT) src = h_off[i] < -1 ? a.V + (-2 - h_off[i]) + slab * 64 : src;
     glds16(src, dst);
   };
   auto issue_b = [&](int tile) {                      // tile = slab*9 + tap -> K offset tap*Cs + slab*64
@@ -244,9 +281,21 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     const char* const st = bring + tap_s * B_STAGE;    // tap % 3
     const int tapoff = tap_r * PW + tap_s;
     int a_base[FM], a_sw[FM];
+    int vrow = 0;
+    if constexpr (VIRT) {
+      // patch row read by this wave's image row for filter row tap_r: redirected to the frame row / the zero pixel at the edges
+      vrow = (wm + tap_r) * PW;
+      if (tap_r == 2) vrow = (v_top && wm == 1) ? 0 : ((v_bot && wm == 3) ? 1000 : vrow);
+      if (tap_r == 0) vrow = (v_bot && wm == 2) ? 5 * PW : ((v_top && wm == 0) ? 1000 : vrow);
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int pt = pb[i] + tapoff;
+      int pt = pb[i] + tapoff;
+      if constexpr (VIRT) {
+        const int col = tap_s == 0 ? vc0[i] : (tap_s == 2 ? vc2[i] : i * FR + (lane & (FR - 1)) + 1);
+        pt = vrow + col;
+        pt = pt < PZ ? pt : PZ;
+      }
       a_base[i] = pt << 7;
       a_sw[i] = MF16 ? (pt & 6) << 4 : ((pt >> 1) & 7) << 4;
     }
