@@ -86,6 +86,15 @@ template <> struct Vec16<float> {
     f32x4 t = {v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p) = t;
   }
+  // streaming forms (nontemporal hint): the last use of a tensor far larger than the caches
+  __device__ static __forceinline__ void load_nt(const float* p, float (&v)[4]) {
+    f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ static __forceinline__ void store_nt(float* p, const float (&v)[4]) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+  }
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
@@ -118,7 +127,20 @@ template <> struct Vec16<bf16_t> {
       t[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
     *reinterpret_cast<u32x4*>(p) = t;
   }
+  __device__ static __forceinline__ void load_nt(const bf16_t* p, float (&v)[8]) {
+    unpack(__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)), v);
+  }
+  __device__ static __forceinline__ void store_nt(bf16_t* p, const float (&v)[8]) {
+    __builtin_nontemporal_store(pack(v), reinterpret_cast<u32x4*>(p));
+  }
 };
+
+// last read of a large tensor in a streaming kernel (nontemporal hint; -DJPDSE_NO_NT builds the A/B variant without it)
+#ifndef JPDSE_NO_NT
+#define JPDSE_LOAD_LAST(T, ptr, v) Vec16<T>::load_nt(ptr, v)
+#else
+#define JPDSE_LOAD_LAST(T, ptr, v) Vec16<T>::load(ptr, v)
+#endif
 
 // ---- InstanceNorm moments written by conv epilogues (conv_rows.h, dgrad2_rows.h, thin_fwd.h -> norm.hip) ----------------
 // Every block writes, per (image, channel), ONE slot = (mean, M2) of the values it produced -- of the bf16-ROUNDED values,

@@ -99,10 +99,10 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
     const int n = (int)(t / OH);
     const T* p = x + (((long long)n * H + 2 * oh) * W + 2 * ow) * Cs + c * VE;
     float a[VE], b[VE], cc[VE], d[VE];
-    Vec16<T>::load(p, a);
-    Vec16<T>::load(p + Cs, b);
-    Vec16<T>::load(p + (long long)W * Cs, cc);
-    Vec16<T>::load(p + (long long)W * Cs + Cs, d);
+    JPDSE_LOAD_LAST(T, p, a);
+    JPDSE_LOAD_LAST(T, p + Cs, b);
+    JPDSE_LOAD_LAST(T, p + (long long)W * Cs, cc);
+    JPDSE_LOAD_LAST(T, p + (long long)W * Cs + Cs, d);
 #pragma unroll
     for (int e = 0; e < VE; ++e) a[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(cc[e], d[e]));
     Vec16<T>::store(y + idx * VE, a);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const T* __restrict__
     GRID_STRIDE(idx, total) {
       float x[VE], y[VE];
       Vec16<T>::load(a + idx * VE, x);
-      Vec16<T>::load(b + idx * VE, y);
+      JPDSE_LOAD_LAST(T, b + idx * VE, y);
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
         const float d = x[e] - y[e];
@@ -534,10 +534,17 @@ __global__ __launch_bounds__(256) void adam_kernel(const jpdse_adam_entry* __res
   if (base >= e.n) return;
   if (base + 4 <= e.n && (((uintptr_t)(e.p + base) | (uintptr_t)(e.g + base) | (uintptr_t)(e.m + base) |
                            (uintptr_t)(e.v + base)) & 15) == 0) {
+#ifndef JPDSE_NO_NT   // 2.2 GB of optimizer state streamed once per step: nontemporal (5.26 -> 5.67 TB/s, profiles/r03_nontemporal_ab.txt)
+    f32x4 p = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e.p + base));
+    f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e.g + base));
+    f32x4 m = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e.m + base));
+    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e.v + base));
+#else
     f32x4 p = *reinterpret_cast<const f32x4*>(e.p + base);
     f32x4 g = *reinterpret_cast<const f32x4*>(e.g + base);
     f32x4 m = *reinterpret_cast<const f32x4*>(e.m + base);
     f32x4 v = *reinterpret_cast<const f32x4*>(e.v + base);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float gi = g[i] * grad_scale;
@@ -545,9 +552,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const jpdse_adam_entry* __res
       v[i] = beta2 * v[i] + (1.f - beta2) * gi * gi;
       p[i] -= lr_over_bc1 * m[i] / (sqrtf(v[i]) * inv_sqrt_bc2 + eps);
     }
+#ifndef JPDSE_NO_NT
+    __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(e.p + base));
+    __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(e.m + base));
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(e.v + base));
+#else
     *reinterpret_cast<f32x4*>(e.p + base) = p;
     *reinterpret_cast<f32x4*>(e.m + base) = m;
     *reinterpret_cast<f32x4*>(e.v + base) = v;
+#endif
     if (e.cast_bf16 != nullptr) {
       uint32_t w0 = (uint32_t)f2bf(p[0]) | ((uint32_t)f2bf(p[1]) << 16);
       uint32_t w1 = (uint32_t)f2bf(p[2]) | ((uint32_t)f2bf(p[3]) << 16);

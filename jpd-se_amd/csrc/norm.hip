@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void inorm_apply_fwd_kernel(const T* __restric
   for (int p = p0 + ty; p < p1; p += g.TY) {
     const long long off = base + (long long)p * g.Cs;
     float v[VE], r[VE];
-    Vec16<T>::load(x + off, v);
+    JPDSE_LOAD_LAST(T, x + off, v);
     if (res != nullptr) Vec16<T>::load(res + off, r);
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void inorm_apply_bwd_kernel(const T* __restric
   for (int p = p0 + ty; p < p1; p += g.TY) {
     const long long off = base + (long long)p * g.Cs;
     float v[VE], gr[VE];
-    Vec16<T>::load(x + off, v);
-    Vec16<T>::load(dy + off, gr);
+    JPDSE_LOAD_LAST(T, x + off, v);
+    JPDSE_LOAD_LAST(T, dy + off, gr);
 #pragma unroll
     for (int e = 0; e < VE; ++e) {
       const float yh = (v[e] - mean[e]) * rstd[e];

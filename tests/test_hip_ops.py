@@ -96,6 +96,11 @@ CONV_CASES = [
     # reflect data gradient = halo kernel on the interior + ring strips (split-K) folded back
     ('ring_dgrad_64',  2, 8,  64,  64,  128, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
     ('ring_dgrad_192', 1, 12, 128, 192, 64,  3, 1, 1,  PAD_REFLECT, ACT_NONE),
+    # one-launch form (gemm_halo.h VIRT: the ring rides in the folded frame of dy; >= 128 output channels): two column tiles
+    # (left / right edge in different blocks) + interior row tiles + ragged channel tile; a tall single-column image; minimal height
+    ('ring_frame_w128', 2, 16, 128, 192, 128, 3, 1, 1, PAD_REFLECT, ACT_NONE),
+    ('ring_frame_tall', 1, 24, 64,  128, 256, 3, 1, 1, PAD_REFLECT, ACT_NONE),
+    ('ring_frame_h8',   3, 8,  192, 64,  192, 3, 1, 1, PAD_REFLECT, ACT_NONE),
     # all-taps weight gradient (wgrad_taps.h), one case per configuration; ragged 64-pixel chunks, several blocks per tile
     ('taps_3x3s2',     2, 40, 150, 64,  128, 3, 2, 1,  PAD_ZERO,    ACT_NONE),
     ('taps_3x3s1_refl', 2, 36, 100, 64, 64,  3, 1, 1,  PAD_REFLECT, ACT_NONE),
@@ -230,6 +235,7 @@ FUSED_RELU_CASES = [
     ('splitk',        1, 10, 24, 256, 256, 3, 1, 1, PAD_ZERO),
     ('generic_small', 2, 9,  11, 16,  24,  3, 1, 1, PAD_ZERO),
     ('reflect',       1, 12, 20, 64,  64,  3, 1, 1, PAD_REFLECT),
+    ('ring_frame',    2, 12, 128, 128, 128, 3, 1, 1, PAD_REFLECT),  # folded-frame halo kernel: addend / mask in its epilogue
     # tap-program kernel epilogues (gemm_taps.h): 4x4 stride 1 (core + split-K fringe: the finish kernel applies the operands
     # there) and the two-set stride-2 data gradient
     ('taps4_fused',   2, 17, 33, 128, 256, 4, 1, 2, PAD_ZERO),
