@@ -329,8 +329,8 @@ def main():
       f_all = fl.value + extra['wgrad'][1]
       ach = f_all / (t_all * 1e-3) / 1e12
       wg = extra['wgrad']
-      roof_all = dict(bound='mfma', kernel='ResnetBlock 3x3 conv, all passes: gemm_halo_kernel (fwd, dgrad) + ring strips / fold '
-                                          '(gemm_fast_kernel, ring_fold_kernel) + wgrad_nine_kernel',
+      roof_all = dict(bound='mfma', kernel='ResnetBlock 3x3 conv, all passes: gemm_halo_kernel (fwd, dgrad over the folded frame) + '
+                                          'ring_frame_kernel (the "ring" time) + wgrad_nine_kernel',
                       achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
                       ms_per_step=dict(fwd_dgrad=round(ms.value / tsteps, 4), ring=round(extra['ring'][0] / tsteps, 4),
                                        wgrad=round(wg[0] / tsteps, 4)),

@@ -62,7 +62,7 @@ int jpdse_arch_check(int device);
 int jpdse_prof_select(int32_t enable, int32_t Ks, int64_t kdim, int32_t max_launches);
 int jpdse_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
 /* The same sums for the other regions of the selected layer, WITHOUT resetting the log (call before jpdse_prof_collect):
- * cls 1 = the ring-strip GEMMs + fold of the reflect-padded data gradient (time only, their FLOPs belong to the data
+ * cls 1 = the reflect ring of the data gradient -- ring_frame_kernel, or the strip GEMMs + fold (time only, their FLOPs belong to the data
  * gradient counted in class 0), cls 2 = the weight-gradient launches (K == Ks, 9 * CPAD(C) == kdim). */
 int jpdse_prof_collect_class(int32_t cls, double* total_ms, double* total_flops, int64_t* launches);
 /* The same for the HBM-bound calls (bench.py "roofline_hbm"; north_star: "HBM GB/s on the norm/activation kernels"): after

@@ -706,7 +706,8 @@ __global__ __launch_bounds__(256) void pack_dgrad_tile_many_kernel(const jpdse_p
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           pk[j] = (uint32_t)f2bf(tile[kq + 2 * j][cc]) | ((uint32_t)f2bf(tile[kq + 2 * j + 1][cc]) << 16);
-        *reinterpret_cast<u32x4*>(out + ((long long)c * e.Uh + up) * e.Lk + wp * e.Ks + k) = pk;
+        // next read in the NEXT step's backward: nontemporal
+        __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(out + ((long long)c * e.Uh + up) * e.Lk + wp * e.Ks + k));
       }
     }
     return;

@@ -565,8 +565,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const jpdse_adam_entry* __res
       uint32_t w0 = (uint32_t)f2bf(p[0]) | ((uint32_t)f2bf(p[1]) << 16);
       uint32_t w1 = (uint32_t)f2bf(p[2]) | ((uint32_t)f2bf(p[3]) << 16);
       uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(e.cast_bf16) + base);
-      out[0] = w0;
-      out[1] = w1;
+      __builtin_nontemporal_store(w0, out);         // the forward panel: next read in the next step
+      __builtin_nontemporal_store(w1, out + 1);
     }
   } else {
     for (long long i = base; i < base + 4 && i < e.n; ++i) {
