@@ -500,6 +500,30 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       return launch_taps4(v, ws, s);
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    // one output channel (PatchGAN 512 -> 1): dx is written once by an FMA kernel (thin_out1.h)
+    if (thin1_shape_ok(d, p.Cs, p.Ks) && p.nph == 1 && mask == nullptr && mom == nullptr && p.ph[0].Uh == 4 && p.ph[0].Uw == 4 &&
+        p.ph[0].cnth == d->H && p.ph[0].cntw == d->W) {
+      const Phase& f = p.ph[0];
+      Thin1DgradArgs t = {};
+      t.DY = reinterpret_cast<const bf16_t*>(dy);
+      t.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
+      t.taps = reinterpret_cast<float*>(wsb);        // 16 x Cs floats: inside the padded-dy region of every plan
+      t.DX = reinterpret_cast<bf16_t*>(dx);
+      t.addend = reinterpret_cast<const bf16_t*>(addend);
+      t.N = d->N;
+      t.H = d->H;
+      t.W = d->W;
+      t.Cs = p.Cs;
+      t.OH = p.OH;
+      t.OW = p.OW;
+      t.py = (f.Uh - 1) - f.i0h;
+      t.px = (f.Uw - 1) - f.i0w;
+      t.Lk = f.Lk;
+      t.b_stride = (long long)f.Uh * f.Lk;
+      return launch_thin1_dgrad(t, s);
+    }
+  }
   bool fast = false;
   int nlive_phases = 0;
   if constexpr (sizeof(T) == 2) {

@@ -357,6 +357,25 @@ static int conv_wgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
   const bool dry = slab_bytes_out != nullptr;
   if (dry) *slab_bytes_out = 0;
   if constexpr (sizeof(T) == 2) {
+    if (thin1_shape_ok(d, p.Cs, p.Ks)) {
+      // one output channel (PatchGAN 512 -> 1): x read once by an FMA kernel, no copies (thin_out1.h)
+      if (dry) {
+        *slab_bytes_out = thin1_wgrad_slab_bytes(d->N, d->H, d->W, p.Cs);
+        return JPDSE_OK;
+      }
+      Thin1WgradArgs t = {};
+      t.X = reinterpret_cast<const bf16_t*>(x);
+      t.DY = reinterpret_cast<const bf16_t*>(dy);
+      t.partial = slabs;
+      t.N = d->N;
+      t.H = d->H;
+      t.W = d->W;
+      t.Cs = p.Cs;
+      t.OH = p.OH;
+      t.OW = p.OW;
+      t.pad = d->pad;
+      return launch_thin1_wgrad(t, dw, s);
+    }
     const int kexp = d->K * d->R * d->S, kexp_s = round_up(kexp, 64);
     if (g_fast_enabled && !wgrad_head_ok(d, p) && p.Ks == 8 && d->stride == 1 && p.Cs % 64 == 0 && kexp_s <= 256) {
       // few output channels: dense 1x1 weight gradient over the tap-expanded dy (see expand_dy_taps_kernel)

@@ -94,6 +94,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "conv_generic.h"
 #include "conv_plan.h"
 #include "conv_launch.h"
+#include "thin_out1.h"
 #include "conv_dispatch_fwd.h"
 #include "conv_dispatch_dgrad.h"
 #include "conv_dispatch_wgrad.h"
@@ -151,6 +152,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_halo_enabled = enable != 3;      // 3: fast kernels but no halo kernel (A/B)
   g_moments_fused = enable != 32 && enable != 6;   // 32: InstanceNorm moments always in their own pass (A/B); 6 keeps the generic kernels' rounding points
   g_ring_virt = enable != 40 && enable != 6;   // 40: reflect ring as four split-K strip GEMMs + ring_fold_kernel instead of the folded frame (A/B); 6 keeps every product in fp32 until the fold
+  g_thin1_enabled = enable != 41 && enable != 6;   // 41: the one-output-channel layers (PatchGAN 512 -> 1) backward on the GEMM paths (A/B)
   g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
   g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
   g_taps9_enabled = enable != 38 && enable != 6;   // 38: 3x3 layers with 32-pixel-wide grids on the split-K fast kernel (A/B)
@@ -274,7 +276,8 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
   if (d->dtype == JPDSE_BF16) (void)conv_wgrad_t<bf16_t>(d, p, nullptr, nullptr, nullptr, nullptr, nullptr, &slab_bytes);
   else (void)conv_wgrad_t<float>(d, p, nullptr, nullptr, nullptr, nullptr, nullptr, &slab_bytes);
   const size_t fwd = wgrad_front_bytes(d, p) + slab_bytes;
-  const size_t dgrad = p.dypad_bytes + p.dxp_bytes;
+  size_t dgrad = p.dypad_bytes + p.dxp_bytes;
+  if (thin1_shape_ok(d, p.Cs, p.Ks) && dgrad < (size_t)16 * p.Cs * sizeof(float)) dgrad = (size_t)16 * p.Cs * sizeof(float);   // tap table of thin1_dgrad_kernel
   size_t sk = p.splitk_off + p.splitk_bytes;
   if (p.ES == 2 && d->pad_mode == JPDSE_PAD_REFLECT && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1) {
     const size_t ring = (size_t)8 * d->N * (2 * (d->W + 2) + 2 * d->H) * p.Cs * 4;   // ring-strip slabs, <= 8 splits

@@ -55,6 +55,10 @@ CONV_CASES = [
     ('d_layer2',      2, 9,  13, 128,  256, 4, 2,  2,  PAD_ZERO,    ACT_NONE),
     ('d_layer3_s1',   1, 5,  9,  256,  512, 4, 1,  2,  PAD_ZERO,    ACT_NONE),
     ('d_layer4_1ch',  2, 6,  10, 512,  1,   4, 1,  2,  PAD_ZERO,    ACT_NONE),
+    # one-output-channel backward kernels (thin_out1.h): two / three row segments, several items per strip, 128..1024 channels
+    ('d_layer4_wide', 2, 9,  130, 512, 1,   4, 1,  2,  PAD_ZERO,    ACT_NONE),
+    ('d_layer4_3seg', 3, 5,  300, 128, 1,   4, 1,  2,  PAD_ZERO,    ACT_NONE),
+    ('d_layer4_1k',   1, 40, 33, 1024, 1,   4, 1,  2,  PAD_ZERO,    ACT_NONE),
     ('vgg_conv1_1',   1, 16, 24, 3,    64,  3, 1,  1,  PAD_ZERO,    ACT_RELU),
     ('vgg_conv3',     1, 8,  12, 128,  256, 3, 1,  1,  PAD_ZERO,    ACT_RELU),
     ('local_32ch',    1, 14, 22, 39,   32,  7, 1,  3,  PAD_REFLECT, ACT_NONE),
@@ -235,6 +239,7 @@ FUSED_RELU_CASES = [
     ('splitk',        1, 10, 24, 256, 256, 3, 1, 1, PAD_ZERO),
     ('generic_small', 2, 9,  11, 16,  24,  3, 1, 1, PAD_ZERO),
     ('reflect',       1, 12, 20, 64,  64,  3, 1, 1, PAD_REFLECT),
+    ('thin1_fused',   2, 7,  70,  256, 1,   4, 1, 2, PAD_ZERO),      # one output channel: the addend rides in thin1_dgrad_kernel
     ('ring_frame',    2, 12, 128, 128, 128, 3, 1, 1, PAD_REFLECT),  # folded-frame halo kernel: addend / mask in its epilogue
     # tap-program kernel epilogues (gemm_taps.h): 4x4 stride 1 (core + split-K fringe: the finish kernel applies the operands
     # there) and the two-set stride-2 data gradient
