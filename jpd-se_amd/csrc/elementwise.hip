@@ -202,7 +202,18 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
     const long long p0 = pb * pix_per_blk;
     long long p1 = p0 + pix_per_blk;
     p1 = p1 < npix ? p1 : npix;
-    for (long long p = p0 + ty; p < p1; p += TY) {
+    long long p = p0 + ty;
+    // four loads in flight per thread (one per iteration ran at 1.6 TB/s); the sum order stays p ascending
+    for (; p + 3LL * TY < p1; p += 4LL * TY) {
+      float v[4][VE];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Vec16<T>::load(dy + (p + (long long)u * TY) * Cs + col * VE, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[e] += v[u][e];
+    }
+    for (; p < p1; p += TY) {
       float v[VE];
       Vec16<T>::load(dy + p * Cs + col * VE, v);
 #pragma unroll
