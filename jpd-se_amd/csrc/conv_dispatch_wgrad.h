@@ -206,8 +206,12 @@ static int launch_wgrad_taps_cfg(const TapsWgArgs& a, int lds, hipStream_t s) {
   hipLaunchKernelGGL((wgrad_taps_kernel<TMW, WM, WN, S, NROW, ST>), dim3(blocks), dim3(64 * WM * WN), lds, s, a);
   if (int rc = check_launch("wgrad_taps_kernel")) return rc;
   const long long total = (long long)a.K * a.R * a.S * a.C;
-  hipLaunchKernelGGL((wgrad_taps_reduce_kernel<BM, BN, S, NROW>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s,
-                     a, total);
+  if (a.C % 4 == 0 && (reinterpret_cast<uintptr_t>(a.DW) & 15) == 0)
+    hipLaunchKernelGGL((wgrad_taps_reduce_kernel<BM, BN, S, NROW, 4>), dim3((unsigned)((total / 4 + 63) / 64)), dim3(256), 0, s,
+                       a, total / 4);
+  else
+    hipLaunchKernelGGL((wgrad_taps_reduce_kernel<BM, BN, S, NROW, 1>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s,
+                       a, total);
   return check_launch("wgrad_taps_reduce_kernel");
 }
 

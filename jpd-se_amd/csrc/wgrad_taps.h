@@ -204,17 +204,20 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_taps_kernel(const TapsWgAr
 }
 
 // dW[k][r][s][c] = sum over the blocks of the owning tile, fixed order.  256 threads = 64 consecutive
-// elements x 4 slab groups; each thread keeps 8 independent loads in flight (a serial loop over 256-512
+// elements (VEC = 1) or 16-byte vectors along c (VEC = 4: C % 4 == 0; the slabs are ~50 MB per launch and 4-byte loads
+// read them at 1.9 TB/s) x 4 slab groups; each thread keeps 8 independent loads in flight (a serial loop over 256-512
 // slabs per element was latency-bound: ~100 us), the groups are combined through LDS.
-template <int BM, int BN, int S, int NROW>
-__global__ __launch_bounds__(256) void wgrad_taps_reduce_kernel(const TapsWgArgs a, long long total) {
+template <int BM, int BN, int S, int NROW, int VEC>
+__global__ __launch_bounds__(256) void wgrad_taps_reduce_kernel(const TapsWgArgs a, long long total_vec) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
   constexpr int T = NROW * S;
   constexpr long long SLAB = (long long)T * BM * BN;
-  __shared__ float red[4][64];
+  __shared__ vec_t red[4][64];
   const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long long idx = (long long)blockIdx.x * 64 + el;
-  float sum = 0.f;
-  if (idx < total) {
+  const long long vidx = (long long)blockIdx.x * 64 + el;
+  vec_t sum = {};
+  if (vidx < total_vec) {
+    const long long idx = vidx * VEC;
     const int c = (int)(idx % a.C);
     long long t1 = idx / a.C;
     const int s = (int)(t1 % a.S);
@@ -231,17 +234,18 @@ __global__ __launch_bounds__(256) void wgrad_taps_reduce_kernel(const TapsWgArgs
     b1 = b1 < a.blocks_per_tile ? b1 : a.blocks_per_tile;
     int b = b0;
     for (; b + 8 <= b1; b += 8) {
-      float v[8];
+      vec_t v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(long long)(b + u) * SLAB];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec_t*>(src + (long long)(b + u) * SLAB);
 #pragma unroll
       for (int u = 0; u < 8; ++u) sum += v[u];
     }
-    for (; b < b1; ++b) sum += src[(long long)b * SLAB];
+    for (; b < b1; ++b) sum += *reinterpret_cast<const vec_t*>(src + (long long)b * SLAB);
   }
   red[grp][el] = sum;
   __syncthreads();
-  if (grp == 0 && idx < total) a.DW[idx] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+  if (grp == 0 && vidx < total_vec)
+    *reinterpret_cast<vec_t*>(a.DW + vidx * VEC) = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
 }  // namespace jpdse
