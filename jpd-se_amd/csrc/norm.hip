@@ -44,6 +44,10 @@ static MomentGeom moment_geom(int N, int HW, int Cs, int VE) {
   return g;
 }
 
+#ifndef JPDSE_NORM_ILP
+#define JPDSE_NORM_ILP 2      // pixels per thread and loop trip of the streaming norm kernels (bytes in flight; A/B with -DJPDSE_NORM_ILP=1)
+#endif
+
 // ---- per-element functors -----------------------------------------------------------------
 // forward moments: (x - shift), (x - shift)^2 with shift = x[n, pixel 0, c]
 template <typename T> struct FwdMoments {
@@ -54,15 +58,18 @@ template <typename T> struct FwdMoments {
 #pragma unroll
     for (int e = 0; e < Vec16<T>::N; ++e) aux[e] = v[e];
   }
-  __device__ __forceinline__ void at(long long off, int, const float (&aux)[8], float (&s1)[8], float (&s2)[8]) const {
-    float v[Vec16<T>::N];
-    Vec16<T>::load(x + off, v);
+  __device__ __forceinline__ void acc(const float (&v)[Vec16<T>::N], const float (&aux)[8], float (&s1)[8], float (&s2)[8]) const {
 #pragma unroll
     for (int e = 0; e < Vec16<T>::N; ++e) {
       const float d = v[e] - aux[e];
       s1[e] += d;
       s2[e] += d * d;
     }
+  }
+  __device__ __forceinline__ void at(long long off, int, const float (&aux)[8], float (&s1)[8], float (&s2)[8]) const {
+    float v[Vec16<T>::N];
+    Vec16<T>::load(x + off, v);
+    acc(v, aux, s1, s2);
   }
 };
 
@@ -79,6 +86,16 @@ template <typename T> struct BwdMoments {
   const float* stats;  // [N][Cs][2]
   int act;
   float slope;
+  __device__ __forceinline__ void acc2(const float (&v)[Vec16<T>::N], const float (&g)[Vec16<T>::N], const float (&mean)[Vec16<T>::N],
+                                       const float (&rstd)[Vec16<T>::N], float (&s1)[8], float (&s2)[8]) const {
+#pragma unroll
+    for (int e = 0; e < Vec16<T>::N; ++e) {
+      const float yh = (v[e] - mean[e]) * rstd[e];
+      const float dz = g[e] * act_grad(yh, act, slope);
+      s1[e] += dz;
+      s2[e] += dz * yh;
+    }
+  }
   // aux packs mean[e] in [0..VE) -- rstd kept separately
   __device__ __forceinline__ void at2(long long off, int n, int Cs, int c0, float (&s1)[8], float (&s2)[8]) const {
     float v[Vec16<T>::N], g[Vec16<T>::N];
@@ -121,10 +138,42 @@ __global__ __launch_bounds__(256) void moment_kernel(const T* __restrict__ x, co
     if (!BWD) {
       FwdMoments<T> f{x};
       f.prep(n, g.HW, g.Cs, c0, aux);
-      for (int p = p0 + ty; p < p1; p += g.TY) f.at(base + (long long)p * g.Cs, 0, aux, s1, s2);
+      // JPDSE_NORM_ILP pixels per trip, all loads issued before the first use (same summation order: p ascending)
+      int p = p0 + ty;
+      for (; p + (JPDSE_NORM_ILP - 1) * g.TY < p1; p += JPDSE_NORM_ILP * g.TY) {
+        float v[JPDSE_NORM_ILP][VE];
+#pragma unroll
+        for (int u = 0; u < JPDSE_NORM_ILP; ++u) Vec16<T>::load(x + base + (long long)(p + u * g.TY) * g.Cs, v[u]);
+#pragma unroll
+        for (int u = 0; u < JPDSE_NORM_ILP; ++u) f.acc(v[u], aux, s1, s2);
+      }
+      for (; p < p1; p += g.TY) f.at(base + (long long)p * g.Cs, 0, aux, s1, s2);
     } else {
       BwdMoments<T> f{x, dy, stats, act, slope};
-      for (int p = p0 + ty; p < p1; p += g.TY) f.at2(base + (long long)p * g.Cs, n, g.Cs, c0, s1, s2);
+      float mean[VE], rstd[VE];
+      {
+        const float* st = stats + ((long long)n * g.Cs + c0) * 2;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { mean[e] = st[2 * e]; rstd[e] = st[2 * e + 1]; }
+      }
+      int p = p0 + ty;
+      for (; p + (JPDSE_NORM_ILP - 1) * g.TY < p1; p += JPDSE_NORM_ILP * g.TY) {
+        float v[JPDSE_NORM_ILP][VE], gr[JPDSE_NORM_ILP][VE];
+#pragma unroll
+        for (int u = 0; u < JPDSE_NORM_ILP; ++u) {
+          const long long off = base + (long long)(p + u * g.TY) * g.Cs;
+          Vec16<T>::load(x + off, v[u]);
+          Vec16<T>::load(dy + off, gr[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < JPDSE_NORM_ILP; ++u) f.acc2(v[u], gr[u], mean, rstd, s1, s2);
+      }
+      for (; p < p1; p += g.TY) {
+        float v[VE], gr[VE];
+        Vec16<T>::load(x + base + (long long)p * g.Cs, v);
+        Vec16<T>::load(dy + base + (long long)p * g.Cs, gr);
+        f.acc2(v, gr, mean, rstd, s1, s2);
+      }
     }
   }
 #pragma unroll
@@ -240,20 +289,32 @@ __global__ __launch_bounds__(256) void inorm_apply_fwd_kernel(const T* __restric
   int p1 = p0 + g.pix_per_split;
   p1 = p1 < g.HW ? p1 : g.HW;
   const long long base = (long long)n * g.HW * g.Cs + c0;
-  for (int p = p0 + ty; p < p1; p += g.TY) {
-    const long long off = base + (long long)p * g.Cs;
-    float v[VE], r[VE];
-    JPDSE_LOAD_LAST(T, x + off, v);
-    if (res != nullptr) Vec16<T>::load(res + off, r);
+  // JPDSE_NORM_ILP pixels per trip: their loads are issued before the first store
+  for (int p = p0 + ty; p < p1; p += JPDSE_NORM_ILP * g.TY) {
+    float v[JPDSE_NORM_ILP][VE], r[JPDSE_NORM_ILP][VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      float t = (v[e] - mean[e]) * rstd[e];
-      if (act == JPDSE_ACT_RELU) t = t > 0.f ? t : 0.f;
-      else if (act == JPDSE_ACT_LRELU) t = t > 0.f ? t : t * slope;
-      if (res != nullptr) t += r[e];
-      v[e] = t;
+    for (int u = 0; u < JPDSE_NORM_ILP; ++u) {
+      const int pu = p + u * g.TY;
+      if (pu < p1) {
+        const long long off = base + (long long)pu * g.Cs;
+        JPDSE_LOAD_LAST(T, x + off, v[u]);
+        if (res != nullptr) Vec16<T>::load(res + off, r[u]);
+      }
     }
-    Vec16<T>::store(y + off, v);
+#pragma unroll
+    for (int u = 0; u < JPDSE_NORM_ILP; ++u) {
+      const int pu = p + u * g.TY;
+      if (pu >= p1) break;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        float t = (v[u][e] - mean[e]) * rstd[e];
+        if (act == JPDSE_ACT_RELU) t = t > 0.f ? t : 0.f;
+        else if (act == JPDSE_ACT_LRELU) t = t > 0.f ? t : t * slope;
+        if (res != nullptr) t += r[u][e];
+        v[u][e] = t;
+      }
+      Vec16<T>::store(y + base + (long long)pu * g.Cs, v[u]);
+    }
   }
 }
 
@@ -284,18 +345,29 @@ __global__ __launch_bounds__(256) void inorm_apply_bwd_kernel(const T* __restric
   int p1 = p0 + g.pix_per_split;
   p1 = p1 < g.HW ? p1 : g.HW;
   const long long base = (long long)n * g.HW * g.Cs + c0;
-  for (int p = p0 + ty; p < p1; p += g.TY) {
-    const long long off = base + (long long)p * g.Cs;
-    float v[VE], gr[VE];
-    JPDSE_LOAD_LAST(T, x + off, v);
-    JPDSE_LOAD_LAST(T, dy + off, gr);
+  for (int p = p0 + ty; p < p1; p += JPDSE_NORM_ILP * g.TY) {
+    float v[JPDSE_NORM_ILP][VE], gr[JPDSE_NORM_ILP][VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      const float yh = (v[e] - mean[e]) * rstd[e];
-      const float dz = gr[e] * act_grad(yh, act, slope);
-      v[e] = rstd[e] * (dz - s1[e] - yh * s2[e]);
+    for (int u = 0; u < JPDSE_NORM_ILP; ++u) {
+      const int pu = p + u * g.TY;
+      if (pu < p1) {
+        const long long off = base + (long long)pu * g.Cs;
+        JPDSE_LOAD_LAST(T, x + off, v[u]);
+        JPDSE_LOAD_LAST(T, dy + off, gr[u]);
+      }
     }
-    Vec16<T>::store(dx + off, v);
+#pragma unroll
+    for (int u = 0; u < JPDSE_NORM_ILP; ++u) {
+      const int pu = p + u * g.TY;
+      if (pu >= p1) break;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float yh = (v[u][e] - mean[e]) * rstd[e];
+        const float dz = gr[u][e] * act_grad(yh, act, slope);
+        v[u][e] = rstd[e] * (dz - s1[e] - yh * s2[e]);
+      }
+      Vec16<T>::store(dx + base + (long long)pu * g.Cs, v[u]);
+    }
   }
 }
 
