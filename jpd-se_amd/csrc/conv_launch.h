@@ -519,31 +519,60 @@ static int launch_thin_in_rows(ThinInArgs a, hipStream_t s) {
 // ---- tap-program halo kernel (gemm_taps.h): all four sub-pixel phases of a stride-2 data gradient / ConvTranspose forward
 JPDSE_SWITCH(int, g_taps_enabled, 1);       // 35: these layers on the merged-phase fast kernel (A/B)
 
-// 3x3 stride-2 (pad 1, even input): phases (0,0) 2x2 taps, (0,1) 2x1, (1,0) 1x2, (1,1) 1x1 over the same dy pixels
-static bool taps_dgrad2_ok(const jpdse_conv_desc* d, const ConvPlan& p, const void* mask, const void* addend, const float* mom) {
+// Stride-2 data gradients on the tap-program kernel.  3x3 (pad 1, even input): phases (0,0) 2x2 taps, (0,1) 2x1, (1,0) 1x2,
+// (1,1) 1x1 over the same dy pixels.  4x4 (pad 2: the PatchGAN layers 1-2, networks.py:430-436): 2x2 taps in every phase; their
+// inputs have 2^k + 1 rows / columns, so the phases differ by one row / column: the kernel covers the CORE every phase has
+// (a multiple of 4 x 64 sub-pixels), the one-row / one-column FRINGE of the longer phases runs as sub-rectangle problems of the
+// fast kernel behind it (fused operands in its epilogue).
+JPDSE_SWITCH(int, g_taps_dgrad4_enabled, 1);     // 42: the 4x4 stride-2 data gradients on the merged-phase fast kernel (A/B)
+JPDSE_SWITCH(int, g_taps_dgrad4_min_tiles, 512); // 43: no lower bound on the core tile count (tests reach the path with small shapes)
+struct TapsDgrad2Geom { int core_h, core_w, fringe, taps4; };
+static bool taps_dgrad2_geom(const jpdse_conv_desc* d, const ConvPlan& p, const void* mask, const void* addend, const float* mom,
+                             TapsDgrad2Geom* g) {
   if (!(g_fast_enabled && g_taps_enabled) || d->dtype != JPDSE_BF16 || d->pad_mode == JPDSE_PAD_REFLECT) return false;
-  if (d->stride != 2 || d->R != 3 || d->S != 3 || d->pad != 1 || p.nph != 4) return false;
+  const bool k3 = d->R == 3 && d->S == 3 && d->pad == 1, k4 = d->R == 4 && d->S == 4 && d->pad == 2 && g_taps_dgrad4_enabled;
+  if (d->stride != 2 || !(k3 || k4) || p.nph != 4) return false;
   if (mom != nullptr) return false;
-  if (d->H != 2 * p.OH || d->W != 2 * p.OW || p.OH % 4 != 0 || p.OW % 64 != 0) return false;
   if (p.Ks % 64 != 0 || p.Ks < 128 || p.Cs % 64 != 0) return false;
   // the kernel's loaders carry 32-bit element offsets into dy and into each phase's panel
   if ((long long)d->N * p.OH * p.OW * p.Ks >= (1LL << 31) || (long long)p.Cs * 4 * p.Ks >= (1LL << 31)) return false;
+  int min_h = 1 << 30, min_w = 1 << 30, fringe = 0;
   for (int i = 0; i < 4; ++i) {
     const Phase& f = p.ph[i];
-    if (f.cnth != p.OH || f.cntw != p.OW || f.Lk != f.Uw * p.Ks) return false;
-    if (f.Uh != (f.qh == 0 ? 2 : 1) || f.Uw != (f.qw == 0 ? 2 : 1)) return false;
+    if (f.Lk != f.Uw * p.Ks) return false;
+    if (k3 && (f.Uh != (f.qh == 0 ? 2 : 1) || f.Uw != (f.qw == 0 ? 2 : 1))) return false;
+    if (k4 && (f.Uh != 2 || f.Uw != 2)) return false;
     if ((f.Uh - 1) - f.i0h != 0 || (f.Uw - 1) - f.i0w != 0) return false;      // every phase starts at dy pixel (oh, ow)
+    min_h = f.cnth < min_h ? f.cnth : min_h;
+    min_w = f.cntw < min_w ? f.cntw : min_w;
   }
+  const int core_h = min_h / 4 * 4, core_w = min_w / 64 * 64;
+  if (core_h < 4 || core_w < 64) return false;
+  for (int i = 0; i < 4; ++i) {
+    const Phase& f = p.ph[i];
+    if (f.cnth > core_h) ++fringe;
+    if (f.cntw > core_w) ++fringe;
+  }
+  if (k3 && fringe != 0) return false;              // the 3x3 layers of the generator have even inputs: no fringe path needed
+  // 4x4: measured against the merged-phase fast kernel in one process (profiles/r03_taps_dgrad4_ab.txt): +14 % with 1024 core
+  // tiles per program (layer 1 at 257 x 513), +5 % with 256 (layer 2), -9 ... -31 % on the second scale (64-256 tiles: the fringe
+  // launch costs more than the core gains; these K = 512 ... 1024 loops are prologue / epilogue bound either way)
+  if (k4 && (long long)d->N * (core_h / 4) * (core_w / 64) * ((p.Cs + 127) / 128) < g_taps_dgrad4_min_tiles) return false;
+  if (g != nullptr) *g = {core_h, core_w, fringe, k4 ? 1 : 0};
+  (void)mask; (void)addend;
   return true;
 }
+static bool taps_dgrad2_ok(const jpdse_conv_desc* d, const ConvPlan& p, const void* mask, const void* addend, const float* mom) {
+  return taps_dgrad2_geom(d, p, mask, addend, mom, nullptr);
+}
 
-template <int TN>
+template <int TN, int T1A, int T0B, int T1B>
 static int launch_taps_dgrad2_cfg(const TapsArgs& a, int total, hipStream_t s) {
   constexpr int PH = 5, PW = 65;
   constexpr int lds = 2 * ((PH * PW + 7) / 8) * 1024 + 3 * (2 * TN * 32) * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_taps_kernel<TN, 4, 1, 2, 2, 1, PH, PW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_taps_kernel<TN, 4, T1A, T0B, T1B, 1, PH, PW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_taps: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -552,20 +581,23 @@ static int launch_taps_dgrad2_cfg(const TapsArgs& a, int total, hipStream_t s) {
                                4LL * a.N * a.OH * a.OW * a.Ks)) return rc;
   if (total != 2 * a.nblk0 || a.nblk0 != a.N * (a.OH / 4) * (a.OW / 64) * ((a.Ks + 2 * TN * 32 - 1) / (2 * TN * 32)))
     return set_error(JPDSE_EINVAL, "gemm_taps: %d blocks for a grid of 2 x %d", total, a.nblk0);
-  hipLaunchKernelGGL((gemm_taps_kernel<TN, 4, 1, 2, 2, 1, PH, PW>), dim3(total), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_taps_kernel<TN, 4, T1A, T0B, T1B, 1, PH, PW>), dim3(total), dim3(512), lds, s, a);
   return check_launch("gemm_taps_kernel");
 }
 
 static int launch_taps_dgrad2(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx, hipStream_t s,
-                              const void* mask, const void* addend) {
+                              const void* mask, const void* addend, float mask_slope = 0.f) {
+  TapsDgrad2Geom geo = {};
+  if (!taps_dgrad2_geom(d, p, mask, addend, nullptr, &geo)) return set_error(JPDSE_EINVAL, "gemm_taps: not a stride-2 data gradient it covers");
   TapsArgs a = {};
   a.mask = reinterpret_cast<const bf16_t*>(mask);
+  a.mask_slope = mask_slope;
   a.addend = reinterpret_cast<const bf16_t*>(addend);
   a.X = reinterpret_cast<const bf16_t*>(dy);
   a.Y = reinterpret_cast<bf16_t*>(dx);
   a.N = d->N;
-  a.OH = p.OH;
-  a.OW = p.OW;
+  a.OH = geo.core_h;
+  a.OW = geo.core_w;
   a.IH = p.OH;
   a.IW = p.OW;
   a.Cs = p.Ks;
@@ -577,7 +609,7 @@ static int launch_taps_dgrad2(const jpdse_conv_desc* d, const ConvPlan& p, const
   a.out_sh = 2LL * d->W * p.Cs;
   a.out_sw = 2LL * p.Cs;
   a.act = JPDSE_ACT_NONE;
-  // program 0 = {phase (0,0): 4 taps, phase (1,1): 1 tap}, program 1 = {phase (0,1): 2 taps, phase (1,0): 2 taps}
+  // program 0 = {phase (0,0), phase (1,1)}, program 1 = {phase (0,1), phase (1,0)}: 4 + 1 and 2 + 2 taps (3x3), 4 + 4 twice (4x4)
   const Phase* byq[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   for (int i = 0; i < 4; ++i) byq[p.ph[i].qh][p.ph[i].qw] = &p.ph[i];
   const Phase* sets[2][2] = {{byq[0][0], byq[1][1]}, {byq[0][1], byq[1][0]}};
@@ -598,8 +630,58 @@ static int launch_taps_dgrad2(const jpdse_conv_desc* d, const ConvPlan& p, const
     }
   }
   const int bn = p.Cs % 128 == 0 ? 128 : 64;
-  a.nblk0 = d->N * (p.OH / 4) * (p.OW / 64) * ((p.Cs + bn - 1) / bn);
-  return bn == 128 ? launch_taps_dgrad2_cfg<2>(a, 2 * a.nblk0, s) : launch_taps_dgrad2_cfg<1>(a, 2 * a.nblk0, s);
+  a.nblk0 = d->N * (a.OH / 4) * (a.OW / 64) * ((p.Cs + bn - 1) / bn);
+  int rc;
+  if (geo.taps4) rc = bn == 128 ? launch_taps_dgrad2_cfg<2, 4, 4, 4>(a, 2 * a.nblk0, s) : launch_taps_dgrad2_cfg<1, 4, 4, 4>(a, 2 * a.nblk0, s);
+  else rc = bn == 128 ? launch_taps_dgrad2_cfg<2, 1, 2, 2>(a, 2 * a.nblk0, s) : launch_taps_dgrad2_cfg<1, 1, 2, 2>(a, 2 * a.nblk0, s);
+  if (rc != JPDSE_OK || geo.fringe == 0) return rc;
+  // fringe: per phase the sub-pixel rows [core_h, cnth) x all its columns, and the columns [core_w, cntw) x rows [0, core_h)
+  FastBatch fb = {};
+  auto flush = [&]() -> int {
+    if (fb.n == 0) return JPDSE_OK;
+    const int r = launch_fast_batch(fb, s);
+    fb = FastBatch{};
+    return r;
+  };
+  for (int i = 0; i < 4; ++i) {
+    const Phase& f = p.ph[i];
+    const int rect[2][4] = {{geo.core_h, 0, f.cnth - geo.core_h, f.cntw}, {0, geo.core_w, geo.core_h, f.cntw - geo.core_w}};   // j0, c0, rows, cols
+    for (int q = 0; q < 2; ++q) {
+      const int j0 = rect[q][0], c0 = rect[q][1], rows = rect[q][2], cols = rect[q][3];
+      if (rows <= 0 || cols <= 0) continue;
+      FastArgs g = {};
+      g.X = a.X;
+      g.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(pack) + f.pack_off);
+      g.Y = a.Y;
+      g.M = d->N * rows * cols;
+      g.OH = rows;
+      g.OW = cols;
+      g.IH = p.OH;
+      g.IW = p.OW;
+      g.Cs = p.Ks;
+      g.R = f.Uh;
+      g.S = f.Uw;
+      g.sy = g.sx = 1;
+      g.py = (f.Uh - 1) - f.i0h - j0;
+      g.px = (f.Uw - 1) - f.i0w - c0;
+      g.Kout = d->C;
+      g.Ks = p.Cs;
+      g.b_rows = p.Cs;
+      g.out_sn = a.out_sn;
+      g.out_sh = a.out_sh;
+      g.out_sw = a.out_sw;
+      g.out_base = ((long long)(2 * (f.i0h + j0) + f.qh - d->pad) * d->W + (2 * (f.i0w + c0) + f.qw - d->pad)) * p.Cs;
+      g.act = JPDSE_ACT_NONE;
+      g.mask = a.mask;
+      g.mask_slope = mask_slope;
+      g.addend = a.addend;
+      g.splits = 1;
+      fb.p[fb.n++] = g;
+      if (fb.n == 4)
+        if (int r = flush()) return r;
+    }
+  }
+  return flush();
 }
 
 // ---- 4x4 stride-1 zero-padded convs and their (single-phase) data gradient on the tap-program kernel: PatchGAN layer 3 of

@@ -50,6 +50,7 @@ struct TapsArgs {
   float slope;
   const bf16_t* addend;      // optional, Y's addressing: Y = result + addend (gradient fan-in), then
   const bf16_t* mask;        // optional, Y's addressing: zeroed where mask <= 0 (ReLU backward of the conv's input)
+  float mask_slope;          // LeakyReLU backward instead: scaled by this where mask <= 0 (0 = ReLU)
   int reflect;               // 1: patch pixels outside the image are mirrored (ReflectionPad2d), 0: zeros
   // split-K over the channel slabs (one program only; few tiles, long reductions: the 1024-channel ResnetBlocks of the
   // LocalEnhancer trunk at 16 x 32 pixels): block (tile, split) runs slabs [CC split / splits, CC (split + 1) / splits) and stores
@@ -303,7 +304,7 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
         const long long off = blk_base + (long long)r * a.out_sh + (long long)c * a.out_sw + n0 + v * 8;
         u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);
         if (a.addend != nullptr) val = add_bf16x8(val, addv[it]);
-        if (a.mask != nullptr) val = relu_mask8(val, mskv[it]);
+        if (a.mask != nullptr) val = lrelu_mask8(val, mskv[it], a.mask_slope);
         *reinterpret_cast<u32x4*>(a.Y + off) = val;
       }
       continue;

@@ -229,6 +229,28 @@ def test_halo_kernel_mfma_16x16x32_variant(name):
     test_conv_fwd_dgrad_wgrad(case, BF16, 0)
 
 
+@pytest.mark.parametrize('name', ['taps_4x4s2', 'd_layer2'])
+def test_taps_dgrad4_small_shapes(name):
+  # developer mode 43: the 4x4 stride-2 data gradient on the tap program (core) + fast kernel (fringe: all eight rectangles
+  # for taps_4x4s2) at sizes below the shipped tile-count threshold
+  import jpdse_hip
+  case = [c for c in CONV_CASES if c[0] == name][0]
+  with jpdse_hip.dev_mode(43):
+    test_conv_fwd_dgrad_wgrad(case, BF16, 0)
+
+
+@pytest.mark.parametrize('name', ['d1_like_taps', 'd2_like_taps'])
+def test_taps_dgrad4_fused_epilogues(name):
+  # the same path with the LeakyReLU mask and the fan-in addend in the core's epilogue and in the fringe's
+  import jpdse_hip
+  case = [c for c in LRELU_CASES if c[0] == name][0]
+  with jpdse_hip.dev_mode(43):
+    test_conv_dgrad_fused_lrelu(case, BF16)
+  case = [c for c in FUSED_RELU_CASES if c[0] == 'taps_dgrad4_fused'][0]
+  with jpdse_hip.dev_mode(43):
+    test_conv_dgrad_fused_relu(case, BF16)
+
+
 # conv -> ReLU(inplace) -> conv chains (VGG19): the second conv's data gradient with the ReLU backward fused
 # (jpdse_conv_dgrad_relu), on the halo, fast (merged stride phases), split-K and generic paths
 FUSED_RELU_CASES = [
@@ -245,6 +267,7 @@ FUSED_RELU_CASES = [
     # there) and the two-set stride-2 data gradient
     ('taps4_fused',   2, 17, 33, 128, 256, 4, 1, 2, PAD_ZERO),
     ('tapsprog_fused', 1, 16, 128, 128, 256, 3, 2, 1, PAD_ZERO),
+    ('taps_dgrad4_fused', 2, 17, 131, 64, 128, 4, 2, 2, PAD_ZERO),   # 4x4 stride 2, odd grid: core on the tap program + fringe on the fast kernel
     ('taps9_fused',   1, 16, 32, 256, 256, 3, 1, 1, PAD_ZERO),       # split-K: the finish kernel applies addend / mask
 ]
 
@@ -285,6 +308,8 @@ LRELU_CASES = [
     # extents: merged-phase tile kernel), a split-K small one, and a generic-path one
     ('d1_like',      2, 33, 65, 64, 128, 4, 2, 2, PAD_ZERO),
     ('d1_like_even', 1, 32, 64, 64, 128, 4, 2, 2, PAD_ZERO),
+    ('d1_like_taps', 1, 17, 257, 64, 128, 4, 2, 2, PAD_ZERO),      # wide enough for the tap-program core: LeakyReLU mask in its epilogue and in the fringe's
+    ('d2_like_taps', 2, 9, 129, 128, 256, 4, 2, 2, PAD_ZERO),
     ('small_splitk', 1, 9, 9, 64, 128, 4, 2, 2, PAD_ZERO),
     ('generic',      1, 11, 13, 24, 40, 3, 1, 1, PAD_ZERO),
 ]
