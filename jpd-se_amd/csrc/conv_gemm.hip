@@ -154,7 +154,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_ring_virt = enable != 40 && enable != 6;   // 40: reflect ring as four split-K strip GEMMs + ring_fold_kernel instead of the folded frame (A/B); 6 keeps every product in fp32 until the fold
   g_thin1_enabled = enable != 41 && enable != 6;   // 41: the one-output-channel layers (PatchGAN 512 -> 1) backward on the GEMM paths (A/B)
   g_taps_dgrad4_enabled = enable != 42 && enable != 6;   // 42: 4x4 stride-2 data gradients (PatchGAN layers 1-2) on the merged-phase fast kernel (A/B)
-  g_taps_dgrad4_min_tiles = enable == 43 ? 1 : 512;     // 43: 4x4 stride-2 data gradients on the tap program at any size
+  g_taps_dgrad4_min_tiles = enable == 43 ? 1 : (1 << 30);     // 43: 4x4 stride-2 data gradients on the tap program + fringe (developer build only: slower in the step)
   g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
   g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
   g_taps9_enabled = enable != 38 && enable != 6;   // 38: 3x3 layers with 32-pixel-wide grids on the split-K fast kernel (A/B)

@@ -525,7 +525,7 @@ JPDSE_SWITCH(int, g_taps_enabled, 1);       // 35: these layers on the merged-ph
 // (a multiple of 4 x 64 sub-pixels), the one-row / one-column FRINGE of the longer phases runs as sub-rectangle problems of the
 // fast kernel behind it (fused operands in its epilogue).
 JPDSE_SWITCH(int, g_taps_dgrad4_enabled, 1);     // 42: the 4x4 stride-2 data gradients on the merged-phase fast kernel (A/B)
-JPDSE_SWITCH(int, g_taps_dgrad4_min_tiles, 512); // 43: no lower bound on the core tile count (tests reach the path with small shapes)
+JPDSE_SWITCH(int, g_taps_dgrad4_min_tiles, 1 << 30);   // 43: take the path at any size (developer build: tests, A/B) -- the shipped build never does, see below
 struct TapsDgrad2Geom { int core_h, core_w, fringe, taps4; };
 static bool taps_dgrad2_geom(const jpdse_conv_desc* d, const ConvPlan& p, const void* mask, const void* addend, const float* mom,
                              TapsDgrad2Geom* g) {
@@ -554,9 +554,12 @@ static bool taps_dgrad2_geom(const jpdse_conv_desc* d, const ConvPlan& p, const 
     if (f.cntw > core_w) ++fringe;
   }
   if (k3 && fringe != 0) return false;              // the 3x3 layers of the generator have even inputs: no fringe path needed
-  // 4x4: measured against the merged-phase fast kernel in one process (profiles/r03_taps_dgrad4_ab.txt): +14 % with 1024 core
-  // tiles per program (layer 1 at 257 x 513), +5 % with 256 (layer 2), -9 ... -31 % on the second scale (64-256 tiles: the fringe
-  // launch costs more than the core gains; these K = 512 ... 1024 loops are prologue / epilogue bound either way)
+  // 4x4: measured against the merged-phase fast kernel (profiles/r03_taps_dgrad4_ab.txt).  Bare data gradient, one process:
+  // +14 % with 1024 core tiles per program (layer 1 at 257 x 513), +5 % with 256 (layer 2), -9 ... -31 % on the second scale.
+  // In the step, where the LeakyReLU mask and the feature-matching addend ride in the epilogue, layer 1 was SLOWER
+  // (0.195 + 0.130 ms vs 0.186 + 0.116 ms for the two launches): with one block per CU the operand loads of the two epilogues
+  // are exposed, the fast kernel overlaps them across its three co-resident blocks.  These K = 512 ... 1024 loops are
+  // prologue / epilogue bound on either kernel; the path stays in the developer build only.
   if (k4 && (long long)d->N * (core_h / 4) * (core_w / 64) * ((p.Cs + 127) / 128) < g_taps_dgrad4_min_tiles) return false;
   if (g != nullptr) *g = {core_h, core_w, fringe, k4 ? 1 : 0};
   (void)mask; (void)addend;
