@@ -303,7 +303,7 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       h.out_sw = p.Cs;
       h.act = JPDSE_ACT_NONE;
       h.addend = reinterpret_cast<const bf16_t*>(addend);
-      if (ring_halo && g_ring_virt && p.Ks >= 128) {
+      if (ring_halo && g_ring_virt && (p.Ks >= 128 || (p.Ks == 64 && g_halo_single))) {
         // one launch: the ring rides in the frame of dy (gemm_halo.h, VIRT); the mask, if any, in the same epilogue
         bf16_t* frame = reinterpret_cast<bf16_t*>(wsb);
         const long long fv = (long long)d->N * (2 * (d->W + 2) + 2 * d->H) * (p.Ks / 8);

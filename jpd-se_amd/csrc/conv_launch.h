@@ -272,8 +272,8 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
     configured = true;
   }
   if (int rc = check_tile_grid("gemm_halo", a.N, a.OH, a.OW, 4, 64, a.Cs, (long long)a.N * a.IH * a.IW * a.Cs, (long long)a.N * a.OH * a.OW * a.Ks)) return rc;
-  if (VIRT && (a.V == nullptr || a.py != 1 || a.px != 1 || a.IH != a.OH || a.IW != a.OW || a.OH < 8 || a.reflect || a.Cs < 128))
-    return set_error(JPDSE_EINVAL, "gemm_halo: folded-frame form needs a frame, pad 1, equal grids, >= 8 rows, >= 128 channels");
+  if (VIRT && (a.V == nullptr || a.py != 1 || a.px != 1 || a.IH != a.OH || a.IW != a.OW || a.OH < 8 || a.reflect || (a.Cs < 128) != SINGLE))
+    return set_error(JPDSE_EINVAL, "gemm_halo: folded-frame form needs a frame, pad 1, equal grids, >= 8 rows");
   if (MOM && (a.mom == nullptr || a.mom_slots != (a.OH / 4) * (a.OW / 64)))
     return set_error(JPDSE_EINVAL, "gemm_halo: moment epilogue without a moment buffer of %d slots", (a.OH / 4) * (a.OW / 64));
   const int tiles = a.N * (a.OH / 4) * (a.OW / 64) * ((a.Ks + BN - 1) / BN);
@@ -301,7 +301,10 @@ static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
   HaloArgs a = a0;
   a.xcd_mode = g_halo_xcd;
   if (a.V != nullptr) {                   // reflect data gradient with the folded frame
-    if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, false, false, false, true>(a, s);
+    if constexpr (ABL == 0) {
+      if (a.Cs == 64) return launch_halo_cfg_impl<TN, 0, true, false, false, false, false, true>(a, s);     // one slab: single patch buffer
+      return launch_halo_cfg_impl<TN, 0, false, false, false, false, false, true>(a, s);
+    }
   }
   if (a.mom != nullptr) {                 // conv -> InstanceNorm with the moments in this kernel's epilogue (double-buffered form)
     if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, false, false, true>(a, s);

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   constexpr int HU = (UH + NW - 1) / NW;              // patch units per wave (7 for 50 units / 8 waves)
   static_assert(HU <= TAPS - 2, "patch units of the next slab are spread over taps 0..HU-1");
   constexpr int PZ = UH * 8 - 1;                      // VIRT: the last slack pixel of a patch buffer is kept zero
-  static_assert(!VIRT || (PZ >= NP && !MF16 && !SINGLE && !MOM), "VIRT needs a slack pixel; written for the plain 32x32 form");
+  static_assert(!VIRT || (PZ >= NP && !MF16 && !MOM), "VIRT needs a slack pixel; written for the plain 32x32 form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo0 = smem;
   constexpr int NBUF = SINGLE ? 1 : 2;
