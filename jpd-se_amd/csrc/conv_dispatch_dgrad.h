@@ -282,6 +282,17 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         v.tap_s = p.Ks;
         v.act = JPDSE_ACT_NONE;
         v.addend = reinterpret_cast<const bf16_t*>(addend);
+        if (g_ring_virt && d->H >= 16) {
+          // one launch (+ the split-K finish): the ring rides in the frame of dy (gemm_taps.h VIRT)
+          bf16_t* frame = reinterpret_cast<bf16_t*>(wsb);       // in front of the split-K slabs (splitk_off lies behind the padded-dy region)
+          const long long fv = (long long)d->N * (2 * (d->W + 2) + 2 * d->H) * (p.Ks / 8);
+          if ((size_t)fv * 16 > p.splitk_off) return set_error(JPDSE_EWORKSPACE, "reflect data gradient: no room for the frame in front of the slabs");
+          hipLaunchKernelGGL(ring_frame_kernel, dim3(ew_blocks(fv)), dim3(256), 0, s, v.X, frame, d->N, d->H, d->W, p.Ks, fv);
+          if (int rc = check_launch("ring_frame_kernel")) return rc;
+          v.frame = frame;
+          v.mask = reinterpret_cast<const bf16_t*>(mask);
+          return launch_taps9(v, reinterpret_cast<float*>(wsb + p.splitk_off), s);
+        }
         if (int rc = launch_taps9(v, reinterpret_cast<float*>(wsb + p.splitk_off), s)) return rc;
       }
       HaloArgs h = {};

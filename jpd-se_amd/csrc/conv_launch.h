@@ -704,6 +704,7 @@ struct Taps4View {            // a stride-1 4x4 conv as the kernels see it: forw
   int tap_r, tap_s;           // panel offsets per filter-row / filter-column step
   int act; float slope;
   const bf16_t* addend; const bf16_t* mask;   // optional fused operands of a data gradient (Y's addressing)
+  const bf16_t* frame;                        // nine-tap program only: folded frame of X (reflect data gradient in one launch)
   int reflect;                                // 3x3 view only: mirrored instead of zero padding
 };
 
@@ -854,13 +855,13 @@ static int taps9_splits(int N, int OH, int OW, int Cin_s, int Ks_out) {
   return sp > cc / 2 ? (cc / 2 > 0 ? cc / 2 : 1) : sp;                 // >= 2 slabs (18 tap steps) per block
 }
 
-template <int TN>
+template <int TN, bool VIRT = false>
 static int launch_taps9_cfg(const TapsArgs& a, int total, hipStream_t s) {
   constexpr int PH = 10, PW = 34;
   constexpr int lds = 2 * ((PH * PW + 7) / 8) * 1024 + 3 * (2 * TN * 32) * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_taps_kernel<TN, 9, 0, 0, 0, 2, PH, PW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_taps_kernel<TN, 9, 0, 0, 0, 2, PH, PW, VIRT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_taps(3x3): hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -870,7 +871,9 @@ static int launch_taps9_cfg(const TapsArgs& a, int total, hipStream_t s) {
   const int sp = a.splits > 1 ? a.splits : 1;
   if (total != sp * a.N * (a.OH / 8) * (a.OW / 32) * ((a.Ks + 2 * TN * 32 - 1) / (2 * TN * 32)) || (sp > 1 && a.partial == nullptr))
     return set_error(JPDSE_EINVAL, "gemm_taps(3x3): %d blocks do not match the tile grid x %d splits", total, sp);
-  hipLaunchKernelGGL((gemm_taps_kernel<TN, 9, 0, 0, 0, 2, PH, PW>), dim3(total), dim3(512), lds, s, a);
+  if (VIRT && (a.V == nullptr || a.py != 1 || a.px != 1 || a.IH != a.OH || a.IW != a.OW || a.OH < 16 || a.reflect))
+    return set_error(JPDSE_EINVAL, "gemm_taps(3x3): folded-frame form needs a frame, pad 1, equal grids, >= 16 rows");
+  hipLaunchKernelGGL((gemm_taps_kernel<TN, 9, 0, 0, 0, 2, PH, PW, VIRT>), dim3(total), dim3(512), lds, s, a);
   return check_launch("gemm_taps_kernel(3x3)");
 }
 
@@ -899,6 +902,7 @@ static int launch_taps9(const Taps4View& v, float* slabs, hipStream_t s) {
   a.slope = v.slope;
   a.addend = v.addend;
   a.mask = v.mask;
+  a.V = v.frame;
   a.prog[0].B[0] = v.B;
   a.prog[0].ktot[0] = v.ktot;
   a.prog[0].out_base[0] = 0;
@@ -912,7 +916,10 @@ static int launch_taps9(const Taps4View& v, float* slabs, hipStream_t s) {
   a.splits = taps9_splits(v.N, v.OH, v.OW, v.Cin_s, v.Ks_out);
   a.partial = a.splits > 1 ? slabs : nullptr;
   a.nblk0 = tiles * (a.splits > 1 ? a.splits : 1);
-  if (int rc = bn == 128 ? launch_taps9_cfg<2>(a, a.nblk0, s) : launch_taps9_cfg<1>(a, a.nblk0, s)) return rc;
+  int rc;
+  if (v.frame != nullptr) rc = bn == 128 ? launch_taps9_cfg<2, true>(a, a.nblk0, s) : launch_taps9_cfg<1, true>(a, a.nblk0, s);
+  else rc = bn == 128 ? launch_taps9_cfg<2>(a, a.nblk0, s) : launch_taps9_cfg<1>(a, a.nblk0, s);
+  if (rc) return rc;
   if (a.splits <= 1) return JPDSE_OK;
   FastArgs f = {};                                  // what splitk_finish_kernel reads
   f.Y = v.Y;

@@ -58,11 +58,16 @@ struct TapsArgs {
   // index order and applies bias / activation / addend / mask
   int splits;
   float* partial;
+  const bf16_t* V;           // VIRT instantiation: the folded frame of X (ring_frame_kernel): reflect data gradient in one launch (gemm_halo.h)
   int nblk0;                 // blocks [0, nblk0) run prog[0], the rest prog[1]
   TapsProg prog[2];
 };
 
-template <int TN, int T0, int T1, int WROWS, int PH, int PW>
+// VIRT (3x3 program, T0 = 9 taps in row-major order, py = px = 1, equal grids): the reflect ring folded into a frame of the
+// input, exactly as in gemm_halo.h -- the loader puts the frame where the zero padding would be, the fragment addresses of the
+// image rows 1 / OH-2 and columns 1 / OW-2 are redirected to it for the filter rows / columns that cross the border, the reads
+// that must still see the padding go to a zero pixel in the slack of the patch buffer.
+template <int TN, int T0, int T1, int WROWS, int PH, int PW, bool VIRT = false>
 __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg& pr, int bid, char* smem) {
   // (bid is reduced to the tile index below when the launch is split over channel slabs)
   constexpr int NT = T0 + T1, NSETS = T1 > 0 ? 2 : 1;
@@ -78,6 +83,8 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
   constexpr int HU = (UH + NW - 1) / NW;              // patch units per wave
   constexpr int UPT = (HU + NT - 1) / NT;             // patch units of the NEXT slab issued per tap
   static_assert(NT <= kTapsMax && NT >= 2, "tap program length");
+  constexpr int PZ = UH * 8 - 1;                      // VIRT: the last slack pixel of a patch buffer is kept zero
+  static_assert(!VIRT || (T0 == 9 && T1 == 0 && PZ >= NP && PH == TH + 2 && PW == TW + 2), "VIRT: nine taps, one set, a slack pixel");
   // LDS: weight ring first (its stage offsets then fit the 16-bit immediate of ds_read), the two patch buffers behind it
   char* const bring = smem;
   char* const halo0 = smem + 3 * B_STAGE;
@@ -109,6 +116,7 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
     const int ug = on ? u : 0;
     int p = ug * 8 + lrow;
     const int swz_p = p;                              // the swizzle uses the LDS pixel index, also for clamped lanes
+    const bool slack = p >= NP;
     p = p < NP ? p : NP - 1;
     const int hr = p / PW, wc = p - hr * PW;
     int ih = oh0 - a.py + hr, iw = ow0 - a.px + wc;
@@ -120,6 +128,15 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
     }
     const int chunk = (lslot ^ (swz_p >> 1)) & 7;
     h_off[i] = ok ? ((n * a.IH + ih) * a.IW + iw) * a.Cs + chunk * 8 : -1;
+    if constexpr (VIRT) {
+      // padding pixels come from the frame: rows [2][IW + 2] (column index iw + 1), then columns [2][IH]; slack pixels are zeros
+      if (!ok && !slack) {
+        const int fw = a.IW + 2;
+        const int fp = (ih < 0 || ih >= a.IH) ? (ih < 0 ? 0 : fw) + iw + 1 : 2 * fw + (iw < 0 ? 0 : a.IH) + ih;
+        h_off[i] = -2 - ((n * (2 * fw + 2 * a.IH) + fp) * a.Cs + chunk * 8);
+      }
+      if (slack) h_off[i] = -1;
+    }
     h_lds[i] = ug * 1024;
   }
   // ---- weight tile DMA units, per accumulator set
@@ -141,6 +158,18 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
 #pragma unroll
   for (int i = 0; i < 2; ++i)
     pb[i] = WROWS == 1 ? wm * PW + i * 32 + (lane & 31) : (2 * wm + i) * PW + (lane & 31);
+  // VIRT: patch column read by this lane's pixel for tap columns 0 and 2 (>= 1000: the zero pixel); edge flags of the tile
+  int vc0 = 0, vc2 = 0;
+  bool v_top = false, v_bot = false;
+  if constexpr (VIRT) {
+    static_assert(!VIRT || WROWS == 2, "VIRT is written for the 8 x 32 tile (one fragment block per image row)");
+    v_top = oh0 == 0;
+    v_bot = oh0 + TH == a.OH;
+    const bool left = ow0 == 0, right = ow0 + TW == a.OW;
+    const int w = lane & 31;
+    vc0 = (left && w == 0) ? 1000 : ((right && w == TW - 2) ? PW - 1 : w);
+    vc2 = (right && w == TW - 1) ? 1000 : ((left && w == 1) ? 0 : w + 2);
+  }
   const int hsel = lane >> 5;                         // k-chunk of this lane inside a k-step
   int b_rd[TN][4];
 #pragma unroll
@@ -167,6 +196,7 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
   auto issue_patch_unit = [&](int i, int slab) {      // i: compile-time after unrolling at the call sites
     char* const dst = halo0 + (slab & 1) * HALO + h_lds[i];
     const bf16_t* src = h_off[i] >= 0 ? a.X + (h_off[i] + slab * 64) : zero;
+    if constexpr (VIRT) src = h_off[i] < -1 ? a.V + ((-2 - h_off[i]) + slab * 64) : src;
     glds16(src, dst);
   };
   auto issue_b = [&](const int tap, const int slab, const int stage) {      // tap, stage: compile-time at the call sites
@@ -213,7 +243,17 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
     int a_base[2], a_sw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int pt = pb[i] + tapoff;
+      int pt = pb[i] + tapoff;
+      if constexpr (VIRT) {
+        const int tr = TAP / 3, ts = TAP % 3;         // row-major nine-tap program (the launcher sets tap_off = tr * PW + ts); constants after unrolling
+        const int j = 2 * wm + i;                     // image row of this fragment block inside the tile
+        int vrow = (j + tr) * PW;
+        if (tr == 2) vrow = (v_top && j == 1) ? 0 : ((v_bot && j == TH - 1) ? 1000 : vrow);
+        if (tr == 0) vrow = (v_bot && j == TH - 2) ? (PH - 1) * PW : ((v_top && j == 0) ? 1000 : vrow);
+        const int col = ts == 0 ? vc0 : (ts == 2 ? vc2 : (lane & 31) + 1);
+        pt = vrow + col;
+        pt = pt < PZ ? pt : PZ;
+      }
       a_base[i] = pt << 7;
       a_sw[i] = ((pt >> 1) & 7) << 4;
     }
@@ -321,7 +361,7 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
 
 // Two tap programs in one launch (block-uniform branch): <T0A, T1A> for blocks [0, nblk0), <T0B, T1B> for the rest
 // (T0B == 0: one program only).
-template <int TN, int T0A, int T1A, int T0B, int T1B, int WROWS, int PH, int PW>
+template <int TN, int T0A, int T1A, int T0B, int T1B, int WROWS, int PH, int PW, bool VIRT = false>
 __global__ __launch_bounds__(512) void gemm_taps_kernel(const TapsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (T0B > 0) {
@@ -344,7 +384,7 @@ __global__ __launch_bounds__(512) void gemm_taps_kernel(const TapsArgs a) {
     }
     gemm_taps_body<TN, T0A, T1A, WROWS, PH, PW>(a, a.prog[0], local, smem);
   } else {
-    gemm_taps_body<TN, T0A, T1A, WROWS, PH, PW>(a, a.prog[0], (int)blockIdx.x, smem);
+    gemm_taps_body<TN, T0A, T1A, WROWS, PH, PW, VIRT>(a, a.prog[0], (int)blockIdx.x, smem);
   }
 }
 

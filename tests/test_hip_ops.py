@@ -128,6 +128,10 @@ CONV_CASES = [
     # gradient = interior on the same kernel + ring strips + fold), unsplit, 64-wide output tile on a 96-pixel-wide grid
     ('taps9_reflect',   2, 16, 32,  256, 256, 3, 1, 1, PAD_REFLECT,  ACT_NONE),
     ('taps9_zero',      1, 8,  32,  128, 128, 3, 1, 1, PAD_ZERO,     ACT_RELU),
+    # reflect data gradient over the folded frame on the 8 x 32 tiles (gemm_taps.h VIRT): three tile rows (an interior one),
+    # three column tiles, ragged channel tile
+    ('taps9_frame_tall', 1, 24, 32, 128, 192, 3, 1, 1, PAD_REFLECT,  ACT_NONE),
+    ('taps9_frame_w96',  2, 16, 96, 128, 128, 3, 1, 1, PAD_REFLECT,  ACT_NONE),
     ('taps9_n64_w96',   1, 8,  96,  192, 64,  3, 1, 1, PAD_ZERO,     ACT_NONE),
     # filter-in-registers row-streaming kernel (conv_rows.h: 64-channel inputs, 3x3, zero pad): stride 2 with 128 / 64
     # outputs (4 x 1 / 2 x 2 waves), stride 1 likewise; several strips, several bands, bands of 16 rows (steady-state
@@ -262,7 +266,8 @@ FUSED_RELU_CASES = [
     ('generic_small', 2, 9,  11, 16,  24,  3, 1, 1, PAD_ZERO),
     ('reflect',       1, 12, 20, 64,  64,  3, 1, 1, PAD_REFLECT),
     ('thin1_fused',   2, 7,  70,  256, 1,   4, 1, 2, PAD_ZERO),      # one output channel: the addend rides in thin1_dgrad_kernel
-    ('ring_frame',    2, 12, 128, 128, 128, 3, 1, 1, PAD_REFLECT),  # folded-frame halo kernel: addend / mask in its epilogue
+    ('ring_frame',    2, 12, 128, 128, 128, 3, 1, 1, PAD_REFLECT),
+    ('taps9_frame_fused', 1, 16, 32, 256, 256, 3, 1, 1, PAD_REFLECT),   # nine-tap program over the frame + split-K finish with addend / mask  # folded-frame halo kernel: addend / mask in its epilogue
     # tap-program kernel epilogues (gemm_taps.h): 4x4 stride 1 (core + split-K fringe: the finish kernel applies the operands
     # there) and the two-set stride-2 data gradient
     ('taps4_fused',   2, 17, 33, 128, 256, 4, 1, 2, PAD_ZERO),
