@@ -145,6 +145,7 @@ LAYERS_1024 = [
     ('d_layer0',         8, 512, 1024, 39,  64,  4, 2, 2, PAD_ZERO,    False),   # thin_rows
     ('d_layer1',         8, 257, 513,  64,  128, 4, 2, 2, PAD_ZERO,    False),   # odd sizes: ragged tiles
     ('d_layer3',         8, 65,  129,  256, 512, 4, 1, 2, PAD_ZERO,    False),   # 4x4 stride 1
+    ('d_layer4',         8, 66,  130,  512, 1,   4, 1, 2, PAD_ZERO,    False),   # one output channel: thin1_dgrad / thin1_wgrad (thin_out1.h)
 ]
 
 
