@@ -183,6 +183,7 @@ static bool prefer_320(int M, int Ks) {
   return c320 < c256;
 }
 
+JPDSE_SWITCH(int, g_fast_small_stages, 2);   // 44 / 45: 3- / 4-stage rings for the 128-row short-K configs (A/B)
 JPDSE_SWITCH(int, g_fast_small, 20);      // K-tile count up to which the 128-row / 2-stage fast configs are used
 static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   if (b.n <= 0) return JPDSE_OK;
@@ -206,6 +207,11 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   if (g_fast_small && kt <= g_fast_small && b.p[0].splits <= 1) {
     // short reductions are prologue / epilogue bound: 128-row tiles, 4 waves, 2 stages = 64 (48) KiB of LDS, so two
     // (three) blocks share a CU and overlap each other's fill and store phases
+#ifdef JPDSE_DEV
+    // developer A/B: deeper rings for the same tiles (44: 3 stages, 45: 4 stages) -- more bytes in flight per block, fewer blocks per CU
+    if (g_fast_small_stages == 3) return Ks > 64 ? launch_fast_cfg<2, 2, 2, 2, 0, 3>(b, s) : launch_fast_cfg<2, 2, 2, 1, 0, 3>(b, s);
+    if (g_fast_small_stages == 4) return Ks > 64 ? launch_fast_cfg<2, 2, 2, 2, 0, 4>(b, s) : launch_fast_cfg<2, 2, 2, 1, 0, 4>(b, s);
+#endif
     if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);   // 128 x 128
     if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);   // 128 x 64
   }

@@ -353,11 +353,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     for (int i = 0; i < AU; ++i) a_src[i] += ic * a_step[i];
   }
   constexpr int AHEAD = STAGES - 1;       // tiles issued before tile t is consumed
+  static_assert(STAGES >= 2 && STAGES <= 4, "the counted waits below are written for up to three tiles ahead");
+  static_assert(STAGES < 4 || B_UNITS % NW == 0, "4 stages: every wave issues the same number of pieces per tile");
   issue();
   if (AHEAD > 1 && T_total > 1) issue();
+  if (AHEAD > 2 && T_total > 2) issue();
   int cstage = 0;
   for (int t = 0; t < T_total; ++t) {
-    if (AHEAD > 1 && t + 1 < T_total) {
+    if (AHEAD > 2 && t + 2 < T_total) {
+      wait_vmcnt<2 * (AU + BU)>();            // tiles t+1 and t+2 stay in flight
+    } else if (AHEAD > 1 && t + 1 < T_total) {
       if (LW == AU + BU) wait_vmcnt<AU + BU>();
       else wait_vmcnt<AU + (BU > 0 ? BU - 1 : 0)>();
     } else {
