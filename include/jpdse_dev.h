@@ -34,7 +34,8 @@ extern "C" {
  * four ring-strip GEMMs + ring_fold_kernel instead of the folded frame (gemm_halo.h VIRT); 41 = the one-output-channel layers
  * backward on the GEMM paths instead of thin_out1.h; 42 = 4x4 stride-2 data gradients on the merged-phase fast kernel only;
  * 43 = the same layers on the tap program + fringe (developer build only: measured slower in the step);
- * 44 / 45 = 3- / 4-stage rings for the 128-row short-K configurations of the fast kernel (measured 25-50 % slower).  100 + bits = timing-only ablations of the halo loop.
+ * 44 / 45 = 3- / 4-stage rings for the 128-row short-K configurations of the fast kernel (measured 25-50 % slower);
+ * 46 = 128-row tiles also for the <= 16-tile loops with wide outputs (the shipped build takes 64 x 128 tiles there).  100 + bits = timing-only ablations of the halo loop.
  * Each call resets the others to their defaults. */
 int jpdse_debug_set_fast_path(int32_t enable);
 

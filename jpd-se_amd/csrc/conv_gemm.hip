@@ -155,7 +155,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_thin1_enabled = enable != 41 && enable != 6;   // 41: the one-output-channel layers (PatchGAN 512 -> 1) backward on the GEMM paths (A/B)
   g_taps_dgrad4_enabled = enable != 42 && enable != 6;   // 42: 4x4 stride-2 data gradients (PatchGAN layers 1-2) on the merged-phase fast kernel (A/B)
   g_taps_dgrad4_min_tiles = enable == 43 ? 1 : (1 << 30);     // 43: 4x4 stride-2 data gradients on the tap program + fringe (developer build only: slower in the step)
-  g_fast_small_stages = enable == 44 ? 3 : (enable == 45 ? 4 : 2);   // 44 / 45: 3- / 4-stage rings for the 128-row short-K fast configs (A/B)
+  g_fast_small_stages = enable == 44 ? 3 : (enable == 45 ? 4 : (enable == 46 ? 64 : 2));   // 46: no 64-row tiles for the <= 16-tile loops (A/B)
+  //   // 44 / 45: 3- / 4-stage rings for the 128-row short-K fast configs (A/B)
   g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
   g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
   g_taps9_enabled = enable != 38 && enable != 6;   // 38: 3x3 layers with 32-pixel-wide grids on the split-K fast kernel (A/B)

@@ -212,6 +212,11 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
     if (g_fast_small_stages == 3) return Ks > 64 ? launch_fast_cfg<2, 2, 2, 2, 0, 3>(b, s) : launch_fast_cfg<2, 2, 2, 1, 0, 3>(b, s);
     if (g_fast_small_stages == 4) return Ks > 64 ? launch_fast_cfg<2, 2, 2, 2, 0, 4>(b, s) : launch_fast_cfg<2, 2, 2, 1, 0, 4>(b, s);
 #endif
+    // up to 16 K-tiles and wide outputs: 64 x 128 tiles (48 KiB of LDS, three blocks per CU).  Measured per layer in one process
+    // (profiles/r03_fast_tile64_ab.txt): PatchGAN layer 1 forward +7 % / +32 % (first / second scale), layer 2 data gradient
+    // +10 % / +24 %; longer loops (18-32 tiles) and the 64-wide outputs (64 x 64 tiles) lose 3-6 % and keep the 128-row tiles.
+    // Developer mode 46 switches this off.
+    if (Ks > 64 && kt <= 16 && g_fast_small_stages != 64) return launch_fast_cfg<2, 2, 1, 2, 0, 2>(b, s);   // 64 x 128
     if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);   // 128 x 128
     if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);   // 128 x 64
   }
