@@ -146,6 +146,11 @@ int32_t jpdse_conv_moment_slots(const jpdse_conv_desc* d);
 int jpdse_conv_fwd_moments(const jpdse_conv_desc* d, const void* x, const void* fwd_pack, void* y, float* moments,
                            void* ws, size_t ws_bytes, void* stream);
 /* dx = d(loss)/d(x) given dy = d(loss)/d(pre-activation output) */
+/* y as jpdse_conv_fwd and, in the same call, y_pool = MaxPool2d(2, 2)(y) [N][OH/2][OW/2][CPAD(K)] -- the conv -> ReLU ->
+ * MaxPool2d chain of VGG19 (networks.py:477-492).  Kernels that keep their output tile in LDS write both from one epilogue
+ * (the pool pass over y is saved); the others run the pool kernel behind the conv.  Equal to jpdse_conv_fwd + jpdse_maxpool2_fwd. */
+int jpdse_conv_fwd_pool(const jpdse_conv_desc* d, const void* x, const void* fwd_pack, const float* bias,
+                        void* y, void* y_pool, void* ws, size_t ws_bytes, void* stream);
 int jpdse_conv_dgrad(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, void* dx,
                      void* ws, size_t ws_bytes, void* stream);
 /* dx = conv_dgrad(dy) * (x > 0): `x` is this conv's own INPUT [N,H,W,CPAD(C)], which must be a

@@ -6,7 +6,9 @@ namespace jpdse {
 
 template <typename T>
 static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x, const void* pack,
-                      const float* bias, void* y, void* ws, hipStream_t s, float* mom = nullptr) {
+                      const float* bias, void* y, void* ws, hipStream_t s, float* mom = nullptr, void* pool = nullptr,
+                      bool* pooled = nullptr) {
+  // pool != nullptr: the caller wants MaxPool2d(2, 2) of y as well; the branch that can write it from its epilogue sets *pooled
   // mom != nullptr: the caller asked jpdse_conv_moment_slots first, so the branch taken below is one that writes them
   if constexpr (sizeof(T) == 2) {
     if (g_fast_enabled && g_rows_enabled && p.Cs == 8 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
@@ -216,6 +218,10 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       if (mom != nullptr) {
         h.mom = mom;
         h.mom_slots = (p.OH / 4) * (p.OW / 64);
+      }
+      if (pool != nullptr && mom == nullptr && pooled != nullptr && !g_halo_abl) {
+        h.pool = reinterpret_cast<bf16_t*>(pool);
+        *pooled = true;
       }
 #ifdef JPDSE_DEV
       if (g_halo_abl && p.Ks > 64) {      // timing-only ablations (scripts/bench_conv.py --fast 11..)

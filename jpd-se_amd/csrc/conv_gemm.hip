@@ -431,6 +431,24 @@ int jpdse_conv_fwd(const jpdse_conv_desc* d, const void* x, const void* fwd_pack
                                 : conv_fwd_t<float>(d, p, x, fwd_pack, bias, y, ws, as_stream(stream));
 }
 
+int jpdse_conv_fwd_pool(const jpdse_conv_desc* d, const void* x, const void* fwd_pack, const float* bias, void* y,
+                        void* y_pool, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(x && fwd_pack && y && y_pool, "conv_fwd_pool: null pointer");
+  ConvPlan p;
+  make_plan(d, &p);
+  JPDSE_REQUIRE(p.OH >= 2 && p.OW >= 2, "conv_fwd_pool: output of %d x %d pixels", p.OH, p.OW);
+  const size_t need = jpdse_conv_workspace_size(d);
+  if (ws == nullptr || ws_bytes < need)
+    return set_error(JPDSE_EWORKSPACE, "conv_fwd_pool: workspace %zu < %zu", ws_bytes, need);
+  bool pooled = false;
+  const int rc = d->dtype == JPDSE_BF16
+                     ? conv_fwd_t<bf16_t>(d, p, x, fwd_pack, bias, y, ws, as_stream(stream), nullptr, y_pool, &pooled)
+                     : conv_fwd_t<float>(d, p, x, fwd_pack, bias, y, ws, as_stream(stream), nullptr, y_pool, &pooled);
+  if (rc != JPDSE_OK || pooled) return rc;
+  return jpdse_maxpool2_fwd(d->dtype, d->N, p.OH, p.OW, d->K, y, y_pool, stream);     // kernels without the pooled epilogue
+}
+
 int32_t jpdse_conv_moment_slots(const jpdse_conv_desc* d) {
   if (validate(d)) return 0;
   ConvPlan p;

@@ -150,6 +150,17 @@ __device__ __forceinline__ u32x4 add_bf16x8(u32x4 v, u32x4 w) {
   return v;
 }
 
+// element-wise maximum of 8 bf16 values (exact: the result is one of the inputs)
+__device__ __forceinline__ u32x4 max_bf16x8(u32x4 a, u32x4 b) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float alo = __uint_as_float(a[i] << 16), blo = __uint_as_float(b[i] << 16);
+    const float ahi = __uint_as_float(a[i] & 0xffff0000u), bhi = __uint_as_float(b[i] & 0xffff0000u);
+    a[i] = (__float_as_uint(fmaxf(alo, blo)) >> 16) | (__float_as_uint(fmaxf(ahi, bhi)) & 0xffff0000u);
+  }
+  return a;
+}
+
 // 8 bf16 values of `v` zeroed where the matching value of `m` is <= 0 (or NaN)
 __device__ __forceinline__ u32x4 relu_mask8(u32x4 v, u32x4 m) {
 #pragma unroll

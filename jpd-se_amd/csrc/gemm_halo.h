@@ -47,6 +47,7 @@ struct HaloArgs {
   const bf16_t* mask;   // optional fused ReLU backward (see FastArgs::mask)
   const bf16_t* addend; // optional: Y = result + addend
   int xcd_mode;         // 0: block b -> tile b; 1: blocks of one XCD (b % 8) take consecutive tiles; 2: 2 N-tiles x half the patches per XCD
+  bf16_t* pool;         // optional: MaxPool2d(2, 2) of Y, [N][OH/2][OW/2][Ks], written from the same epilogue tile (VGG19 conv -> ReLU -> pool)
   const bf16_t* V;      // VIRT instantiation: the folded frame of the input (see ring_frame_kernel), [N][2(IW+2) + 2 IH][Cs]
   float* mom;           // optional (MOM instantiation): InstanceNorm moments of y, one (mean, M2) slot per block and channel
   int mom_slots;        //   [N][Ks][mom_slots][2], slot = the block's patch index inside its image (common.h; no bias / activation)
@@ -468,6 +469,20 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
     if (n0 + v * 8 >= a.Ks) continue;
     const long long off = blk_base + (long long)(row >> 6) * a.out_sh + (long long)(row & 63) * a.out_sw;
     *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);
+  }
+  if (a.pool != nullptr) {
+    // the 2 x 32 pooled pixels of this 4 x 64 patch, from the tile that is still in LDS: the separate pool pass re-read Y
+    const int OH2 = a.OH >> 1, OW2 = a.OW >> 1;
+    for (int idx = tid; idx < 2 * 32 * VPR; idx += 512) {
+      const int pp = idx / VPR, v = idx - pp * VPR;
+      if (n0 + v * 8 >= a.Ks) continue;
+      const int pr = pp >> 5, pc = pp & 31;
+      const char* const src = smem + ((2 * pr) * 64 + 2 * pc) * PITCH + v * 16;
+      const u32x4 q0 = *reinterpret_cast<const u32x4*>(src), q1 = *reinterpret_cast<const u32x4*>(src + PITCH);
+      const u32x4 q2 = *reinterpret_cast<const u32x4*>(src + 64 * PITCH), q3 = *reinterpret_cast<const u32x4*>(src + 65 * PITCH);
+      *reinterpret_cast<u32x4*>(a.pool + (((long long)n * OH2 + (oh0 >> 1) + pr) * OW2 + (ow0 >> 1) + pc) * a.Ks + n0 + v * 8) =
+          max_bf16x8(max_bf16x8(q0, q1), max_bf16x8(q2, q3));
+    }
   }
 }
 

@@ -395,13 +395,18 @@ class Vgg19(nn.Module):
 
   def fwd(self, x, save=True):
     maps, ctxs, ci = [], [], 0
-    for item in VGG_CFG:
+    pooled = None
+    for pos, item in enumerate(VGG_CFG):
       if item == 'M':
-        y = ops.maxpool2_fwd(x)
+        y = pooled if pooled is not None else ops.maxpool2_fwd(x)     # written by the conv in front of it (jpdse_conv_fwd_pool)
+        pooled = None
         ctxs.append(Ctx(x) if save else None)
         x = y
         continue
-      x, c = self.convs[ci].fwd(x)
+      if pos + 1 < len(VGG_CFG) and VGG_CFG[pos + 1] == 'M' and x.H % 2 == 0 and x.W % 2 == 0:
+        x, pooled, c = self.convs[ci].fwd_pool(x)
+      else:
+        x, c = self.convs[ci].fwd(x)
       ctxs.append(c if save else None)
       if ci in VGG_TAPS:
         maps.append(x)

@@ -68,6 +68,7 @@ SIGNATURES = {
     'jpdse_conv_pack_weights': (_I32, [_CD, _P, _P, _P, _P]),
     'jpdse_conv_workspace_size': (_SZ, [_CD]),
     'jpdse_conv_fwd': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_conv_fwd_pool': (_I32, [_CD, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad_relu': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad_fused': (_I32, [_CD, _P, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -176,6 +176,14 @@ class HipConv2d(nn.Module):
     y = ops.conv_fwd(d, x, fwd_pack, self.bias if self.apply_bias else None)
     return y, Ctx(x, y if self.act != ACT_NONE else None)
 
+  def fwd_pool(self, x):
+    """(y, MaxPool2d(2, 2)(y), ctx): the conv -> ReLU -> pool chain of VGG19 in one call."""
+    assert not self.transposed
+    fwd_pack, _ = self.packs()
+    d = self._desc(x.N, x.H, x.W)
+    y, yp = ops.conv_fwd_pool(d, x, fwd_pack, self.bias if self.apply_bias else None)
+    return y, yp, Ctx(x, y if self.act != ACT_NONE else None)
+
   def fwd_moments(self, x):
     """Forward for a conv whose output goes straight into an affine-less InstanceNorm: (y, ctx, moments, slots) with the
     norm's moment pass fused into the conv epilogue (jpdse_conv_fwd_moments), or None when this layer's kernel has no such

@@ -118,6 +118,17 @@ def conv_fwd(d, x, fwd_pack, bias, out=None):
   return y
 
 
+def conv_fwd_pool(d, x, fwd_pack, bias):
+  """(y, MaxPool2d(2, 2)(y)) in one call (jpdse_conv_fwd_pool)."""
+  oh, ow = conv_out_shape(d)
+  y = Act.empty(d.N, oh, ow, d.K, d.dtype, x.t.device)
+  yp = Act.empty(d.N, oh // 2, ow // 2, d.K, d.dtype, x.t.device)
+  ws, n = _conv_ws(d, x.t.device)
+  check(lib().jpdse_conv_fwd_pool(ctypes.byref(d), _p(x.t), _p(fwd_pack), _p(bias), _p(y.t), _p(yp.t), _p(ws), ws.numel(),
+                                  _stream()), 'conv_fwd_pool')
+  return y, yp
+
+
 def conv_dgrad(d, dy, dgrad_pack, relu_input=None, addend=None, mask_slope=0.0):
   """relu_input: the conv's own input x when it is a ReLU output -- dx is then masked where x <= 0
   (the ReLU backward fused into the GEMM epilogue); with mask_slope != 0 x is a LeakyReLU(mask_slope) output and

@@ -357,6 +357,26 @@ def test_conv_dgrad_fused_lrelu(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 8, 64, 128, 128), (1, 12, 128, 64, 192), (1, 16, 64, 256, 64), (2, 6, 10, 16, 24), (1, 7, 9, 8, 8)],
+                         ids=['halo_128', 'halo_64in_ragged', 'halo_n64', 'generic', 'odd'])
+def test_conv_fwd_pool(shape, dtype):
+  """jpdse_conv_fwd_pool == jpdse_conv_fwd followed by jpdse_maxpool2_fwd, bit for bit (halo epilogue and the fallback)."""
+  N, H, W, C, K = shape
+  g = G(N * 1000 + H * 10 + C)
+  layer = HipConv2d(C, K, 3, 1, 1, PAD_ZERO, act=ACT_RELU, dtype=dtype, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5)
+    layer.bias.copy_(torch.randn(K, generator=g) * 0.1)
+  x = to_act(quantize_like(torch.randn(N, C, H, W, generator=g), dtype), dtype)
+  y, ctx = layer.fwd(x)
+  ref = ops.maxpool2_fwd(y)
+  y2, yp, ctx2 = layer.fwd_pool(x)
+  torch.cuda.synchronize()
+  assert torch.equal(y.t, y2.t), 'conv output changed by the pooled epilogue'
+  assert yp.t.shape == ref.t.shape and torch.equal(yp.t, ref.t), 'pooled output differs from conv + maxpool'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('relu_a', [False, True])
 def test_l1_fwd_bwd_one_pass(dtype, relu_a):
   g = G(93)
