@@ -36,7 +36,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 
 records = []          # (key, e0, e1)
-_orig = dict(fwd=ops.conv_fwd, dgrad=ops.conv_dgrad, wgrad=ops.conv_wgrad)
+_orig = dict(fwd=ops.conv_fwd, dgrad=ops.conv_dgrad, wgrad=ops.conv_wgrad, fwd_pool=ops.conv_fwd_pool)
 
 
 def _key(kind, d):
@@ -52,12 +52,13 @@ def _wrap(kind):
     r = f(d, *a, **k)
     c1 = time.perf_counter()
     e1.record()
-    records.append((_key(kind, d), e0, e1, c1 - c0))
+    records.append((_key('fwd' if kind == 'fwd_pool' else kind, d), e0, e1, c1 - c0))     # conv + pooled epilogue counts as the forward
     return r
   return g
 
 
 ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = _wrap('fwd'), _wrap('dgrad'), _wrap('wgrad')
+ops.conv_fwd_pool = _wrap('fwd_pool')
 # convs whose epilogue also writes the InstanceNorm moments (ConvTranspose forward = the data gradient of the underlying conv)
 _fm = ops.conv_fwd_moments
 def _fwd_moments(d, x, pack, slots, transposed=False):
