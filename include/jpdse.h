@@ -286,6 +286,19 @@ int jpdse_insert_channels(int32_t dtype, int64_t npix, void* dst, int32_t cs, co
  * count the mean divides by (padding lanes are zero in both operands).
  * out[0] = mean |a-b|  (nn.L1Loss: networks.py:131, model.py:207,218) */
 size_t jpdse_loss_workspace_size(int64_t n);
+/* Deferred second stage.  Every jpdse_*_fwd / jpdse_l1_fwd_bwd below accepts out == NULL: the block partials then stay in `ws`
+ * (which must not be reused before they are consumed) and ONE jpdse_loss_finalize call reduces any number of such terms --
+ * out[0] = inv_count * sum(partial[0 .. n)) in index order, per term -- instead of one tiny launch per term (the train step has 20:
+ * model.py:196-221).  n = jpdse_loss_partial_count(work items): 16-byte vectors of `a` for the L1 / MSE terms, pixels for
+ * jpdse_mse_const_fwd.  `terms` is a HOST array (copied into the launch). */
+typedef struct jpdse_loss_term {
+  const float* partial;
+  int32_t n;
+  float inv_count;
+  float* out;
+} jpdse_loss_term;
+int32_t jpdse_loss_partial_count(int64_t work_items);
+int jpdse_loss_finalize(const jpdse_loss_term* terms, int32_t n_terms, void* stream);
 int jpdse_l1_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out,
                  void* ws, size_t ws_bytes, void* stream);
 /* da = scale * (*gout) * sign(a-b) / count ; gout is a DEVICE scalar (no host sync) */

@@ -495,6 +495,17 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict
   if (threadIdx.x == 0) out[0] = t * inv_count;
 }
 
+// deferred second stage of up to 32 loss terms in one launch: block t = term t (table by value in the kernel arguments)
+struct LossTermTable { jpdse_loss_term t[32]; };
+__global__ __launch_bounds__(256) void loss_final_many_kernel(const LossTermTable tab) {
+  __shared__ float red[4];
+  const jpdse_loss_term e = tab.t[blockIdx.x];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < e.n; i += 256) acc += e.partial[i];
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) e.out[0] = t * e.inv_count;
+}
+
 // relu_a: `a` is a ReLU output and the gradient is wanted w.r.t. the PRE-activation (masked where a <= 0)
 template <typename T, int MODE>
 __global__ void loss_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, float target, int cs,
@@ -974,7 +985,7 @@ size_t jpdse_loss_workspace_size(int64_t n) { return kRedBlocks * sizeof(float);
 template <int MODE>
 static int loss_fwd(const char* name, int dtype, long long total, long long count, const void* a, const void* b,
                     float target, int cs, float* out, void* ws, size_t ws_bytes, void* stream) {
-  JPDSE_REQUIRE(!bad_dtype(dtype) && a && out && total > 0 && count > 0, "%s: bad argument", name);
+  JPDSE_REQUIRE(!bad_dtype(dtype) && a && total > 0 && count > 0, "%s: bad argument", name);
   if (ws == nullptr || ws_bytes < kRedBlocks * sizeof(float))
     return set_error(JPDSE_EWORKSPACE, "%s: workspace too small", name);
   int grid = ew_blocks(total);
@@ -987,6 +998,7 @@ static int loss_fwd(const char* name, int dtype, long long total, long long coun
     hipLaunchKernelGGL((loss_partial_kernel<float, MODE>), dim3(grid), dim3(256), 0, as_stream(stream), cptr<float>(a),
                        cptr<float>(b), target, cs, partial, total);
   if (int rc = check_launch(name)) return rc;
+  if (out == nullptr) return JPDSE_OK;                  // deferred: jpdse_loss_finalize reduces the partials
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, grid,
                      1.f / (float)count, out);
   return check_launch(name);
@@ -1016,6 +1028,28 @@ static int vec_count(const char* name, int dtype, int64_t n, long long* tv) {
 
 extern "C" {
 
+int32_t jpdse_loss_partial_count(int64_t work_items) {
+  if (work_items <= 0) return 0;
+  const int grid = ew_blocks(work_items);
+  return grid > kRedBlocks ? kRedBlocks : grid;
+}
+
+int jpdse_loss_finalize(const jpdse_loss_term* terms, int32_t n_terms, void* stream) {
+  JPDSE_REQUIRE(terms != nullptr && n_terms > 0, "loss_finalize: bad argument");
+  for (int32_t t0 = 0; t0 < n_terms; t0 += 32) {
+    LossTermTable tab = {};
+    const int n = n_terms - t0 < 32 ? n_terms - t0 : 32;
+    for (int i = 0; i < n; ++i) {
+      const jpdse_loss_term& e = terms[t0 + i];
+      JPDSE_REQUIRE(e.partial != nullptr && e.out != nullptr && e.n > 0 && e.n <= kRedBlocks, "loss_finalize: term %d is malformed", t0 + i);
+      tab.t[i] = e;
+    }
+    hipLaunchKernelGGL(loss_final_many_kernel, dim3(n), dim3(256), 0, as_stream(stream), tab);
+    if (int rc = check_launch("loss_finalize")) return rc;
+  }
+  return JPDSE_OK;
+}
+
 int jpdse_l1_fwd(int32_t dtype, int64_t n, int64_t count, const void* a, const void* b, float* out, void* ws,
                  size_t ws_bytes, void* stream) {
   long long tv;
@@ -1034,7 +1068,7 @@ int jpdse_l1_fwd_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, con
                      int32_t relu_a, void* da, void* ws, size_t ws_bytes, void* stream) {
   long long tv;
   if (int rc = vec_count("l1_fwd_bwd", dtype, n, &tv)) return rc;
-  JPDSE_REQUIRE(a && b && out && da && count > 0, "l1_fwd_bwd: bad argument");
+  JPDSE_REQUIRE(a && b && da && count > 0, "l1_fwd_bwd: bad argument");
   if (ws == nullptr || ws_bytes < kRedBlocks * sizeof(float))
     return set_error(JPDSE_EWORKSPACE, "l1_fwd_bwd: workspace too small");
   int grid = ew_blocks(tv);
@@ -1048,6 +1082,7 @@ int jpdse_l1_fwd_bwd(int32_t dtype, int64_t n, int64_t count, const void* a, con
     hipLaunchKernelGGL((loss_partial_kernel<float, RED_L1>), dim3(grid), dim3(256), 0, as_stream(stream),
                        cptr<float>(a), cptr<float>(b), 0.f, 0, partial, tv, mptr<float>(da), gs, relu_a);
   if (int rc = check_launch("l1_fwd_bwd")) return rc;
+  if (out == nullptr) return JPDSE_OK;                  // deferred: jpdse_loss_finalize reduces the partials
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, grid, 1.f / (float)count, out);
   return check_launch("l1_fwd_bwd");
 }

@@ -362,30 +362,31 @@ class Pix2PixHDModel(BaseModel):
     s = lambda i: slots[i:i + 1]
     gw = grad_w or {}
     d_feat, d_vgg, d_dist = None, None, None
-    for i in range(nD if run_d else 0):
-      p = pred[i][-1]
-      ops.mse_const_fwd(p.batch_slice(0, B), 0.0, s(layout['D_fake'][i]))
-      ops.mse_const_fwd(p.batch_slice(B, 2 * B), 1.0, s(layout['D_real'][i]))
-      ops.mse_const_fwd(p.batch_slice(0, B), 1.0, s(layout['G_GAN'][i]))
-      for j in range(nF):
-        f = pred[i][j]
-        ff, fr = f.batch_slice(0, B), f.batch_slice(B, 2 * B)
-        if gw.get('feat') and j < nF - 1:
-          d_feat = d_feat if d_feat is not None else [[None] * nF for _ in range(nD)]
-          d_feat[i][j] = ops.l1_fwd_bwd(ff, fr, s(layout['feat'][i][j]), gw['feat'] / nD)
+    with ops.deferred_loss_finals():          # the second stage of all the loss terms below in ONE launch (jpdse_loss_finalize)
+      for i in range(nD if run_d else 0):
+        p = pred[i][-1]
+        ops.mse_const_fwd(p.batch_slice(0, B), 0.0, s(layout['D_fake'][i]))
+        ops.mse_const_fwd(p.batch_slice(B, 2 * B), 1.0, s(layout['D_real'][i]))
+        ops.mse_const_fwd(p.batch_slice(0, B), 1.0, s(layout['G_GAN'][i]))
+        for j in range(nF):
+          f = pred[i][j]
+          ff, fr = f.batch_slice(0, B), f.batch_slice(B, 2 * B)
+          if gw.get('feat') and j < nF - 1:
+            d_feat = d_feat if d_feat is not None else [[None] * nF for _ in range(nD)]
+            d_feat[i][j] = ops.l1_fwd_bwd(ff, fr, s(layout['feat'][i][j]), gw['feat'] / nD)
+          else:
+            ops.l1_fwd(ff, fr, s(layout['feat'][i][j]))
+      wk = networks.VGGLoss.weights
+      for k in range(len(vf)):
+        if gw.get('vgg') and v_ctx is not None:
+          d_vgg = d_vgg if d_vgg is not None else [None] * len(vf)
+          d_vgg[k] = ops.l1_fwd_bwd(vf[k], vr[k], s(layout['vgg'][k]), gw['vgg'] * wk[k], relu_a=True)
         else:
-          ops.l1_fwd(ff, fr, s(layout['feat'][i][j]))
-    wk = networks.VGGLoss.weights
-    for k in range(len(vf)):
-      if gw.get('vgg') and v_ctx is not None:
-        d_vgg = d_vgg if d_vgg is not None else [None] * len(vf)
-        d_vgg[k] = ops.l1_fwd_bwd(vf[k], vr[k], s(layout['vgg'][k]), gw['vgg'] * wk[k], relu_a=True)
+          ops.l1_fwd(vf[k], vr[k], s(layout['vgg'][k]))
+      if opt.distortion_loss_fn == 'l1' and gw.get('dist'):
+        d_dist = ops.l1_fwd_bwd(fake, real, s(layout['dist']), gw['dist'])
       else:
-        ops.l1_fwd(vf[k], vr[k], s(layout['vgg'][k]))
-    if opt.distortion_loss_fn == 'l1' and gw.get('dist'):
-      d_dist = ops.l1_fwd_bwd(fake, real, s(layout['dist']), gw['dist'])
-    else:
-      (ops.l1_fwd if opt.distortion_loss_fn == 'l1' else ops.mse_fwd)(fake, real, s(layout['dist']))
+        (ops.l1_fwd if opt.distortion_loss_fn == 'l1' else ops.mse_fwd)(fake, real, s(layout['dist']))
     state = dict(B=B, fake=fake, real=real, g_ctx=g_ctx, pred=pred, d_ctx=d_ctx, vf=vf, vr=vr, v_ctx=v_ctx,
                  d_feat=d_feat, d_vgg=d_vgg, d_dist=d_dist)
     return state, slots, layout

@@ -39,6 +39,10 @@ class PackEntry(ctypes.Structure):
              [('blocks', ctypes.c_int64), ('block0', ctypes.c_int64)]
 
 
+class LossTerm(ctypes.Structure):
+  _fields_ = [('partial', ctypes.c_void_p), ('n', ctypes.c_int32), ('inv_count', ctypes.c_float), ('out', ctypes.c_void_p)]
+
+
 class AdamEntry(ctypes.Structure):
   _fields_ = [('p', ctypes.c_void_p), ('g', ctypes.c_void_p), ('m', ctypes.c_void_p),
               ('v', ctypes.c_void_p), ('n', ctypes.c_int64), ('block0', ctypes.c_int64),
@@ -108,6 +112,8 @@ SIGNATURES = {
                                    _I32, _I32, _P]),
     'jpdse_insert_channels': (_I32, [_I32, _I64, _P, _I32, _P, _I32, _I32, _I32, _P]),
     'jpdse_loss_workspace_size': (_SZ, [_I64]),
+    'jpdse_loss_partial_count': (_I32, [_I64]),
+    'jpdse_loss_finalize': (_I32, [_P, _I32, _P]),
     'jpdse_l1_fwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_l1_bwd': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),
     'jpdse_l1_bwd_relu': (_I32, [_I32, _I64, _I64, _P, _P, _P, _F, _P, _P]),

@@ -370,20 +370,67 @@ def _loss_ws(device):
   return workspace(lib().jpdse_loss_workspace_size(0), device)
 
 
+# Deferred second stage of the loss reductions (jpdse_loss_finalize): inside `with deferred_loss_finals():` every loss
+# forward leaves its block partials in its own region of a per-device buffer and ONE launch at the end of the block writes all
+# the slots -- the train step computes 20 loss terms (pix2pixHD_model.py:196-221), each of which had its own 5-us final kernel.
+_LOSS_TERMS_MAX = 64
+_loss_defer = None
+_loss_regions = {}
+
+
+class deferred_loss_finals(object):
+  def __enter__(self):
+    global _loss_defer
+    assert _loss_defer is None, 'deferred_loss_finals does not nest'
+    _loss_defer = []
+    return self
+
+  def __exit__(self, et, ev, tb):
+    global _loss_defer
+    terms, _loss_defer = _loss_defer, None
+    if et is None and terms:
+      from . import LossTerm
+      arr = (LossTerm * len(terms))()
+      for i, (part, n, inv, out) in enumerate(terms):
+        arr[i].partial, arr[i].n, arr[i].inv_count, arr[i].out = part, n, inv, out
+      check(lib().jpdse_loss_finalize(arr, len(terms), _stream()), 'loss_finalize')
+    return False
+
+
+def _loss_target(out, device, work_items, count):
+  """(ws tensor, out pointer or None): the shared loss workspace and the caller's slot, or -- deferred -- a private region and NULL."""
+  if _loss_defer is None:
+    return _loss_ws(device), _p(out)
+  per = lib().jpdse_loss_workspace_size(0) // 4
+  buf = _loss_regions.get(device)
+  if buf is None:
+    buf = _loss_regions[device] = torch.empty(_LOSS_TERMS_MAX * per, dtype=torch.float32, device=device)
+  i = len(_loss_defer)
+  if i >= _LOSS_TERMS_MAX:
+    return _loss_ws(device), _p(out)                  # more terms than regions: this one finishes on its own
+  region = buf[i * per:(i + 1) * per]
+  _loss_defer.append((region.data_ptr(), int(lib().jpdse_loss_partial_count(int(work_items))), 1.0 / float(count), out.data_ptr()))
+  return region, None
+
+
+def _vec_items(a):
+  return a.t.numel() // (4 if a.dtype == F32 else 8)
+
+
 def l1_fwd(a, b, out):
   """out: fp32 device scalar slot (1-element view); mean over LOGICAL elements."""
-  ws = _loss_ws(a.t.device)
   count = a.N * a.H * a.W * a.C
-  check(lib().jpdse_l1_fwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(out), _p(ws), ws.numel(), _stream()), 'l1_fwd')
+  ws, o = _loss_target(out, a.t.device, _vec_items(a), count)
+  check(lib().jpdse_l1_fwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), o, _p(ws), ws.numel() * ws.element_size(), _stream()), 'l1_fwd')
 
 
 def l1_fwd_bwd(a, b, out, scale, relu_a=False):
   """Loss value into `out` and its gradient w.r.t. a (times `scale`) in one pass; returns the gradient."""
-  ws = _loss_ws(a.t.device)
   da = a.empty_like()
   count = a.N * a.H * a.W * a.C
-  check(lib().jpdse_l1_fwd_bwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(out), float(scale), int(relu_a),
-                               _p(da.t), _p(ws), ws.numel(), _stream()), 'l1_fwd_bwd')
+  ws, o = _loss_target(out, a.t.device, _vec_items(a), count)
+  check(lib().jpdse_l1_fwd_bwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), o, float(scale), int(relu_a),
+                               _p(da.t), _p(ws), ws.numel() * ws.element_size(), _stream()), 'l1_fwd_bwd')
   return da
 
 
@@ -397,9 +444,9 @@ def l1_bwd(a, b, gout, scale, relu_a=False):
 
 
 def mse_fwd(a, b, out):
-  ws = _loss_ws(a.t.device)
   count = a.N * a.H * a.W * a.C
-  check(lib().jpdse_mse_fwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), _p(out), _p(ws), ws.numel(), _stream()), 'mse_fwd')
+  ws, o = _loss_target(out, a.t.device, _vec_items(a), count)
+  check(lib().jpdse_mse_fwd(a.dtype, a.t.numel(), count, _p(a.t), _p(b.t), o, _p(ws), ws.numel() * ws.element_size(), _stream()), 'mse_fwd')
 
 
 def mse_bwd(a, b, gout, scale):
@@ -411,9 +458,9 @@ def mse_bwd(a, b, gout, scale):
 
 def mse_const_fwd(x, target, out):
   assert x.C == 1
-  ws = _loss_ws(x.t.device)
   npix = x.N * x.H * x.W
-  check(lib().jpdse_mse_const_fwd(x.dtype, npix, x.Cs, target, _p(x.t), _p(out), _p(ws), ws.numel(), _stream()),
+  ws, o = _loss_target(out, x.t.device, npix, npix)
+  check(lib().jpdse_mse_const_fwd(x.dtype, npix, x.Cs, target, _p(x.t), o, _p(ws), ws.numel() * ws.element_size(), _stream()),
         'mse_const_fwd')
 
 

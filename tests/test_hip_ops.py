@@ -376,6 +376,31 @@ def test_conv_fwd_pool(shape, dtype):
   assert yp.t.shape == ref.t.shape and torch.equal(yp.t, ref.t), 'pooled output differs from conv + maxpool'
 
 
+def test_deferred_loss_finals_match_immediate():
+  """jpdse_loss_finalize (one launch for all terms) == the per-term second stage, bit for bit; the gradients do not change."""
+  g = G(77)
+  a = quantize_like(torch.randn(2, 24, 33, 17, generator=g), BF16)
+  b = quantize_like(torch.randn(2, 24, 33, 17, generator=g), BF16)
+  p = quantize_like(torch.randn(2, 1, 35, 67, generator=g), BF16)
+  aa, ba, pa = to_act(a, BF16), to_act(b, BF16), to_act(p, BF16)
+  ref = torch.zeros(4, dtype=torch.float32, device=DEV)
+  da_ref = ops.l1_fwd_bwd(aa, ba, ref[0:1], 0.7, relu_a=True)
+  ops.l1_fwd(aa, ba, ref[1:2])
+  ops.mse_fwd(aa, ba, ref[2:3])
+  ops.mse_const_fwd(pa, 1.0, ref[3:4])
+  out = torch.zeros(4, dtype=torch.float32, device=DEV)
+  with ops.deferred_loss_finals():
+    da = ops.l1_fwd_bwd(aa, ba, out[0:1], 0.7, relu_a=True)
+    ops.l1_fwd(aa, ba, out[1:2])
+    ops.mse_fwd(aa, ba, out[2:3])
+    ops.mse_const_fwd(pa, 1.0, out[3:4])
+    torch.cuda.synchronize()
+    assert float(out.abs().sum()) == 0.0, 'slots written before the deferred finalize'
+  torch.cuda.synchronize()
+  assert torch.equal(out, ref) and torch.equal(da.t, da_ref.t)
+  assert abs(float(ref[1]) - float((a - b).abs().mean())) < 1e-5
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('relu_a', [False, True])
 def test_l1_fwd_bwd_one_pass(dtype, relu_a):
