@@ -247,7 +247,8 @@ class HipConv2d(nn.Module):
                       self.pad_mode, ACT_NONE, self.slope)
     if getattr(self, '_slice_key', None) != key:
       ws = w.detach()[:, c0:c1].contiguous(memory_format=torch.channels_last)
-      if getattr(self, '_slice_packs', None) is None or self._slice_key[3:] != key[3:]:
+      # same dtype and channel range as last time: re-pack into the existing panels (the weight version alone changes every step)
+      if getattr(self, '_slice_packs', None) is None or (self._slice_key[3], self._slice_key[5:]) != (key[3], key[5:]):
         self._slice_packs = ops.conv_pack(d, ws, w.device)
       else:
         ops.conv_pack_into(d, ws, self._slice_packs[0], self._slice_packs[1])
