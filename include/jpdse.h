@@ -168,7 +168,7 @@ int jpdse_conv_dgrad_fused(const jpdse_conv_desc* d, const void* dy, const void*
                            void* stream);
 /* LeakyReLU form of the above: dx = r * (x > 0 ? 1 : slope) with r = conv_dgrad(dy) + addend rounded to
  * the tensor dtype.  `x` (required) is this conv's own input, the OUTPUT of LeakyReLU(slope) -- the chain
- * Conv2d -> LeakyReLU(0.2) -> Conv2d of NLayerDiscriminator (networks.py:399-404) -- so dx is the
+ * Conv2d -> LeakyReLU(0.2) -> Conv2d of NLayerDiscriminator (networks.py:430-437) -- so dx is the
  * gradient w.r.t. that LeakyReLU's pre-activation; equal, bit for bit, to jpdse_conv_dgrad_fused(x = NULL)
  * followed by jpdse_act_bwd(JPDSE_ACT_LRELU). */
 int jpdse_conv_dgrad_fused_lrelu(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack,
@@ -289,7 +289,7 @@ size_t jpdse_loss_workspace_size(int64_t n);
 /* Deferred second stage.  Every jpdse_*_fwd / jpdse_l1_fwd_bwd below accepts out == NULL: the block partials then stay in `ws`
  * (which must not be reused before they are consumed) and ONE jpdse_loss_finalize call reduces any number of such terms --
  * out[0] = inv_count * sum(partial[0 .. n)) in index order, per term -- instead of one tiny launch per term (the train step has 20:
- * model.py:196-221).  n = jpdse_loss_partial_count(work items): 16-byte vectors of `a` for the L1 / MSE terms, pixels for
+ * pix2pixHD_model.py:205-221).  n = jpdse_loss_partial_count(work items): 16-byte vectors of `a` for the L1 / MSE terms, pixels for
  * jpdse_mse_const_fwd.  `terms` is a HOST array (copied into the launch). */
 typedef struct jpdse_loss_term {
   const float* partial;

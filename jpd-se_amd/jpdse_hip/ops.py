@@ -372,7 +372,7 @@ def _loss_ws(device):
 
 # Deferred second stage of the loss reductions (jpdse_loss_finalize): inside `with deferred_loss_finals():` every loss
 # forward leaves its block partials in its own region of a per-device buffer and ONE launch at the end of the block writes all
-# the slots -- the train step computes 20 loss terms (pix2pixHD_model.py:196-221), each of which had its own 5-us final kernel.
+# the slots -- the train step computes 20 loss terms (pix2pixHD_pix2pixHD_model.py:205-221), each of which had its own 5-us final kernel.
 _LOSS_TERMS_MAX = 64
 _loss_defer = None
 _loss_regions = {}
