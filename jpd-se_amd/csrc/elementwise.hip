@@ -149,6 +149,41 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict
   }
 }
 
+// even H and W: one thread per WINDOW and channel vector -- the four x vectors and the dy vector are loaded once and the four dx
+// vectors written (the per-pixel form above loads the window once per pixel: 5 loads per store instead of 5 per 4 stores)
+template <typename T>
+__global__ void maxpool2_bwd_win_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int H, int W,
+                                        int OH, int OW, int Cs, long long total_vec) {
+  constexpr int VE = Vec16<T>::N;
+  const int cv = Cs / VE;
+  GRID_STRIDE(idx, total_vec) {
+    const int c = (int)(idx % cv);
+    long long t = idx / cv;
+    const int ow = (int)(t % OW);
+    t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const long long base = (((long long)n * H + 2 * oh) * W + 2 * ow) * Cs + c * VE;
+    const long long offs[4] = {0, (long long)Cs, (long long)W * Cs, (long long)W * Cs + Cs};
+    float w[4][VE], g[VE], out[4][VE];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) JPDSE_LOAD_LAST(T, x + base + offs[k], w[k]);
+    JPDSE_LOAD_LAST(T, dy + idx * VE, g);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      int best = 0;
+      float bv = w[0][e];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (w[k][e] > bv) { bv = w[k][e]; best = k; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[k][e] = (best == k) ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Vec16<T>::store(dx + base + offs[k], out[k]);
+  }
+}
+
 // ---- activation backward / add / zero ----------------------------------------------------------
 template <typename T>
 __global__ void act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dz, int act,
@@ -734,6 +769,16 @@ int jpdse_maxpool2_bwd(int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C
   JPDSE_REQUIRE(!bad_dtype(dtype) && x && dy && dx && N > 0 && H > 1 && W > 1 && C > 0, "maxpool2_bwd: bad argument");
   const int Cs = cpad(C), OH = H / 2, OW = W / 2;
   const long long tv = (long long)N * H * W * (Cs / (16 / (int)esize(dtype)));
+  if (H % 2 == 0 && W % 2 == 0) {
+    const long long wv = tv / 4;
+    if (dtype == JPDSE_BF16)
+      hipLaunchKernelGGL((maxpool2_bwd_win_kernel<bf16_t>), dim3(ew_blocks(wv)), dim3(256), 0, as_stream(stream),
+                         cptr<bf16_t>(x), cptr<bf16_t>(dy), mptr<bf16_t>(dx), H, W, OH, OW, Cs, wv);
+    else
+      hipLaunchKernelGGL((maxpool2_bwd_win_kernel<float>), dim3(ew_blocks(wv)), dim3(256), 0, as_stream(stream),
+                         cptr<float>(x), cptr<float>(dy), mptr<float>(dx), H, W, OH, OW, Cs, wv);
+    return check_launch("maxpool2_bwd");
+  }
   if (dtype == JPDSE_BF16)
     hipLaunchKernelGGL((maxpool2_bwd_kernel<bf16_t>), dim3(ew_blocks(tv)), dim3(256), 0, as_stream(stream),
                        cptr<bf16_t>(x), cptr<bf16_t>(dy), mptr<bf16_t>(dx), H, W, OH, OW, Cs, tv);
