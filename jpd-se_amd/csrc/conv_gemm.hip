@@ -388,6 +388,8 @@ int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w, void* fwd_
     if (int rc = check_launch("pack_fwd_toep_kernel")) return rc;
   }
   if (dgrad_pack) {
+    PackPhaseTable tab = {};
+    const long long esz = (long long)esize(d->dtype);
     for (int i = 0; i < p.nph; ++i) {
       const Phase& f = p.ph[i];
       const long long total = (long long)p.Cs * f.Uh * f.Lk;
@@ -404,15 +406,21 @@ int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w, void* fwd_
         if (int rc = check_launch("pack_dgrad_tile_kernel")) return rc;
         continue;
       }
+      // the other phases of the layer go into one launch below
+      const int q = tab.n++;
+      tab.first[q + 1] = tab.first[q] + total;
+      tab.out_off[q] = (long long)f.pack_off / esz;
+      tab.qh[q] = f.qh; tab.qw[q] = f.qw; tab.Uh[q] = f.Uh; tab.Uw[q] = f.Uw; tab.Lk[q] = f.Lk;
+    }
+    if (tab.n > 0) {
+      const long long total = tab.first[tab.n];
       if (d->dtype == JPDSE_BF16)
-        hipLaunchKernelGGL((pack_dgrad_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
-                           reinterpret_cast<bf16_t*>(out), d->K, p.Ks, d->C, p.Cs, d->R, d->S, d->stride, f.qh,
-                           f.qw, f.Uh, f.Uw, f.Lk, total);
+        hipLaunchKernelGGL((pack_dgrad_phases_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
+                           reinterpret_cast<bf16_t*>(dgrad_pack), d->K, p.Ks, d->C, p.Cs, d->R, d->S, d->stride, tab);
       else
-        hipLaunchKernelGGL((pack_dgrad_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
-                           reinterpret_cast<float*>(out), d->K, p.Ks, d->C, p.Cs, d->R, d->S, d->stride, f.qh, f.qw,
-                           f.Uh, f.Uw, f.Lk, total);
-      if (int rc = check_launch("pack_dgrad_kernel")) return rc;
+        hipLaunchKernelGGL((pack_dgrad_phases_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, s, w,
+                           reinterpret_cast<float*>(dgrad_pack), d->K, p.Ks, d->C, p.Cs, d->R, d->S, d->stride, tab);
+      if (int rc = check_launch("pack_dgrad_phases_kernel")) return rc;
     }
   }
   return JPDSE_OK;

@@ -601,13 +601,25 @@ __global__ void pack_fwd_toep_kernel(const float* __restrict__ w, T* __restrict_
   }
 }
 
-// one stride phase of the data-gradient panel: rows = input channels c, K-dim = (u', w', k)
+// data-gradient panel of a stride phase: rows = input channels c, K-dim = (u', w', k)
+// the stride phases of one layer in ONE launch (a stride-2 layer has four: PatchGAN layer 0 launched 16 of these 5-us kernels per step)
+struct PackPhaseTable {
+  long long first[5];          // element range [first[i], first[i + 1]) of the launch belongs to phase i
+  long long out_off[4];        // element offset of the phase's panel in `out`
+  int qh[4], qw[4], Uh[4], Uw[4], Lk[4];
+  int n;
+};
 template <typename T>
-__global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int Ks, int C, int Cs,
-                                  int R, int S, int st, int qh, int qw, int Uh, int Uw, int Lk,
-                                  long long total) {
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+__global__ void pack_dgrad_phases_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int Ks, int C, int Cs, int R,
+                                         int S, int st, const PackPhaseTable tab) {
+  const long long total = tab.first[tab.n];
+  for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    int ph = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < tab.n && g >= tab.first[i]) ph = i;
+    const long long idx = g - tab.first[ph];
+    const int Lk = tab.Lk[ph], Uh = tab.Uh[ph], Uw = tab.Uw[ph];
     const int j = (int)(idx % Lk);
     long long t = idx / Lk;
     const int up = (int)(t % Uh);
@@ -615,10 +627,10 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, T* __restrict__ o
     const int wp = j / Ks, k = j - wp * Ks;
     float v = 0.f;
     if (c < C && k < K && wp < Uw) {
-      const int r = qh + st * (Uh - 1 - up), s = qw + st * (Uw - 1 - wp);
+      const int r = tab.qh[ph] + st * (Uh - 1 - up), s = tab.qw[ph] + st * (Uw - 1 - wp);
       v = w[(((long long)k * R + r) * S + s) * C + c];
     }
-    ElemOps<T>::st(out + idx, v);
+    ElemOps<T>::st(out + tab.out_off[ph] + idx, v);
   }
 }
 
