@@ -257,9 +257,12 @@ def test_bf16_step_tracks_fp32():
   xd = omodel.synthetic_batch(2, 32, 64, seed=11)
   tr32.step(xd)
   tr16.step(xd)
+  ora.step(xd)                                   # the CPU oracle on the same weights and batch: the yardstick is not another HIP run
   for k in omodel.LOSS_NAMES:
-    a, b = tr16.last_losses[k], tr32.last_losses[k]
+    a, b, o = tr16.last_losses[k], tr32.last_losses[k], float(ora.last_losses[k])
     assert abs(a - b) <= 5e-2 * max(abs(b), 1e-3), (k, a, b)
+    assert abs(a - o) <= 5e-2 * max(abs(o), 1e-3), ('bf16 vs oracle', k, a, o)
+    assert abs(b - o) <= 1e-3 * max(abs(o), 1e-3), ('fp32 vs oracle', k, b, o)
 
 
 def test_bf16_full_width_fast_kernels_in_situ():
@@ -332,15 +335,24 @@ def test_bf16_local_enhancer_full_width_in_situ():
   cosine >= 0.85 (bf16 storage noise, see test_bf16_full_width_fast_kernels_in_situ) and norm within 6 %."""
   kw = dict(netG='local', ngf=32)
   xd = omodel.synthetic_batch(1, 128, 256, seed=33)
-  opt32 = _opts(**kw)
-  torch.manual_seed(77)
-  tr32 = get_trainer(opt32)(opt32, 'train')
+  tr32, ora, opt32 = _paired(kw, seed=77)          # HIP fp32 and the CPU oracle on the same seeded weights
   sdG = {k: v.detach().clone() for k, v in tr32.model.netG.state_dict().items()}     # state_dict() aliases the parameters
   sdD = {k: v.detach().clone() for k, v in tr32.model.netD.state_dict().items()}
+  oG, _oD = ora.grads_in_dtype(xd, torch.float32)
+  ora.step(xd)
   tr32.step(xd)
   g32 = {k: p.grad.detach().cpu().double().flatten() for k, p in tr32.model.netG.named_parameters() if k.endswith('.weight')}
   L32 = dict(tr32.last_losses)
   del tr32
+  # the fp32 HIP run is the yardstick for bf16 below: pin IT to the oracle at this width first (losses 1e-3; gradients by
+  # cosine and norm -- two correct fp32 implementations differ in the sign() gradients of the L1 terms, hence not element-wise)
+  cos0 = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
+  for k in omodel.LOSS_NAMES:
+    assert abs(L32[k] - ora.last_losses[k]) <= 1e-3 * max(abs(ora.last_losses[k]), 1e-3), ('fp32 vs oracle', k, L32[k], ora.last_losses[k])
+  for k, a in g32.items():
+    r = oG[k].detach().double().flatten()
+    assert cos0(a, r) >= 0.999 and abs(float(a.norm() / r.norm()) - 1.0) < 5e-3, \
+        '%s: fp32 HIP vs oracle weight gradient: cosine %.5f, norm ratio %.4f' % (k, cos0(a, r), float(a.norm() / r.norm()))
   opt16 = _opts(compute_dtype='bf16', **kw)
   tr16 = get_trainer(opt16)(opt16, 'train')
   tr16.model.netG.load_state_dict(sdG)
@@ -348,6 +360,7 @@ def test_bf16_local_enhancer_full_width_in_situ():
   tr16.step(xd)
   for k in omodel.LOSS_NAMES:
     assert abs(tr16.last_losses[k] - L32[k]) <= 2e-2 * max(abs(L32[k]), 1e-3), (k, tr16.last_losses[k], L32[k])
+    assert abs(tr16.last_losses[k] - ora.last_losses[k]) <= 2e-2 * max(abs(ora.last_losses[k]), 1e-3), ('bf16 vs oracle', k)
   cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
   for k, p in tr16.model.netG.named_parameters():
     if not k.endswith('.weight'):
