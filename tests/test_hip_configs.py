@@ -153,6 +153,41 @@ LAYERS_1024_THIN = [
 ]
 
 
+def test_1024x512_train_step_losses_vs_oracle():
+  """One whole train step at BASELINE.json's headline size (1024x512, global generator ngf 64, 2-scale PatchGAN, VGG; batch 1 so
+  that the CPU oracle finishes in seconds) against the oracle on the same seeded weights: the six losses of the fp32 HIP path
+  within 1e-3, of the bf16 path within 2e-2, and the post-Adam generator weights of the fp32 path within the sign-flip bound
+  (hip_step._check_weights' criterion: relative L2 <= 2e-3 per tensor)."""
+  kw = dict(use_compressed=True)
+  opt32 = _opts(**kw)
+  torch.manual_seed(4321)
+  ora = omodel.OracleTrainer(omodel.default_opt(**kw))
+  xd = omodel.synthetic_batch(1, 512, 1024, seed=17)
+  sdG = {k: v.detach().clone() for k, v in ora.G.items()}
+  sdD = {k: v.detach().clone() for k, v in ora.D.items()}
+  ora.step(xd)
+  got = {}
+  for dt in ('fp32', 'bf16'):
+    opt = _opts(compute_dtype=dt, **kw)
+    tr = get_trainer(opt)(opt, 'train')
+    tr.model.netG.load_state_dict(sdG)
+    tr.model.netD.load_state_dict(sdD)
+    tr.step(xd)
+    torch.cuda.synchronize()
+    got[dt] = dict(tr.last_losses)
+    tol = 1e-3 if dt == 'fp32' else 2e-2
+    for k in omodel.LOSS_NAMES:
+      o = float(ora.last_losses[k])
+      assert abs(got[dt][k] - o) <= tol * max(abs(o), 1e-3), ('%s vs oracle at 1024x512' % dt, k, got[dt][k], o)
+    if dt == 'fp32':
+      for k, v in tr.model.netG.state_dict().items():
+        if k.endswith('.weight'):
+          a, b = v.cpu().double(), ora.G[k].detach().double()
+          assert float((a - b).norm() / b.norm()) <= 2e-3, 'post-Adam %s: relative L2 %.3e' % (k, float((a - b).norm() / b.norm()))
+    del tr
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('case', LAYERS_1024_THIN, ids=[c[0] for c in LAYERS_1024_THIN])
 def test_1024x512_adjointness_thin_layers_bf16(case):
   assert _adjointness(*case), 'weight gradient not bit-reproducible'
