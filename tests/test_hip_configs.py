@@ -188,6 +188,30 @@ def test_1024x512_train_step_losses_vs_oracle():
     torch.cuda.empty_cache()
 
 
+def test_2048x1024_losses_vs_oracle():
+  """BASELINE config 5's size: the six losses of one 2048x1024 step (batch 1) against the oracle's forward on the same seeded
+  weights -- fp32 within 1e-3, bf16 within 2e-2 (the oracle runs the forward only: no CPU backward at this size)."""
+  kw = dict(use_compressed=True)
+  torch.manual_seed(8765)
+  ora = omodel.OracleTrainer(omodel.default_opt(**kw))
+  xd = omodel.synthetic_batch(1, 1024, 2048, seed=29)
+  sdG = {k: v.detach().clone() for k, v in ora.G.items()}
+  sdD = {k: v.detach().clone() for k, v in ora.D.items()}
+  with torch.no_grad():
+    ref = dict(zip(omodel.LOSS_NAMES, [float(v) for v in ora.train_losses(xd)]))
+  for dt, tol in (('fp32', 1e-3), ('bf16', 2e-2)):
+    opt = _opts(compute_dtype=dt, **kw)
+    tr = get_trainer(opt)(opt, 'train')
+    tr.model.netG.load_state_dict(sdG)
+    tr.model.netD.load_state_dict(sdD)
+    tr.step(xd)
+    torch.cuda.synchronize()
+    for k in omodel.LOSS_NAMES:
+      assert abs(tr.last_losses[k] - ref[k]) <= tol * max(abs(ref[k]), 1e-3), ('%s vs oracle at 2048x1024' % dt, k, tr.last_losses[k], ref[k])
+    del tr
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('case', LAYERS_1024_THIN, ids=[c[0] for c in LAYERS_1024_THIN])
 def test_1024x512_adjointness_thin_layers_bf16(case):
   assert _adjointness(*case), 'weight gradient not bit-reproducible'
