@@ -153,12 +153,13 @@ LAYERS_1024_THIN = [
 ]
 
 
-def test_1024x512_train_step_losses_vs_oracle():
-  """One whole train step at BASELINE.json's headline size (1024x512, global generator ngf 64, 2-scale PatchGAN, VGG; batch 1 so
-  that the CPU oracle finishes in seconds) against the oracle on the same seeded weights: the six losses of the fp32 HIP path
-  within 1e-3, of the bf16 path within 2e-2, and the post-Adam generator weights of the fp32 path within the sign-flip bound
-  (hip_step._check_weights' criterion: relative L2 <= 2e-3 per tensor)."""
-  kw = dict(use_compressed=True)
+@pytest.mark.parametrize('netG', ['global', 'local'])
+def test_1024x512_train_step_losses_vs_oracle(netG):
+  """One whole train step at BASELINE.json's headline size (1024x512, global generator ngf 64 -- and config 3's LocalEnhancer
+  ngf 32 --, 2-scale PatchGAN, VGG; batch 1 so that the CPU oracle finishes in seconds) against the oracle on the same seeded
+  weights: the six losses of the fp32 HIP path within 1e-3, of the bf16 path within 2e-2, and the post-Adam generator weights of
+  the fp32 path within the sign-flip bound (hip_step._check_weights' criterion: relative L2 <= 2e-3 per tensor)."""
+  kw = dict(use_compressed=True) if netG == 'global' else dict(use_compressed=True, netG='local', ngf=32)
   opt32 = _opts(**kw)
   torch.manual_seed(4321)
   ora = omodel.OracleTrainer(omodel.default_opt(**kw))
