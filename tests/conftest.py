@@ -14,6 +14,14 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+  # The CPU oracle runs small torch graphs; torch's default thread count is the host's core count (128 on the GPU boxes, of
+  # which a one-GPU job may use 16): oversubscribed, a 64x128 oracle step took 2.2 s there against 0.15 s on 8 threads.
+  try:
+    import torch
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)
+    torch.set_num_threads(max(1, min(16, n)))
+  except Exception:
+    pass
 
 
 @pytest.fixture(scope='session')
