@@ -153,8 +153,8 @@ LAYERS_1024_THIN = [
 ]
 
 
-@pytest.mark.parametrize('netG', ['global', 'local'])
-def test_1024x512_train_step_losses_vs_oracle(netG):
+@pytest.mark.parametrize('netG,batch', [('global', 4), ('local', 1)], ids=['global_batch4', 'local_batch1'])
+def test_1024x512_train_step_losses_vs_oracle(netG, batch):
   """One whole train step at BASELINE.json's headline size (1024x512, global generator ngf 64 -- and config 3's LocalEnhancer
   ngf 32 --, 2-scale PatchGAN, VGG; batch 1 so that the CPU oracle finishes in seconds) against the oracle on the same seeded
   weights: the six losses of the fp32 HIP path within 1e-3, of the bf16 path within 2e-2, and the post-Adam generator weights of
@@ -163,7 +163,7 @@ def test_1024x512_train_step_losses_vs_oracle(netG):
   opt32 = _opts(**kw)
   torch.manual_seed(4321)
   ora = omodel.OracleTrainer(omodel.default_opt(**kw))
-  xd = omodel.synthetic_batch(1, 512, 1024, seed=17)
+  xd = omodel.synthetic_batch(batch, 512, 1024, seed=17)
   sdG = {k: v.detach().clone() for k, v in ora.G.items()}
   sdD = {k: v.detach().clone() for k, v in ora.D.items()}
   ora.step(xd)
