@@ -154,7 +154,7 @@ LAYERS_1024_THIN = [
 
 
 @pytest.mark.parametrize('netG,batch', [('global', 4), ('local', 1)], ids=['global_batch4', 'local_batch1'])
-def test_1024x512_train_step_losses_vs_oracle(netG, batch):
+def test_1024x512_train_step_vs_oracle(netG, batch):
   """One whole train step at BASELINE.json's headline size (1024x512, global generator ngf 64 -- and config 3's LocalEnhancer
   ngf 32 --, 2-scale PatchGAN, VGG; batch 1 so that the CPU oracle finishes in seconds) against the oracle on the same seeded
   weights: the six losses of the fp32 HIP path within 1e-3, of the bf16 path within 2e-2, and the post-Adam generator weights of
@@ -166,8 +166,10 @@ def test_1024x512_train_step_losses_vs_oracle(netG, batch):
   xd = omodel.synthetic_batch(batch, 512, 1024, seed=17)
   sdG = {k: v.detach().clone() for k, v in ora.G.items()}
   sdD = {k: v.detach().clone() for k, v in ora.D.items()}
+  oG, oD = ora.grads_in_dtype(xd, torch.float32)          # every weight gradient of G and D at this size, from the oracle
   ora.step(xd)
   got = {}
+  cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
   for dt in ('fp32', 'bf16'):
     opt = _opts(compute_dtype=dt, **kw)
     tr = get_trainer(opt)(opt, 'train')
@@ -181,6 +183,14 @@ def test_1024x512_train_step_losses_vs_oracle(netG, batch):
       o = float(ora.last_losses[k])
       assert abs(got[dt][k] - o) <= tol * max(abs(o), 1e-3), ('%s vs oracle at 1024x512' % dt, k, got[dt][k], o)
     if dt == 'fp32':
+      # gradients (they are still in .grad after the step): two correct fp32 implementations differ in the sign() gradients of
+      # the L1 terms, so by direction and size rather than element-wise
+      for net, ref in ((tr.model.netG, oG), (tr.model.netD, oD)):
+        for k, p in net.named_parameters():
+          if k.endswith('.weight') and p.grad is not None and ref.get(k) is not None:
+            a, r = p.grad.detach().cpu().double().flatten(), ref[k].detach().double().flatten()
+            assert cos(a, r) >= 0.999 and abs(float(a.norm() / r.norm()) - 1.0) < 5e-3, \
+                '%s: fp32 weight gradient vs oracle at 1024x512: cosine %.5f, norm ratio %.4f' % (k, cos(a, r), float(a.norm() / r.norm()))
       for k, v in tr.model.netG.state_dict().items():
         if k.endswith('.weight'):
           a, b = v.cpu().double(), ora.G[k].detach().double()
