@@ -167,6 +167,12 @@ def test_1024x512_train_step_vs_oracle(netG, batch):
   sdG = {k: v.detach().clone() for k, v in ora.G.items()}
   sdD = {k: v.detach().clone() for k, v in ora.D.items()}
   oG, oD = ora.grads_in_dtype(xd, torch.float32)          # every weight gradient of G and D at this size, from the oracle
+  from oracle.ctu_cpu import nets as onets
+  onets.storage_bf16(True)                                 # the oracle with bf16 STORAGE of activations / activation gradients emulated:
+  try:                                                     # what any bf16 path loses against fp32 (test_hip_step.py, in-situ test)
+    eG, _eD = ora.grads_in_dtype(xd, torch.float32)
+  finally:
+    onets.storage_bf16(False)
   ora.step(xd)
   got = {}
   cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
@@ -182,6 +188,15 @@ def test_1024x512_train_step_vs_oracle(netG, batch):
     for k in omodel.LOSS_NAMES:
       o = float(ora.last_losses[k])
       assert abs(got[dt][k] - o) <= tol * max(abs(o), 1e-3), ('%s vs oracle at 1024x512' % dt, k, got[dt][k], o)
+    if dt == 'bf16':
+      # bf16 has no reference counterpart: at least as close to the fp32 oracle as the bf16-storage emulation, minus 0.03, and
+      # gradient norms within 6 %
+      for k, p in tr.model.netG.named_parameters():
+        if k.endswith('.weight') and p.grad is not None:
+          a = p.grad.detach().cpu().double().flatten()
+          r, e = oG[k].detach().double().flatten(), eG[k].detach().double().flatten()
+          assert cos(a, r) >= cos(e, r) - 0.03, '%s: bf16 vs fp32 oracle %.4f, emulation vs fp32 oracle %.4f' % (k, cos(a, r), cos(e, r))
+          assert abs(float(a.norm() / r.norm()) - 1.0) < 6e-2, '%s: bf16 gradient norm ratio %.4f' % (k, float(a.norm() / r.norm()))
     if dt == 'fp32':
       # gradients (they are still in .grad after the step): two correct fp32 implementations differ in the sign() gradients of
       # the L1 terms, so by direction and size rather than element-wise
