@@ -185,9 +185,13 @@ def test_1024x512_train_step_vs_oracle(netG, batch):
     torch.cuda.synchronize()
     got[dt] = dict(tr.last_losses)
     tol = 1e-3 if dt == 'fp32' else 2e-2
+    worst = 0.0
     for k in omodel.LOSS_NAMES:
       o = float(ora.last_losses[k])
+      worst = max(worst, abs(got[dt][k] - o) / max(abs(o), 1e-3))
       assert abs(got[dt][k] - o) <= tol * max(abs(o), 1e-3), ('%s vs oracle at 1024x512' % dt, k, got[dt][k], o)
+    from hip_util import record
+    record('%s %s losses vs oracle, whole step at 1024x512 batch %d (relative)' % (netG, dt, batch), worst, tol)
     if dt == 'bf16':
       # bf16 has no reference counterpart: at least as close to the fp32 oracle as the bf16-storage emulation, minus 0.03, and
       # gradient norms within 6 %
@@ -197,6 +201,8 @@ def test_1024x512_train_step_vs_oracle(netG, batch):
           r, e = oG[k].detach().double().flatten(), eG[k].detach().double().flatten()
           assert cos(a, r) >= cos(e, r) - 0.03, '%s: bf16 vs fp32 oracle %.4f, emulation vs fp32 oracle %.4f' % (k, cos(a, r), cos(e, r))
           assert abs(float(a.norm() / r.norm()) - 1.0) < 6e-2, '%s: bf16 gradient norm ratio %.4f' % (k, float(a.norm() / r.norm()))
+          record('%s bf16 weight gradients vs fp32 oracle: (emulation cosine - HIP cosine), worst layer' % netG, cos(e, r) - cos(a, r), 0.03, k)
+          record('%s bf16 weight gradients vs fp32 oracle: |norm ratio - 1|, worst layer' % netG, abs(float(a.norm() / r.norm()) - 1.0), 6e-2, k)
     if dt == 'fp32':
       # gradients (they are still in .grad after the step): two correct fp32 implementations differ in the sign() gradients of
       # the L1 terms, so by direction and size rather than element-wise
@@ -204,8 +210,11 @@ def test_1024x512_train_step_vs_oracle(netG, batch):
         for k, p in net.named_parameters():
           if k.endswith('.weight') and p.grad is not None and ref.get(k) is not None:
             a, r = p.grad.detach().cpu().double().flatten(), ref[k].detach().double().flatten()
-            assert cos(a, r) >= 0.999 and abs(float(a.norm() / r.norm()) - 1.0) < 5e-3, \
+            # bounds ~10x the measured 1.6e-5 / 1.5e-4 (profiles/r03_parity_report.txt)
+            assert cos(a, r) >= 1.0 - 2e-4 and abs(float(a.norm() / r.norm()) - 1.0) < 1.5e-3, \
                 '%s: fp32 weight gradient vs oracle at 1024x512: cosine %.5f, norm ratio %.4f' % (k, cos(a, r), float(a.norm() / r.norm()))
+            record('%s fp32 weight gradients vs oracle: 1 - cosine, worst layer' % netG, 1.0 - cos(a, r), 2e-4, k)
+            record('%s fp32 weight gradients vs oracle: |norm ratio - 1|, worst layer' % netG, abs(float(a.norm() / r.norm()) - 1.0), 1.5e-3, k)
       for k, v in tr.model.netG.state_dict().items():
         if k.endswith('.weight'):
           a, b = v.cpu().double(), ora.G[k].detach().double()
