@@ -223,17 +223,21 @@ def test_1024x512_train_step_vs_oracle(netG, batch):
     torch.cuda.empty_cache()
 
 
-def test_2048x1024_losses_vs_oracle():
+def test_2048x1024_step_vs_oracle():
   """BASELINE config 5's size: the six losses of one 2048x1024 step (batch 1) against the oracle's forward on the same seeded
-  weights -- fp32 within 1e-3, bf16 within 2e-2 (the oracle runs the forward only: no CPU backward at this size)."""
+  weights -- fp32 within 1e-3, bf16 within 2e-2 -- and the generator weight gradients of the fp32 path against the oracle's
+  (1 - cosine <= 2e-4, norm within 1.5e-3)."""
   kw = dict(use_compressed=True)
   torch.manual_seed(8765)
   ora = omodel.OracleTrainer(omodel.default_opt(**kw))
   xd = omodel.synthetic_batch(1, 1024, 2048, seed=29)
   sdG = {k: v.detach().clone() for k, v in ora.G.items()}
   sdD = {k: v.detach().clone() for k, v in ora.D.items()}
+  oG, _oD = ora.grads_in_dtype(xd, torch.float32)          # generator weight gradients of the oracle at this size
   with torch.no_grad():
     ref = dict(zip(omodel.LOSS_NAMES, [float(v) for v in ora.train_losses(xd)]))
+  from hip_util import record
+  cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
   for dt, tol in (('fp32', 1e-3), ('bf16', 2e-2)):
     opt = _opts(compute_dtype=dt, **kw)
     tr = get_trainer(opt)(opt, 'train')
@@ -241,8 +245,18 @@ def test_2048x1024_losses_vs_oracle():
     tr.model.netD.load_state_dict(sdD)
     tr.step(xd)
     torch.cuda.synchronize()
+    worst = 0.0
     for k in omodel.LOSS_NAMES:
+      worst = max(worst, abs(tr.last_losses[k] - ref[k]) / max(abs(ref[k]), 1e-3))
       assert abs(tr.last_losses[k] - ref[k]) <= tol * max(abs(ref[k]), 1e-3), ('%s vs oracle at 2048x1024' % dt, k, tr.last_losses[k], ref[k])
+    record('%s losses vs oracle, whole step at 2048x1024 batch 1 (relative)' % dt, worst, tol)
+    if dt == 'fp32':
+      for k, p in tr.model.netG.named_parameters():
+        if k.endswith('.weight') and p.grad is not None:
+          a, r = p.grad.detach().cpu().double().flatten(), oG[k].detach().double().flatten()
+          assert cos(a, r) >= 1.0 - 2e-4 and abs(float(a.norm() / r.norm()) - 1.0) < 1.5e-3, \
+              '%s: fp32 weight gradient vs oracle at 2048x1024: cosine %.6f, norm ratio %.5f' % (k, cos(a, r), float(a.norm() / r.norm()))
+          record('fp32 weight gradients vs oracle at 2048x1024: 1 - cosine, worst layer', 1.0 - cos(a, r), 2e-4, k)
     del tr
     torch.cuda.empty_cache()
 
