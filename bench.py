@@ -66,9 +66,11 @@ def parse():
                        'the multi-rank schedule on a box with fewer GPUs than ranks (with --share-gpu)')
   ap.add_argument('--share-gpu', action='store_true',
                   help='rehearsal: ranks take device LOCAL_RANK %% device_count (several ranks per GPU; needs --backend gloo)')
-  ap.add_argument('--bf16-reduce', action='store_true',
-                  help='all-reduce the gradients in bf16 (half the xGMI bytes) instead of fp32; reported next to the fp32 '
-                       'reduce (SURVEY.md 8d config 4)')
+  ap.add_argument('--grad-reduce', default='auto', choices=['auto', 'bf16', 'fp32'],
+                  help='N > 1: wire dtype of the gradient all-reduce.  auto (default) = bf16 -- half the xGMI bytes, one rounding '
+                       'of each rank\'s contribution and of the sum -- and the SAME run then repeats the timed steps on an fp32 '
+                       'wire and prints that figure next to it as "fp32_wire" (SURVEY.md 8d config 4 asks for both)')
+  ap.add_argument('--bf16-reduce', action='store_true', help='same as --grad-reduce bf16 (kept for round-2/3 command lines)')
   ap.add_argument('--ddp-overlap', default='d_backward', choices=['d_backward', 'layers'],
                   help='N > 1: the generator gradient all-reduce overlaps the discriminator backward (default) or is fired '
                        'layer by layer from the backward hooks (round 1-2 behaviour); same results')
@@ -82,7 +84,7 @@ def make_opt(args, device_index):
   from ctu.utils.synthetic import default_opt
   kw = dict(gpu_ids=[device_index], print_losses=False, compute_dtype=args.dtype, use_compressed=True,
             netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch,
-            bf16_grad_reduce=args.bf16_reduce, ddp_overlap=args.ddp_overlap)
+            bf16_grad_reduce=(args.bf16_reduce or args.grad_reduce in ('auto', 'bf16')), ddp_overlap=args.ddp_overlap)
   if args.no_vgg:
     kw.update(no_vgg_loss=True, skip_unused_losses=True)
   return default_opt(**kw)
@@ -267,17 +269,53 @@ def main():
   # In-library kernel timers (hipEvent pairs on the kernels' own stream, inside the timed region).  Every event costs the
   # stream ~3.7 us (measured round 3: 296 events per step = 1.1 ms of a 26.3 ms step), so they cover the FIRST
   # step of the timed region only -- one step holds 36 ResnetBlock GEMM launches, 18 weight gradients, 72 norm calls.
-  timed_steps = 0 if args.no_kernel_timers else min(1, args.steps)
+  # Round 4: the ResnetBlock GEMM regions -- the headline `roofline` fractions -- are sampled on the first
+  # THREE timed steps (3 x 72 regions = 432 events = 1.6 ms spread over the timed region: 0.08 ms per step at the driver's 20
+  # steps), the HBM regions on the first step (148 events = 0.55 ms); `kernel_timers` in the output says so.
+  timed_steps = 0 if args.no_kernel_timers else min(3, args.steps)
+  hbm_steps = 0 if args.no_kernel_timers else min(1, args.steps)
   tsteps = max(timed_steps, 1)
+  hsteps = max(hbm_steps, 1)
   if timed_steps:
     check(L.jpdse_prof_select(1, 1024, 9216, 72 * timed_steps), 'prof_select')        # 36 halo + 18 ring + 18 wgrad regions per step
-    check(L.jpdse_prof_hbm_select(1, 74 * timed_steps), 'prof_hbm_select')           # 72 norm calls + 2 Adams per step
+    check(L.jpdse_prof_hbm_select(1, 74 * hbm_steps), 'prof_hbm_select')             # 72 norm calls + 2 Adams per step
+  if world > 1:
+    trainer.model.ddp_timeline = []          # per-step timing events of the data-parallel schedule (7 events per step)
   barrier()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     trainer.step(xd)
   barrier()
   elapsed = time.perf_counter() - t0
+  ddp_info = None
+  if world > 1:
+    tl, trainer.model.ddp_timeline = trainer.model.ddp_timeline, None
+    mean = lambda a, b: sum(t[a].elapsed_time(t[b]) for t in tl) / max(len(tl), 1)
+    bg = trainer.model.grad_buckets.get('G')
+    ddp_info = dict(overlap=args.ddp_overlap, g_buckets=len(bg.buckets) if bg is not None else 0,
+                    g_bytes=bg.total_bytes() if bg is not None else 0,
+                    d_backward_ms=round(mean('g_bwd_end', 'd_bwd_end'), 3),
+                    g_allreduce_exposed_ms=round(mean('d_bwd_end', 'g_reduced'), 3),
+                    d_allreduce_exposed_ms=round(mean('adam_g_end', 'd_reduced'), 3),
+                    note='compute-stream events; exposed = what the compute stream waited for the collective beyond the work '
+                         'it overlaps (DESIGN.md 6 budget: <= 1.5 ms per step at 8 GPUs on the bf16 wire)')
+  # N > 1, --grad-reduce auto: the same K steps again on an fp32 wire (twice the xGMI bytes), reported next to the bf16 figure
+  fp32_wire = None
+  if world > 1 and args.grad_reduce == 'auto' and not args.bf16_reduce:
+    trainer.enable_data_parallel(reduce_dtype=None)
+    for _ in range(max(1, min(2, args.warmup))):
+      trainer.step(xd)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+      trainer.step(xd)
+    barrier()
+    e2 = time.perf_counter() - t1
+    t = torch.tensor([e2], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    e2 = float(t.item())
+    fp32_wire = dict(value=round(args.batch * world * args.steps / e2, 4), ms_per_step=round(1e3 * e2 / args.steps, 3),
+                     steps=args.steps, note='same process, same weights, gradient all-reduce on an fp32 wire')
   ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
   extra = {}
   for cls, name in ((1, 'ring'), (2, 'wgrad')):      # the other two regions of the same layer, before the log is reset
@@ -346,11 +384,11 @@ def main():
       roof_hbm = dict(bound='hbm', kernel='InstanceNorm + activation (+ residual): moment / finalize / apply and register-held kernels, '
                                            'forward and backward (norm.hip)',
                       achieved=gbs(nb, nt), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nb / (nt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                      traffic=None, calls_per_step=(hbm['inorm_fwd'][2] + hbm['inorm_bwd'][2]) / tsteps,
-                      ms_per_step=round(nt / tsteps, 4), algorithmic_bytes_per_step=nb / tsteps,
-                      forward=dict(achieved=gbs(hbm['inorm_fwd'][1], hbm['inorm_fwd'][0]), ms_per_step=round(hbm['inorm_fwd'][0] / tsteps, 4)),
-                      backward=dict(achieved=gbs(hbm['inorm_bwd'][1], hbm['inorm_bwd'][0]), ms_per_step=round(hbm['inorm_bwd'][0] / tsteps, 4)),
-                      adam=dict(achieved=gbs(hbm['adam'][1], hbm['adam'][0]), ms_per_step=round(hbm['adam'][0] / tsteps, 4),
+                      traffic=None, calls_per_step=(hbm['inorm_fwd'][2] + hbm['inorm_bwd'][2]) / hsteps,
+                      ms_per_step=round(nt / hsteps, 4), algorithmic_bytes_per_step=nb / hsteps,
+                      forward=dict(achieved=gbs(hbm['inorm_fwd'][1], hbm['inorm_fwd'][0]), ms_per_step=round(hbm['inorm_fwd'][0] / hsteps, 4)),
+                      backward=dict(achieved=gbs(hbm['inorm_bwd'][1], hbm['inorm_bwd'][0]), ms_per_step=round(hbm['inorm_bwd'][0] / hsteps, 4)),
+                      adam=dict(achieved=gbs(hbm['adam'][1], hbm['adam'][0]), ms_per_step=round(hbm['adam'][0] / hsteps, 4),
                                 frac=round(hbm['adam'][1] / (hbm['adam'][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hbm['adam'][0] > 0 else None))
       tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
       if (os.path.exists(tpath) and (args.netG, args.width, args.height, args.batch, args.dtype) == ('global', 1024, 512, 4, 'bf16')):
@@ -374,14 +412,17 @@ def main():
                                'Adam x2, batch %d/GPU' % (args.width, args.height, args.netG, opt.ngf,
                                                           '' if args.no_vgg else 'VGG19+', args.batch),
                    'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                   'grad_reduce': ('bf16' if args.bf16_reduce else 'fp32') if world > 1 else None,
+                   'grad_reduce': ('bf16' if (args.bf16_reduce or args.grad_reduce in ('auto', 'bf16')) else 'fp32') if world > 1 else None,
                    'step_mfma_frac': (round(f_alg * value / 1e3 / peak, 4) if f_alg else None),
                    'f_alg_gflop_per_image': f_alg},
         'roofline': roof,
         'roofline_resblock_all_passes': roof_all,
         'roofline_hbm': roof_hbm,
-        'kernel_timers': {'steps_covered': timed_steps, 'of_timed_steps': args.steps,
-                          'note': 'hipEvent pairs inside the timed region, first steps only (each event costs the stream ~3.7 us)'},
+        'kernel_timers': {'steps_covered': timed_steps, 'hbm_steps_covered': hbm_steps, 'of_timed_steps': args.steps,
+                          'note': 'hipEvent pairs inside the timed region: ResnetBlock GEMM regions on the first 3 steps, '
+                                  'norm / Adam regions on the first (each event costs the stream ~3.7 us: ~2.1 ms in all)'},
+        'multi_gpu': ({'ddp': ddp_info, 'fp32_wire': fp32_wire} if world > 1 else
+                      'N = 1: no collective ran; the 1/2/4/8-GPU curve needs the driver\'s 8-GPU node (python bench.py --gpus N)'),
     }
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(args)

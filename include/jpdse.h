@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define JPDSE_ABI_VERSION 1
+#define JPDSE_ABI_VERSION 2   /* 2 (round 4): + jpdse_conv_dgrad_nsum_slots / _fused_nsums, jpdse_inorm_bwd_from_sums; round 3 had already added
+                                * jpdse_loss_finalize, jpdse_conv_fwd_pool, jpdse_conv_dgrad_fused_lrelu, jpdse_input_builder, jpdse_copy, jpdse_prof_hbm_* under version 1 */
 
 enum { JPDSE_F32 = 0, JPDSE_BF16 = 1 };
 enum { JPDSE_PAD_ZERO = 0, JPDSE_PAD_REFLECT = 1 };
@@ -116,13 +117,15 @@ int jpdse_conv_pack_weights(const jpdse_conv_desc* d, const float* w_krsc, void*
 /* Batched re-packing of the data-gradient panels of many layers in ONE launch (per optimizer step every
  * conv of the stepped network needs a fresh panel).  jpdse_conv_pack_entries (host only, no GPU work)
  * appends one entry per stride phase of layer `d` to `out` and returns their number, or -1 when the
- * layer cannot be batched (fp32, or a phase whose panel rows are padded): use jpdse_conv_pack_weights
+ * layer cannot be batched (a phase whose panel rows are padded): use jpdse_conv_pack_weights
  * for those.  The caller fills `block0` with the running sum of `blocks` over its whole table, uploads
  * the table once and calls jpdse_conv_pack_run(table_dev, n, total_blocks) after each optimizer step. */
 typedef struct jpdse_pack_entry {
   const float* w;   /* fp32 KRSC master */
   void* out;        /* this phase's panel inside the layer's dgrad pack */
   int32_t K, Ks, C, Cs, R, S, st, qh, qw, Uh, Uw, Lk, gx, gy;
+  int32_t out_f32;  /* 1: the panel is fp32 (JPDSE_F32 layers), 0: bf16 (ABI version 2) */
+  int32_t reserved_;
   int64_t blocks;   /* thread blocks this entry needs */
   int64_t block0;   /* first block of this entry in the launch */
 } jpdse_pack_entry;
@@ -174,6 +177,17 @@ int jpdse_conv_dgrad_fused(const jpdse_conv_desc* d, const void* dy, const void*
 int jpdse_conv_dgrad_fused_lrelu(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack,
                                  const void* x, float slope, const void* addend, void* dx, void* ws,
                                  size_t ws_bytes, void* stream);
+/* jpdse_conv_dgrad_fused whose output dx is the gradient w.r.t. the OUTPUT of an InstanceNorm2d (+ activation): the chains
+ * conv -> InstanceNorm -> ReLU -> [pad] conv and x + conv_block(x) of ResnetBlock (networks.py:283-305).  The norm's backward
+ * needs, per (image, channel), sum dz and sum dz * yhat with yhat = (norm_x - mean) rstd and dz = dx act'(yhat); the epilogue
+ * that writes dx forms them per block from the values it stores and norm_x (the norm's INPUT, same shape as dx), norm_stats
+ * ([N][CPAD(C)][2] = (mean, rstd) of jpdse_inorm_fwd) and writes sums [N][CPAD(C)][slots][2], slots =
+ * jpdse_conv_dgrad_nsum_slots(d) (0: this layer's data-gradient kernel has no such epilogue -- use jpdse_conv_dgrad_fused +
+ * jpdse_inorm_bwd).  jpdse_inorm_bwd_from_sums then replaces jpdse_inorm_bwd's own pass over (x, dy) for the sums. */
+int32_t jpdse_conv_dgrad_nsum_slots(const jpdse_conv_desc* d);
+int jpdse_conv_dgrad_fused_nsums(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, const void* x,
+                                 const void* addend, void* dx, const void* norm_x, const float* norm_stats,
+                                 int32_t norm_act, float norm_slope, float* sums, void* ws, size_t ws_bytes, void* stream);
 /* dw (fp32, KRSC master layout) = d(loss)/d(w); overwritten (beta = 0) */
 int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw_krsc,
                      void* ws, size_t ws_bytes, void* stream);
@@ -211,6 +225,11 @@ int jpdse_inorm_fwd(const jpdse_inorm_desc* d, const void* x, const void* residu
  * fixed order --, then the apply pass. */
 int jpdse_inorm_fwd_from_moments(const jpdse_inorm_desc* d, const void* x, const float* moments, int32_t slots,
                                  const void* residual, void* y, float* stats, void* stream);
+/* jpdse_inorm_bwd with the per-channel sums taken from the per-block slots a data-gradient epilogue wrote
+ * (jpdse_conv_dgrad_fused_nsums): the slots of each (image, channel) are added in slot order, then the apply pass.
+ * ws: jpdse_inorm_workspace_size(d) bytes. */
+int jpdse_inorm_bwd_from_sums(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy,
+                              const float* sums, int32_t slots, void* dx, void* ws, size_t ws_bytes, void* stream);
 /* dx from (x, stats, dy); the residual branch's gradient is dy itself */
 int jpdse_inorm_bwd(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy,
                     void* dx, void* ws, size_t ws_bytes, void* stream);

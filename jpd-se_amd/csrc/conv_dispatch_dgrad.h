@@ -160,10 +160,31 @@ __global__ void relu_mask_kernel(T* __restrict__ dx, const T* __restrict__ mask,
   }
 }
 
+// The InstanceNorm (+ activation) whose backward consumes this data gradient (jpdse_conv_dgrad_fused_nsums): its input, its
+// (mean, rstd), its activation, and where the per-block sums of its backward go (gemm_halo.h NSUM).
+struct NormSink {
+  const void* x;
+  const float* stats;
+  float* sums;
+  int act;
+  float slope;
+};
+
+// blocks per image whose norm-backward sums the data gradient of this layer writes (0: its kernel has no such epilogue):
+// the reflect-padded 3x3 convs on the folded-frame halo kernel with 128-channel output tiles -- the ResnetBlock convs
+static int dgrad_nsum_slots(const jpdse_conv_desc* d, const ConvPlan& p) {
+  if (d->dtype != JPDSE_BF16 || d->pad_mode != JPDSE_PAD_REFLECT || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1) return 0;
+  if (!g_ring_enabled || !g_ring_virt || d->H < 8 || p.ph[0].Lk != 3 * p.Ks || p.Ks < 128 || p.Cs <= 64 || p.Cs % 128 != 0 || d->C != p.Cs) return 0;
+  if (!halo_ok(3, 3, 1, d->H, d->W, p.Ks, p.Cs)) return 0;
+  return (d->H / 4) * (d->W / 64);
+}
+
 template <typename T>
 static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* dy, const void* pack, void* dx,
                         void* ws, hipStream_t s, const void* mask = nullptr, const void* addend = nullptr, float* mom = nullptr,
-                        float mask_slope = 0.f) {
+                        float mask_slope = 0.f, const NormSink* sink = nullptr) {
+  if (sink != nullptr && (sizeof(T) != 2 || dgrad_nsum_slots(d, p) == 0 || (mask != nullptr && mask_slope != 0.f)))
+    return set_error(JPDSE_EINVAL, "conv_dgrad: this layer's data-gradient kernel writes no norm-backward sums (jpdse_conv_dgrad_nsum_slots == 0)");
   char* wsb = reinterpret_cast<char*>(ws);
   void* dyp = wsb;
   void* dxp = wsb + p.dypad_bytes;
@@ -325,6 +346,14 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
         if (rc) return rc;
         h.V = frame;
         h.mask = reinterpret_cast<const bf16_t*>(mask);
+        if (sink != nullptr) {
+          h.nx = reinterpret_cast<const bf16_t*>(sink->x);
+          h.nstats = sink->stats;
+          h.nsums = sink->sums;
+          h.nact = sink->act;
+          h.nslope = sink->slope;
+          h.mom_slots = (d->H / 4) * (d->W / 64);
+        }
         return p.Cs > 64 ? launch_halo_cfg<2>(h, s) : launch_halo_cfg<1>(h, s);
       }
       if (ring_halo)
@@ -643,6 +672,8 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
     }
     a.act = JPDSE_ACT_NONE;
     a.slope = 0.f;
+    a.partial = reinterpret_cast<float*>(wsb + p.splitk_off);     // split-K slabs, reused by the phases (stream order)
+    a.partial_cap = p.splitk_bytes;
     rc = launch_fwd<T>(a, s);
     if (rc) return rc;
   }

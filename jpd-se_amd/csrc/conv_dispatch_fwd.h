@@ -333,6 +333,8 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
   a.out_base = 0;
   a.act = d->act;
   a.slope = d->slope;
+  a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + p.splitk_off);   // split-K slabs (fp32 layers with few tiles)
+  a.partial_cap = p.splitk_bytes;
   return launch_fwd<T>(a, s);
 }
 

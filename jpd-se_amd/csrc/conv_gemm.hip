@@ -46,6 +46,13 @@ struct GemmFwdArgs {
   int act;
   float slope;
   int col_mod, k_real;   // col_mod > 0: GEMM column -> channel (col % col_mod), live when < k_real (Toeplitz head)
+  // split-K (round 4; small M: fewer tiles than CUs -- the fp32 layers of BASELINE config 2 at 512x256 batch 1): block
+  // (tile, blockIdx.y = split) reduces K-chunks [T*split/splits, T*(split+1)/splits) and stores its fp32 partial tile into slab
+  // `split` of `partial` ([splits][M][Ks]); gemm_splitk_finish_kernel adds the slabs in index order (deterministic) and applies
+  // bias + activation.  splits is chosen by the launcher (generic_splitk_for); partial_cap = bytes available behind `partial`.
+  int splits;
+  float* partial;
+  size_t partial_cap;
 };
 
 struct GemmWgradArgs {
@@ -182,6 +189,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_tapsum_enabled = enable != 13;    // 13: narrow-output layers without the tap-sum forward (A/B)
   g_thin_out_fast = enable != 13;     // 13: narrow-output long-K layers on the generic kernel (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
+  g_generic_splitk = enable != 48;    // 48: fp32 generic kernel without split-K (A/B; BASELINE config 2)
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
   return JPDSE_OK;
 }
@@ -316,7 +324,7 @@ size_t jpdse_conv_workspace_size(const jpdse_conv_desc* d) {
 int jpdse_conv_pack_entries(const jpdse_conv_desc* d, const float* w, void* dgrad_pack, jpdse_pack_entry* out,
                             int32_t max_entries) {
   if (validate(d)) return -1;
-  if (d->dtype != JPDSE_BF16 || w == nullptr || dgrad_pack == nullptr || out == nullptr) return -1;
+  if (w == nullptr || dgrad_pack == nullptr || out == nullptr) return -1;
   ConvPlan p;
   make_plan(d, &p);
   int n = 0;
@@ -331,6 +339,7 @@ int jpdse_conv_pack_entries(const jpdse_conv_desc* d, const float* w, void* dgra
     e.K = d->K; e.Ks = p.Ks; e.C = d->C; e.Cs = p.Cs; e.R = d->R; e.S = d->S; e.st = d->stride;
     e.qh = f.qh; e.qw = f.qw; e.Uh = f.Uh; e.Uw = f.Uw; e.Lk = f.Lk;
     e.gx = (p.Cs + 63) / 64; e.gy = (p.Ks + 63) / 64;
+    e.out_f32 = d->dtype == JPDSE_F32 ? 1 : 0;
     e.blocks = e.gx * e.gy * f.Uh * f.Uw;
     e.block0 = 0;            // filled by the caller (prefix sum over its whole table)
     out[n++] = e;
@@ -541,6 +550,31 @@ int jpdse_conv_dgrad_fused_lrelu(const jpdse_conv_desc* d, const void* dy, const
   return d->dtype == JPDSE_BF16
              ? conv_dgrad_t<bf16_t>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x, addend, nullptr, slope)
              : conv_dgrad_t<float>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x, addend, nullptr, slope);
+}
+
+int32_t jpdse_conv_dgrad_nsum_slots(const jpdse_conv_desc* d) {
+  if (validate(d)) return 0;
+  ConvPlan p;
+  make_plan(d, &p);
+  return dgrad_nsum_slots(d, p);
+}
+
+int jpdse_conv_dgrad_fused_nsums(const jpdse_conv_desc* d, const void* dy, const void* dgrad_pack, const void* x,
+                                 const void* addend, void* dx, const void* norm_x, const float* norm_stats, int32_t norm_act,
+                                 float norm_slope, float* sums, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = validate(d)) return rc;
+  JPDSE_REQUIRE(dy && dgrad_pack && dx && norm_x && norm_stats && sums, "conv_dgrad_fused_nsums: null pointer");
+  JPDSE_REQUIRE(norm_act == JPDSE_ACT_NONE || norm_act == JPDSE_ACT_RELU || norm_act == JPDSE_ACT_LRELU,
+                "conv_dgrad_fused_nsums: activation %d", norm_act);
+  ConvPlan p;
+  make_plan(d, &p);
+  JPDSE_REQUIRE(d->dtype == JPDSE_BF16 && dgrad_nsum_slots(d, p) > 0,
+                "conv_dgrad_fused_nsums: this layer has no norm-backward-sum epilogue (jpdse_conv_dgrad_nsum_slots == 0)");
+  const size_t need = jpdse_conv_workspace_size(d);
+  if (ws == nullptr || ws_bytes < need)
+    return set_error(JPDSE_EWORKSPACE, "conv_dgrad_fused_nsums: workspace %zu < %zu", ws_bytes, need);
+  const NormSink sink = {norm_x, norm_stats, sums, norm_act, norm_slope};
+  return conv_dgrad_t<bf16_t>(d, p, dy, dgrad_pack, dx, ws, as_stream(stream), x, addend, nullptr, 0.f, &sink);
 }
 
 int jpdse_conv_wgrad(const jpdse_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes,

@@ -173,24 +173,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArg
   f32x16 master[(sizeof(T) == 4) ? TM : 1][(sizeof(T) == 4) ? TN : 1];
   using TL = TwoLevel<T, (sizeof(T) == 4) ? TM : 1, (sizeof(T) == 4) ? TN : 1>;
   if constexpr (sizeof(T) == 4) TL::init(master);
-  const int T_total = a.R * a.cpr;
+  const int T_all = a.R * a.cpr;
+  const int split = a.splits > 1 ? (int)blockIdx.y : 0;
+  const int t_begin = a.splits > 1 ? (int)((long long)T_all * split / a.splits) : 0;
+  const int T_total = a.splits > 1 ? (int)((long long)T_all * (split + 1) / a.splits) : T_all;   // end of this block's chunk range
   const long long a_row_bytes = a.in_sr * ES;
   u32x4 areg[AV], breg[BV];
-  // chunk 0
+  int r = t_begin / a.cpr, jc = t_begin - r * a.cpr;
+  // first chunk of the range
   {
+    const long long a_off = (long long)r * a_row_bytes + (long long)jc * 64;
+    const long long b_off = (long long)t_begin * 64;
 #pragma unroll
-    for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4*>(a_ptr[i]);
+    for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + a_off);
 #pragma unroll
-    for (int i = 0; i < BV; ++i) breg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i]);
+    for (int i = 0; i < BV; ++i) breg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + b_off);
 #pragma unroll
     for (int i = 0; i < AV; ++i) *reinterpret_cast<u32x4*>(As + a_lds[i]) = areg[i];
 #pragma unroll
     for (int i = 0; i < BV; ++i) *reinterpret_cast<u32x4*>(Bs + b_lds[i]) = breg[i];
   }
   __syncthreads();
-  int r = 0, jc = 0;
-  for (int t = 0; t < T_total; ++t) {
-    const int cur = t & 1;
+  for (int t = t_begin; t < T_total; ++t) {
+    const int cur = (t - t_begin) & 1;
     const bool more = (t + 1) < T_total;
     if (more) {
       if (++jc == a.cpr) { jc = 0; ++r; }
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArg
       for (int i = 0; i < BV; ++i) breg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + b_off);
     }
     MmaChunk<T, TM, TN>::run(As + cur * BM * 64, Bs + cur * BN * 64, a_rd, b_rd, acc);
-    if constexpr (sizeof(T) == 4) TL::flush(t, acc, master);
+    if constexpr (sizeof(T) == 4) TL::flush(t - t_begin, acc, master);
     if (more) {
       char* const An = As + (cur ^ 1) * BM * 64;
       char* const Bn = Bs + (cur ^ 1) * BN * 64;
@@ -215,6 +220,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArg
   }
 
   if constexpr (sizeof(T) == 4) TL::finish(acc, master);
+  if (a.splits > 1) {
+    // split-K: the raw fp32 partial tile into this split's slab (plain stores; gemm_splitk_finish_kernel sums the slabs)
+    float* const slab = a.partial + (long long)split * a.M * a.Ks;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      if (col >= a.Ks) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          if (m < a.M) slab[(long long)m * a.Ks + col] = acc[i][j][e];
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: bias + activation, NHWC store through the output addressing -------------
   long long* const row_off = reinterpret_cast<long long*>(smem);
   for (int row = tid; row < BM; row += NT) {
@@ -246,6 +269,38 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArg
         ElemOps<T>::st(Y + off + col, v);
       }
     }
+  }
+}
+
+// Sum of the split-K slabs of gemm_fwd_kernel (index order: deterministic) + bias + activation -> output, 4 columns per
+// thread (Ks is a multiple of 8).  Slabs are read four at a time before they are added (one round trip per group).
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const GemmFwdArgs a, long long total_vec) {
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= total_vec) return;
+  const int vpr = a.Ks >> 2;
+  const int m = (int)(v / vpr), c0 = (int)(v % vpr) * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* const base = a.partial + (long long)m * a.Ks + c0;
+  const long long slab_elems = (long long)a.M * a.Ks;
+  int sidx = 0;
+  for (; sidx + 4 <= a.splits; sidx += 4) {
+    f32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(base + (sidx + u) * slab_elems);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += t[u];
+  }
+  for (; sidx < a.splits; ++sidx) acc += *reinterpret_cast<const f32x4*>(base + sidx * slab_elems);
+  const int ow = m % a.OW, t = m / a.OW, oh = t % a.OH, n = t / a.OH;
+  const long long off = a.out_base + n * a.out_sn + oh * a.out_sh + ow * a.out_sw;
+  T* const Y = reinterpret_cast<T*>(a.Y);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int col = c0 + e;
+    const bool live = col < a.Kout;
+    const float bv = (a.bias != nullptr && live) ? a.bias[col] : 0.f;
+    ElemOps<T>::st(Y + off + col, live ? apply_act(acc[e] + bv, a.act, a.slope) : 0.f);
   }
 }
 
@@ -308,8 +363,11 @@ struct PixCursor {
   }
 };
 
+// (fp32, 128 x 128: without the second launch-bounds argument hipcc takes 208 VGPRs + 64 AGPRs = 272 registers -- ONE wave per
+// SIMD, one block per CU; the ResnetBlock weight gradient of BASELINE config 2 (576 tiles of 32 chunks) then runs three rounds of
+// single, latency-exposed waves: 300 us for 9.7 GFLOP.  Two waves per SIMD asked for: <= 256 registers.)
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_kernel(const GemmWgradArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (sizeof(T) == 4 && BM * BN >= 128 * 128) ? 2 : 1) void gemm_wgrad_kernel(const GemmWgradArgs a) {
   using ST = WgStage<T>;
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -509,8 +567,11 @@ __global__ __launch_bounds__(256) void pad_kernel(const T* __restrict__ src, T* 
     else row_ok = (h >= 0) & (h < H);
     const T* srow = src + ((long long)n * H + (row_ok ? h : 0)) * W * Cs;
     T* drow = dst + (long long)row * Wp * Cs;
+    // gridDim.y column segments per row (small tensors: N * Hp rows alone leave most CUs idle -- 18 blocks for a 16 x 32 map)
+    const int segw = (Wp + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int w_lo = (int)blockIdx.y * segw, w_hi = w_lo + segw < Wp ? w_lo + segw : Wp;
     for (int c = tx; c < cv; c += TX) {
-      for (int wp = ty; wp < Wp; wp += TY) {
+      for (int wp = w_lo + ty; wp < w_hi; wp += TY) {
         int w = wp - pl;
         bool ok = row_ok;
         if (mode == JPDSE_PAD_REFLECT) w = w < 0 ? -w : (w >= W ? 2 * (W - 1) - w : w);
@@ -521,7 +582,7 @@ __global__ __launch_bounds__(256) void pad_kernel(const T* __restrict__ src, T* 
       }
     }
   }
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0 && blockIdx.y == 0)
     for (long long i = threadIdx.x; i < slack_vec; i += 256) *reinterpret_cast<u32x4*>(dst + (total_vec + i) * VE) = zero4;
 }
 
@@ -707,8 +768,24 @@ __global__ __launch_bounds__(256) void pack_dgrad_tile_many_kernel(const jpdse_p
       tile[kk][cq + 3] = v[3];
     }
     __syncthreads();
-    bf16_t* const out = reinterpret_cast<bf16_t*>(e.out);
     const int kq = (t & 7) * 8;
+    if (e.out_f32) {                                    // fp32 panels (JPDSE_F32 layers): the same transpose, two 16-byte stores
+      float* const outf = reinterpret_cast<float*>(e.out);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int cc = (t >> 3) + 32 * i;
+        const int c = c0 + cc, k = k0 + kq;
+        if (c < e.Cs && k < e.Ks) {
+          float* const dst = outf + ((long long)c * e.Uh + up) * e.Lk + wp * e.Ks + k;
+          const f32x4 lo = {tile[kq][cc], tile[kq + 1][cc], tile[kq + 2][cc], tile[kq + 3][cc]};
+          const f32x4 hi = {tile[kq + 4][cc], tile[kq + 5][cc], tile[kq + 6][cc], tile[kq + 7][cc]};
+          *reinterpret_cast<f32x4*>(dst) = lo;
+          *reinterpret_cast<f32x4*>(dst + 4) = hi;
+        }
+      }
+      return;
+    }
+    bf16_t* const out = reinterpret_cast<bf16_t*>(e.out);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int cc = (t >> 3) + 32 * i;
@@ -731,9 +808,14 @@ __global__ __launch_bounds__(256) void pack_dgrad_tile_many_kernel(const jpdse_p
   }
   __syncthreads();
   bf16_t* const out = reinterpret_cast<bf16_t*>(e.out);
+  float* const outf = reinterpret_cast<float*>(e.out);
   for (int cc = ty; cc < 64; cc += 4) {
     const int c = c0 + cc, k = k0 + tx;
-    if (c < e.Cs && k < e.Ks) out[((long long)c * e.Uh + up) * e.Lk + wp * e.Ks + k] = f2bf(tile[tx][cc]);
+    if (c < e.Cs && k < e.Ks) {
+      const long long o = ((long long)c * e.Uh + up) * e.Lk + wp * e.Ks + k;
+      if (e.out_f32) outf[o] = tile[tx][cc];
+      else out[o] = f2bf(tile[tx][cc]);
+    }
   }
 }
 

@@ -44,21 +44,31 @@ static void prof_end(int slot, int cls, double flops, hipStream_t s) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-static int launch_fwd_cfg(const GemmFwdArgs& a, hipStream_t s) {
+static int launch_fwd_cfg(const GemmFwdArgs& a_in, hipStream_t s) {
+  GemmFwdArgs a = a_in;
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Ks + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * 64;
+  // split-K (fp32, few tiles): only with a slab region big enough behind `partial` (the plan sized it with the same function)
+  a.splits = (a.col_mod == 0 && a.partial != nullptr) ? generic_splitk_for((int)sizeof(T), a.M, a.Ks, a.R * a.cpr) : 1;
+  if (a.splits > 1 && (size_t)a.splits * a.M * a.Ks * sizeof(float) > a.partial_cap) a.splits = 1;
   const long long kdim = (long long)a.R * a.cpr * (64 / (int)sizeof(T));
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_fwd_kernel<T, BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((gemm_fwd_kernel<T, BM, BN, WM, WN>), dim3(tiles_m * tiles_n, a.splits > 1 ? a.splits : 1), dim3(64 * WM * WN), lds, s, a);
+  int rc = check_launch("gemm_fwd_kernel");
+  if (rc == JPDSE_OK && a.splits > 1) {
+    const long long total_vec = (long long)a.M * (a.Ks / 4);
+    hipLaunchKernelGGL((gemm_splitk_finish_kernel<T>), dim3((unsigned)((total_vec + 255) / 256)), dim3(256), 0, s, a, total_vec);
+    rc = check_launch("gemm_splitk_finish_kernel");
+  }
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
     g_prof.cls[g_prof.used] = 0;
     ++g_prof.used;
   }
-  return check_launch("gemm_fwd_kernel");
+  return rc;
 }
 
 template <typename T>
@@ -270,14 +280,14 @@ JPDSE_SWITCH(int, g_halo_enabled, 1);
 JPDSE_SWITCH(int, g_halo_abl, 0);
 
 template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false,
-          bool VIRT = false>
+          bool VIRT = false, bool NSUM = false>
 static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   constexpr int BN = 2 * TN * 32;
   constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
   constexpr int lds = (SINGLE ? 1 : 2) * UH * 1024 + 3 * BN * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM, VIRT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM, VIRT, NSUM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -287,13 +297,16 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
     return set_error(JPDSE_EINVAL, "gemm_halo: folded-frame form needs a frame, pad 1, equal grids, >= 8 rows");
   if (MOM && (a.mom == nullptr || a.mom_slots != (a.OH / 4) * (a.OW / 64)))
     return set_error(JPDSE_EINVAL, "gemm_halo: moment epilogue without a moment buffer of %d slots", (a.OH / 4) * (a.OW / 64));
+  if (NSUM && (a.nx == nullptr || a.nstats == nullptr || a.nsums == nullptr || a.mom_slots != (a.OH / 4) * (a.OW / 64) ||
+               a.out_sw != a.Ks || a.out_sh != (long long)a.OW * a.Ks || a.out_sn != (long long)a.OH * a.OW * a.Ks || a.out_base != 0))
+    return set_error(JPDSE_EINVAL, "gemm_halo: norm-backward sums need the norm's input, its statistics, %d slots and a dense output", (a.OH / 4) * (a.OW / 64));
   const int tiles = a.N * (a.OH / 4) * (a.OW / 64) * ((a.Ks + BN - 1) / BN);
   const long long kdim = 9LL * a.Cs;
   const int M = a.N * a.OH * a.OW;
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM, VIRT>), dim3(tiles), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM, VIRT, NSUM>), dim3(tiles), dim3(512), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
@@ -312,6 +325,13 @@ static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
   HaloArgs a = a0;
   a.xcd_mode = g_halo_xcd;
   if (a.V != nullptr) {                   // reflect data gradient with the folded frame
+    if constexpr (ABL == 0 && TN == 2) {
+      if (a.nsums != nullptr) {           // ... and the sums of the InstanceNorm backward that consumes its output
+        if (a.Cs == 64) return set_error(JPDSE_EINVAL, "gemm_halo: norm-backward sums are built for the double-buffered form (>= 128 input channels)");
+        return launch_halo_cfg_impl<TN, 0, false, false, false, false, false, true, true>(a, s);
+      }
+    }
+    if (a.nsums != nullptr) return set_error(JPDSE_EINVAL, "gemm_halo: norm-backward sums need the 128-channel tile");
     if constexpr (ABL == 0) {
       if (a.Cs == 64) return launch_halo_cfg_impl<TN, 0, true, false, false, false, false, true>(a, s);     // one slab: single patch buffer
       return launch_halo_cfg_impl<TN, 0, false, false, false, false, false, true>(a, s);

@@ -82,6 +82,21 @@ static int splitk_for(int M, int Ks, int k_tiles) {
   return sp < 2 ? 1 : sp;
 }
 
+// Split-K factor of the GENERIC kernel (gemm_fwd_kernel, fp32 layers): M rows, Ks output channels, `chunks` 64-byte K-chunks
+// (16 fp32 elements each).  Only when the 128-row tiles alone leave most of the chip idle -- at 512x256 batch 1 (BASELINE
+// config 2) the ResnetBlock GEMM is M = 512: 32 tiles on 256 CUs, 0.88 ms per launch; 16 splits: 512 blocks, three per CU.
+JPDSE_SWITCH(int, g_generic_splitk, 1);   // A/B switch (jpdse_debug_set_fast_path 48 / 49)
+static int generic_splitk_for(int ES, int M, int Ks, int chunks) {
+  if (!g_generic_splitk || ES != 4 || M <= 0 || chunks < 32) return 1;
+  const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32), bm = Ks > 32 ? 128 : 256;
+  const long long tiles = (long long)((M + bm - 1) / bm) * ((Ks + bn - 1) / bn);
+  if (tiles >= 256) return 1;
+  int sp = (int)((512 + tiles - 1) / tiles);
+  if (sp > chunks / 16) sp = chunks / 16;         // >= 16 chunks (one two-level flush) per split
+  if (sp > 32) sp = 32;
+  return sp < 2 ? 1 : sp;
+}
+
 static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
   p->ES = (int)esize(d->dtype);
   p->BKE = bke(d->dtype);
@@ -151,6 +166,18 @@ static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
       dgr = sd > 1 ? (size_t)sd * Md * p->Cs * 4 : 0;
     }
     p->splitk_bytes = align_up(fwd > dgr ? fwd : dgr, 256);
+  } else {
+    // generic split-K (fp32): forward and every stride phase of the data gradient (run one after the other: the slabs are reused)
+    const int Mf = d->N * p->OH * p->OW;
+    size_t need = (size_t)generic_splitk_for(p->ES, Mf, p->Ks, d->R * (p->Lk_fwd / p->BKE)) * Mf * p->Ks * 4;
+    for (int i = 0; i < p->nph; ++i) {
+      const Phase& f = p->ph[i];
+      if (f.cnth <= 0 || f.cntw <= 0) continue;
+      const int Md = d->N * f.cnth * f.cntw;
+      const size_t b = (size_t)generic_splitk_for(p->ES, Md, p->Cs, f.Uh * (f.Lk / p->BKE)) * Md * p->Cs * 4;
+      need = need > b ? need : b;
+    }
+    p->splitk_bytes = align_up(need, 256);
   }
 }
 
@@ -165,7 +192,12 @@ static int launch_pad(const void* src, void* dst, int N, int H, int W, int Cs, i
   while ((1 << tx_shift) < Cs / VE && tx_shift < 8) ++tx_shift;
   int grid = N * Hp;
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL((pad_kernel<T>), dim3(grid), dim3(256), 0, s,
+  // few rows (the deep layers at small resolutions: BASELINE config 2 at batch 1 has 18-row maps): split every row into column
+  // segments until ~512 blocks exist, at least 4 pixels per thread row and segment
+  const int TY = 256 >> tx_shift;
+  int segs = 1;
+  while (grid * segs < 512 && Wp / (segs * 2) >= 4 * TY && segs < 64) segs *= 2;
+  hipLaunchKernelGGL((pad_kernel<T>), dim3(grid, segs), dim3(256), 0, s,
                      reinterpret_cast<const T*>(src), reinterpret_cast<T*>(dst), N, H, W, Cs, pt, pl, Hp, Wp,
                      mode, tx_shift, total_vec, slack_vec);
   return check_launch("pad_kernel");

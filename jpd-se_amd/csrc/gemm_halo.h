@@ -51,6 +51,15 @@ struct HaloArgs {
   const bf16_t* V;      // VIRT instantiation: the folded frame of the input (see ring_frame_kernel), [N][2(IW+2) + 2 IH][Cs]
   float* mom;           // optional (MOM instantiation): InstanceNorm moments of y, one (mean, M2) slot per block and channel
   int mom_slots;        //   [N][Ks][mom_slots][2], slot = the block's patch index inside its image (common.h; no bias / activation)
+  // NSUM instantiation (round 4): Y is the gradient dy w.r.t. the OUTPUT of an InstanceNorm (+ activation) whose input was nx
+  // (same addressing as Y) with statistics nstats [N][Ks][2] = (mean, rstd).  The epilogue also writes, per block and channel,
+  // the two sums that norm's backward needs -- sum dz and sum dz * yhat with yhat = (nx - mean) rstd, dz = dy act'(yhat) (norm.hip,
+  // BwdMoments) -- into nsums [N][Ks][mom_slots][2]: the norm's backward then needs no pass of its own over (x, dy) for them.
+  const bf16_t* nx;
+  const float* nstats;
+  float* nsums;
+  int nact;
+  float nslope;
 };
 
 // ABL: timing-only ablation bits (results are wrong when non-zero): 1 = no DMA after the prologue,
@@ -71,7 +80,7 @@ struct HaloArgs {
 // pixel in the slack of the patch buffer.  Costs an add and a min per fragment address and tap; replaces the four ring-strip
 // GEMMs + ring_fold_kernel.  Needs py = px = 1, IH = OH, IW = OW, OH >= 8.
 template <int TH, int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false,
-          bool VIRT = false>
+          bool VIRT = false, bool NSUM = false>
 __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   constexpr int R = 3, S = 3, TAPS = 9;
   constexpr int NW = 8, WN = 2;                       // waves: TH (=4) x 2
@@ -440,6 +449,87 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   // paid one memory round trip per vector -- 8 in a row with the block alone on its CU.
   constexpr int NV = TH * 64 * VPR / 512;
   static_assert(TH * 64 * VPR % 512 == 0, "every thread owns the same number of output vectors");
+  if constexpr (NSUM) {
+    // Same epilogue as the fused form below, plus the sums of the InstanceNorm backward that consumes Y (HaloArgs::nx).  A
+    // thread's vectors all lie in ONE 8-channel column (512 % VPR == 0), so its sums stay in registers over its NV pixels; the
+    // four lanes of a wave that share a column are merged by two xor shuffles, the eight waves through LDS in wave order
+    // (fixed order: deterministic), one slot per block and channel.
+    static_assert(512 % VPR == 0 && !MF16 && !SINGLE, "one channel column per thread");
+    constexpr int NRED_OFF = TH * 64 * PITCH;
+    static_assert(NRED_OFF + NW * BN * 2 * 4 <= NBUF * HALO + 3 * B_STAGE, "the reduction rows fit behind the epilogue tile");
+    const int v = tid % VPR;
+    const bool on = n0 + v * 8 < a.Ks;
+    u32x4 addv[NV], mskv[NV], nxv[NV];
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int row = (tid + 512 * it) / VPR;
+      const long long off = blk_base + (long long)(row >> 6) * a.out_sh + (long long)(row & 63) * a.out_sw + n0 + v * 8;
+      if (on && a.addend != nullptr) addv[it] = *reinterpret_cast<const u32x4*>(a.addend + off);
+      if (on && a.mask != nullptr) mskv[it] = *reinterpret_cast<const u32x4*>(a.mask + off);
+      if (on) nxv[it] = *reinterpret_cast<const u32x4*>(a.nx + off);
+    }
+    float mean[8], rstd[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mean[e] = 0.f; rstd[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+    if (on) {
+      const f32x4* const st = reinterpret_cast<const f32x4*>(a.nstats + ((long long)n * a.Ks + n0 + v * 8) * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 t = st[q];
+        mean[2 * q] = t[0]; rstd[2 * q] = t[1]; mean[2 * q + 1] = t[2]; rstd[2 * q + 1] = t[3];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int row = (tid + 512 * it) / VPR;
+      if (!on) continue;
+      const long long off = blk_base + (long long)(row >> 6) * a.out_sh + (long long)(row & 63) * a.out_sw + n0 + v * 8;
+      u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * PITCH + v * 16);
+      if (a.addend != nullptr) val = add_bf16x8(val, addv[it]);
+      if (a.mask != nullptr) val = relu_mask8(val, mskv[it]);
+      *reinterpret_cast<u32x4*>(a.Y + off) = val;
+      float g[8], x[8];
+      Vec16<bf16_t>::unpack(val, g);                   // the ROUNDED gradient: what the norm's backward re-reads
+      Vec16<bf16_t>::unpack(nxv[it], x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yh = (x[e] - mean[e]) * rstd[e];
+        float dz = g[e];
+        if (a.nact == JPDSE_ACT_RELU) dz = yh > 0.f ? dz : 0.f;
+        else if (a.nact == JPDSE_ACT_LRELU) dz = yh > 0.f ? dz : dz * a.nslope;
+        s1[e] += dz;
+        s2[e] += dz * yh;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s1[e] += __shfl_xor(s1[e], 16, 64);
+      s2[e] += __shfl_xor(s2[e], 16, 64);
+      s1[e] += __shfl_xor(s1[e], 32, 64);
+      s2[e] += __shfl_xor(s2[e], 32, 64);
+    }
+    float* const nred = reinterpret_cast<float*>(smem + NRED_OFF);     // [NW][BN][2], behind the tile the other waves still read
+    if (lane < VPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        nred[(wid * BN + v * 8 + e) * 2] = s1[e];
+        nred[(wid * BN + v * 8 + e) * 2 + 1] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.Ks) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        t1 += nred[(w * BN + tid) * 2];
+        t2 += nred[(w * BN + tid) * 2 + 1];
+      }
+      float* const o = a.nsums + (((long long)n * a.Ks + n0 + tid) * a.mom_slots + (th_i * tiles_w + tw_i)) * 2;
+      o[0] = t1;
+      o[1] = t2;
+    }
+    return;
+  }
   if (a.addend != nullptr || a.mask != nullptr) {
     u32x4 addv[NV], mskv[NV];
 #pragma unroll

@@ -616,7 +616,10 @@ __global__ __launch_bounds__(256, (P == 8 ? 3 : 2)) void inorm_reg_bwd_kernel(co
                                                                              T* __restrict__ dx,
                                                                              const float* __restrict__ stats, float* partial,
                                                                              unsigned* count, int act, float slope,
-                                                                             FusedGeom g) {
+                                                                             FusedGeom g, int mslots = 0) {
+  // PHASE 3 (round 4): the two sums come from the per-block slots that the epilogue of the data-gradient kernel producing dy
+  // wrote (`partial` = sums[n][c][mslots][2], gemm_halo.h NSUM): ONE kernel per norm backward -- each block adds the slots of
+  // its channels itself (slot order: deterministic) and applies
   constexpr int VE = Vec16<T>::N;
   __shared__ float red[256 * VE * 2];
   __shared__ int s_ctl[2];
@@ -646,7 +649,24 @@ __global__ __launch_bounds__(256, (P == 8 ? 3 : 2)) void inorm_reg_bwd_kernel(co
 #pragma unroll
     for (int e = 0; e < VE; ++e) { mean[e] = st[2 * e]; rstd[e] = st[2 * e + 1]; }
   }
-  if constexpr (PHASE == 2) {
+  if constexpr (PHASE == 3) {
+    const int nch = g.TX * VE;
+    if (tid < nch) {
+      const int ch = cb * nch + tid;
+      float a = 0.f, b = 0.f;
+      if (ch < g.Cs) {
+        const float2* const src = reinterpret_cast<const float2*>(partial) + ((long long)n * g.Cs + ch) * mslots;
+        for (int q = 0; q < mslots; ++q) {
+          const float2 v = src[q];
+          a += v.x;
+          b += v.y;
+        }
+      }
+      red[tid * 2] = a;
+      red[tid * 2 + 1] = b;
+    }
+    __syncthreads();
+  } else if constexpr (PHASE == 2) {
     const float* rows = partial + (long long)grp * g.splits * g.nv;
     const float total = tid < g.nv ? sum_rows<false>(rows + tid, g.splits, g.nv) : 0.f;
     if (tid < g.nv) red[tid] = total;
@@ -966,6 +986,60 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(const float* __rest
   }
 }
 
+// Backward sums from per-block slots written by the epilogue of the data-gradient kernel that produced dy:
+// sums[n][c][slot] = (sum dz, sum dz * yhat) over the block's pixels.  (n, c) pairs are summed in slot order by 8 lanes each.
+__global__ __launch_bounds__(256) void finalize_bwd_slots_kernel(const float* __restrict__ slots_in, float* __restrict__ sums, int NC,
+                                                                int slots, int HW) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = gid >> 3, sub = gid & 7;
+  float a = 0.f, b = 0.f;
+  if (idx < NC) {
+    const float2* const src = reinterpret_cast<const float2*>(slots_in) + (long long)idx * slots;
+    for (int q = sub; q < slots; q += 8) {
+      const float2 v = src[q];
+      a += v.x;
+      b += v.y;
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  if (idx >= NC || sub != 0) return;
+  const float inv = 1.f / (float)HW;
+  sums[2 * idx] = a * inv;
+  sums[2 * idx + 1] = b * inv;
+}
+
+template <typename T>
+static int inorm_bwd_from_sums_t(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy, const float* slot_sums,
+                                 int slots, void* dx, void* ws, hipStream_t s) {
+  constexpr int VE = Vec16<T>::N;
+  const int HW = d->H * d->W, Cs = cpad(d->C);
+  if (norm_form() != 0 && slots <= 64) {
+    FusedGeom fg;
+    const int P = reg_pick<T, true>(d, false, &fg);
+    if (P == 8) {
+      const dim3 grid((unsigned)((size_t)d->N * fg.col_blocks * fg.splits));
+      hipLaunchKernelGGL((inorm_reg_bwd_kernel<T, 8, 3>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(x),
+                         reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx), stats, const_cast<float*>(slot_sums), nullptr,
+                         d->act, d->slope, fg, slots);
+      return check_launch("inorm apply-from-slots bwd");
+    }
+  }
+  float* const sums = reinterpret_cast<float*>(ws);
+  const int NC = d->N * Cs;
+  hipLaunchKernelGGL(finalize_bwd_slots_kernel, dim3((NC * 8 + 255) / 256), dim3(256), 0, s, slot_sums, sums, NC, slots, HW);
+  if (int rc = check_launch("inorm finalize bwd from slots")) return rc;
+  MomentGeom g = moment_geom(d->N, HW, Cs, VE);
+  const int col_blocks = (g.cv + g.TX - 1) / g.TX;
+  hipLaunchKernelGGL((inorm_apply_bwd_kernel<T>), dim3(d->N * g.splits * col_blocks), dim3(256), 0, s,
+                     reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx), stats,
+                     sums, d->act, d->slope, g);
+  return check_launch("inorm apply bwd");
+}
+
 template <typename T>
 static int inorm_from_moments_t(const jpdse_inorm_desc* d, const void* x, const float* mom, int slots, const void* res, void* y,
                                 float* stats, hipStream_t s) {
@@ -1036,6 +1110,19 @@ int jpdse_inorm_bwd(const jpdse_inorm_desc* d, const void* x, const float* stats
   const int rc = d->dtype == JPDSE_BF16 ? inorm_bwd_t<bf16_t>(d, x, stats, dy, dx, ws, as_stream(stream))
                                         : inorm_bwd_t<float>(d, x, stats, dy, dx, ws, as_stream(stream));
   hbm_prof_end(pslot, JPDSE_HBM_INORM_BWD, tensor_bytes(d) * 5.0, as_stream(stream));
+  return rc;
+}
+
+int jpdse_inorm_bwd_from_sums(const jpdse_inorm_desc* d, const void* x, const float* stats, const void* dy, const float* sums,
+                              int32_t slots, void* dx, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = jpdse::validate(d)) return rc;
+  JPDSE_REQUIRE(x && stats && dy && dx && sums && slots > 0, "inorm_bwd_from_sums: null pointer / no slots");
+  const size_t need = align_up((size_t)d->N * cpad(d->C) * 2 * sizeof(float), 256);
+  if (ws == nullptr || ws_bytes < need) return set_error(JPDSE_EWORKSPACE, "inorm_bwd_from_sums: workspace %zu < %zu", ws_bytes, need);
+  const int pslot = hbm_prof_begin(as_stream(stream));
+  const int rc = d->dtype == JPDSE_BF16 ? inorm_bwd_from_sums_t<bf16_t>(d, x, stats, dy, sums, slots, dx, ws, as_stream(stream))
+                                        : inorm_bwd_from_sums_t<float>(d, x, stats, dy, sums, slots, dx, ws, as_stream(stream));
+  hbm_prof_end(pslot, JPDSE_HBM_INORM_BWD, tensor_bytes(d) * 3.0, as_stream(stream));      // x, dy read once, dx written
   return rc;
 }
 

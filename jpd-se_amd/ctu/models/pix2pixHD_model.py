@@ -503,20 +503,42 @@ class Pix2PixHDModel(BaseModel):
     # gradient all-reduce (93 % of the bytes) the whole D backward to hide behind (launch_all below), instead of the
     # ResnetBlock GEMMs whose grids are exactly one workgroup per CU and take a second round when RCCL holds any CU.
     bg, bd = self.grad_buckets.get('G'), self.grad_buckets.get('D')
+    # Opt-in timeline of the data-parallel schedule (self.ddp_timeline = []: one dict of timing events per step, recorded on the
+    # compute stream; bench.py --gpus N > 1 and tests/test_hip_ddp.py read it).  `g_reduced` is recorded right behind the waits
+    # on G's all-reduce handles, so elapsed(d_bwd_end -> g_reduced) is what of the collective the D backward did NOT hide.
+    tl = getattr(self, 'ddp_timeline', None)
+    marks = {} if tl is not None else None
+
+    def mark(name):
+      if marks is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks[name] = ev
+
     did_G = self.backward_G(state, w_gan, w_feat, w_vgg, w_dist)
+    mark('g_bwd_end')
     if did_G and bg is not None:
       bg.launch_all()                  # no-op for buckets already started from the per-layer hooks (defer=False)
     did_D = self.backward_D(state, 0.0 if opt.no_d_gan_loss else 0.5)
+    mark('d_bwd_end')
     if did_G:
       if bg is not None:
         bg.finish()
+      mark('g_reduced')
       optimizer_G.step()
       self._repack('G')
+      mark('adam_g_end')
     if did_D:
       if bd is not None:
         bd.finish()
+      mark('d_reduced')
       optimizer_D.step()
       self._repack('D')
+    mark('step_end')
+    if tl is not None:
+      marks['stats_G'] = dict(bg.stats) if bg is not None and bg.stats else None
+      marks['stats_D'] = dict(bd.stats) if bd is not None and bd.stats else None
+      tl.append(marks)
     if not early:
       loss_host, loss_ready = self._queue_loss_readback(slots)
     loss_ready.synchronize()

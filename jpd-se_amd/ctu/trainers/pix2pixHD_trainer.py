@@ -36,7 +36,7 @@ class Pix2PixHDTrainer(BaseTrainer):
         self.enable_data_parallel(reduce_dtype=torch.bfloat16 if getattr(opt, 'bf16_grad_reduce', False) else None)
 
   # ---- data parallelism (no reference counterpart: base_parser.py:234-237 refuses >1 GPU) ----
-  def enable_data_parallel(self, bucket_bytes=64 << 20, process_group=None, reduce_dtype=None, overlap=None):
+  def enable_data_parallel(self, bucket_bytes=None, process_group=None, reduce_dtype=None, overlap=None):
     """Replicate-and-average: broadcast rank 0's weights once, re-home every gradient into flat all-reduce buckets, and
     let Adam divide by the world size.  Runs for any initialised process group, world size 1 included (the RCCL
     calls are then no-ops in value, which is how the path is exercised on a one-GPU box).  reduce_dtype
@@ -54,6 +54,11 @@ class Pix2PixHDTrainer(BaseTrainer):
     # of its last layer and overlaps the rest of G's backward (round 1-2 behaviour).  Same results either way.
     overlap = overlap or getattr(self.opt, 'ddp_overlap', 'd_backward')
     assert overlap in ('d_backward', 'layers'), overlap
+    if bucket_bytes is None:
+      # 'layers': 64 MB buckets (one ResnetBlock filter = 37.7 MB each) so that a bucket goes on the wire as soon as its layer is
+      # done; 'd_backward': everything starts at once, so fewer and larger collectives (256 MB: the generator's 730 MB in 3 + the
+      # small layers) -- a ring all-reduce's fixed cost (2 (N-1) hops of latency + a kernel launch) is paid per bucket
+      bucket_bytes = (64 << 20) if overlap == 'layers' else (256 << 20)
     self._dp = dict(bucket_bytes=bucket_bytes, process_group=process_group, reduce_dtype=reduce_dtype, world=world,
                     overlap=overlap)
     self._rebuild_buckets('G', self.model.netG, self.optimizer_G)

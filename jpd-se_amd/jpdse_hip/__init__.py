@@ -35,7 +35,8 @@ class InormDesc(ctypes.Structure):
 
 class PackEntry(ctypes.Structure):
   _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + \
-             [(n, ctypes.c_int32) for n in ('K', 'Ks', 'C', 'Cs', 'R', 'S', 'st', 'qh', 'qw', 'Uh', 'Uw', 'Lk', 'gx', 'gy')] + \
+             [(n, ctypes.c_int32) for n in ('K', 'Ks', 'C', 'Cs', 'R', 'S', 'st', 'qh', 'qw', 'Uh', 'Uw', 'Lk', 'gx', 'gy',
+                                            'out_f32', 'reserved_')] + \
              [('blocks', ctypes.c_int64), ('block0', ctypes.c_int64)]
 
 
@@ -77,6 +78,8 @@ SIGNATURES = {
     'jpdse_conv_dgrad_relu': (_I32, [_CD, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad_fused': (_I32, [_CD, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_dgrad_fused_lrelu': (_I32, [_CD, _P, _P, _P, _F, _P, _P, _P, _SZ, _P]),
+    'jpdse_conv_dgrad_nsum_slots': (_I32, [_CD]),
+    'jpdse_conv_dgrad_fused_nsums': (_I32, [_CD, _P, _P, _P, _P, _P, _P, _P, _I32, _F, _P, _P, _SZ, _P]),
     'jpdse_conv_wgrad': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_convT_fwd': (_I32, [_CD, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_conv_moment_slots': (_I32, [_CD]),
@@ -89,6 +92,7 @@ SIGNATURES = {
     'jpdse_inorm_workspace_size': (_SZ, [_ND]),
     'jpdse_inorm_fwd': (_I32, [_ND, _P, _P, _P, _P, _P, _SZ, _P]),
     'jpdse_inorm_bwd': (_I32, [_ND, _P, _P, _P, _P, _P, _SZ, _P]),
+    'jpdse_inorm_bwd_from_sums': (_I32, [_ND, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P]),
     'jpdse_avgpool3s2_fwd': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     'jpdse_avgpool3s2_bwd': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     'jpdse_maxpool2_fwd': (_I32, [_I32, _I32, _I32, _I32, _I32, _P, _P, _P]),

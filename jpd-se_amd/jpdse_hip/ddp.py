@@ -72,6 +72,10 @@ class GradBuckets(object):
       b['pending'] = len(b['params'])
       b['handle'] = None
 
+  # What the last finish() saw (tests/test_hip_ddp.py asserts on it; bench.py prints it for N > 1): how many collectives were
+  # started, how many of them had been started before finish() itself had to start them, how many handles were waited for.
+  stats = None
+
   def world_size(self):
     return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -116,12 +120,16 @@ class GradBuckets(object):
   def finish(self):
     """Launch whatever has not been launched (parameters without a gradient this step) and make
     the current stream wait for every bucket; no host synchronisation with RCCL."""
+    early = sum(1 for b in self.buckets if b['handle'] is not None)
     self.launch_all()
+    waited = 0
     for b in self.buckets:
       if b['handle'] is not None:
         b['handle'].wait()
+        waited += 1
         if b['wire'] is not None:
           self._convert(b['wire'], b['flat'])
+    self.stats = dict(buckets=len(self.buckets), started_before_finish=early, waited=waited)
     self.reset()
 
   def total_bytes(self):

@@ -21,6 +21,11 @@ from .ops import Act
 _weights_epoch = [0]
 
 
+def lib_pack_size(d):
+  from . import lib
+  return int(lib().jpdse_conv_dgrad_pack_size(ctypes.byref(d)))
+
+
 def bump_weights_epoch():
   """Call after any in-place update of master weights done outside torch's version counter
   (the fused Adam kernel): packed GEMM panels are rebuilt lazily on next use."""
@@ -104,10 +109,25 @@ class HipConv2d(nn.Module):
     C, K = (self.cout, self.cin) if self.transposed else (self.cin, self.cout)
     return self.cdtype == BF16 and C % 64 == 0 and K % 8 == 0 and K > 8     # thin inputs / heads carry extra panels
 
+  def _fp32_alias_fwd_panel(self):
+    """fp32 layers whose forward panel [Ks][R][S*Cs] would be an element-for-element copy of the KRSC master (no channel or
+    chunk padding): the kernels read the master itself -- no copy after each optimizer step (round 4: 32 such copies per step
+    cost BASELINE config 2 0.4 ms of 24)."""
+    C, K = (self.cout, self.cin) if self.transposed else (self.cin, self.cout)
+    return self.cdtype == F32 and C % 8 == 0 and K % 8 == 0 and (self.k * C) % 16 == 0
+
   def packs(self):
     w = self._master()
     wver = getattr(w, '_jpdse_wver', 0)        # bumped by FusedAdam for the tensors it updated
     key = (w._version, _weights_epoch[0], w.data_ptr(), self.cdtype, wver)
+    if self._pack_key != key and self._fp32_alias_fwd_panel():
+      d = self._desc(1, 64, 64)
+      if self._packs is None or self._pack_key[3] != self.cdtype or self._packs[0].data_ptr() != w.data_ptr():
+        nd = lib_pack_size(d)
+        self._packs = (w.detach(), torch.empty(nd, dtype=torch.uint8, device=w.device))
+      ops.conv_pack_into(d, w, None, self._packs[1])        # the data-gradient panels only
+      self._pack_key = key
+      return self._packs
     if self._pack_key != key:
       d = self._desc(1, 64, 64)   # pack layout does not depend on N,H,W
       if self._packs is None or self._pack_key[3] != self.cdtype:
@@ -129,14 +149,18 @@ class HipConv2d(nn.Module):
     """Table entries for PackBatcher, or None when this layer needs its own pack call right now (first use,
     fp32, forward panel not written by Adam, weights replaced, padded panel rows)."""
     w = self._master()
-    if self._packs is None or self._pack_key is None or self.cdtype != BF16:
+    if self._packs is None or self._pack_key is None:
+      return None
+    if self.cdtype != BF16 and not (self._fp32_alias_fwd_panel() and self._packs[0].data_ptr() == w.data_ptr()):
       return None
     key = self._pack_key_now()
     if key == self._pack_key:
       return []                                     # nothing to do
-    if not (getattr(w, '_jpdse_cast_out', None) is self._packs[0] and
-            getattr(w, '_jpdse_cast_wver', None) == key[4] and self._pack_key[:4] == key[:4]):
+    if self.cdtype == BF16 and not (getattr(w, '_jpdse_cast_out', None) is self._packs[0] and
+                                    getattr(w, '_jpdse_cast_wver', None) == key[4] and self._pack_key[:4] == key[:4]):
       return None
+    if self.cdtype != BF16 and self._pack_key[:4] != key[:4]:
+      return None                                   # weights replaced (load_state_dict): the lazy per-layer path
     if getattr(self, '_pack_entries_cache', None) is None or self._pack_entries_cache[0] != (w.data_ptr(), self._packs[1].data_ptr()):
       from . import lib, PackEntry
       buf = (PackEntry * 4)()
@@ -203,11 +227,24 @@ class HipConv2d(nn.Module):
     y, mom = ops.conv_fwd_moments(d, x, dgrad_pack if self.transposed else fwd_pack, slots, self.transposed)
     return y, (Ctx(x) if self.transposed else Ctx(x, None)), mom, slots
 
-  def bwd(self, ctx, dy, need_dx=True, need_dw=True, dy_is_dz=False, relu_input=False, addend=None, input_slope=0.0):
+  def nsum_slots(self, N, H, W):
+    """Slots per image of the norm-backward sums this layer's data-gradient epilogue can write (0: none), cached per shape."""
+    if self.transposed or self.cdtype != BF16:
+      return 0
+    from . import binding_epoch
+    key = (binding_epoch(), N, H, W)
+    cache = self.__dict__.setdefault('_nsum_slots', {})
+    if key not in cache:
+      cache[key] = ops.conv_dgrad_nsum_slots(self._desc(N, H, W))
+    return cache[key]
+
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True, dy_is_dz=False, relu_input=False, addend=None, input_slope=0.0, sink=None):
     """dy_is_dz: dy is already the gradient w.r.t. the PRE-activation (the caller fused this layer's
     activation backward upstream); relu_input: the layer's input is a ReLU output (LeakyReLU(input_slope) when
     input_slope != 0) and the returned dx is wanted w.r.t. that activation's pre-activation (mask fused into the
-    data-gradient epilogue); addend: another gradient w.r.t. the layer's input, summed into dx in the same epilogue."""
+    data-gradient epilogue); addend: another gradient w.r.t. the layer's input, summed into dx in the same epilogue;
+    sink = (norm input Act, stats, act, slope): dx is the gradient w.r.t. the OUTPUT of that InstanceNorm (+ activation) -- when
+    this layer's data-gradient kernel can, its epilogue also writes the sums of that norm's backward (dx.nsums)."""
     fwd_pack, dgrad_pack = self.packs()
     need_dw = need_dw and self.weight.requires_grad
     if self.transposed:
@@ -231,6 +268,12 @@ class HipConv2d(nn.Module):
       self._fire()
     if not need_dx:
       return None
+    if sink is not None and input_slope == 0.0:
+      slots = self.nsum_slots(x.N, x.H, x.W)
+      if slots > 0:
+        sx, sstats, sact, sslope = sink
+        return ops.conv_dgrad_nsums(d, dz, dgrad_pack, slots, sx, sstats, sact, sslope,
+                                    relu_input=x if relu_input else None, addend=addend)
     return ops.conv_dgrad(d, dz, dgrad_pack, relu_input=x if relu_input else None, addend=addend, mask_slope=input_slope)
 
   def bwd_input_slice(self, ctx, dy, c0, c1, dy_is_dz=False):
@@ -315,7 +358,12 @@ class InstNormAct(object):
 
   def bwd(self, ctx, dy, need_dx=True, need_dw=True):
     x, stats = ctx.items
-    return ops.inorm_bwd(x, stats, dy, self.act, self.slope, self.eps)
+    return ops.inorm_bwd(x, stats, dy, self.act, self.slope, self.eps)     # takes dy.nsums when the producer of dy wrote them
+
+  def sink(self, ctx):
+    """What the producer of this norm's dy needs to write the backward sums in its epilogue (HipConv2d.bwd sink=)."""
+    x, stats = ctx.items
+    return (x, stats, self.act, self.slope)
 
 
 class ConvNormAct(object):
@@ -339,6 +387,10 @@ class ConvNormAct(object):
     c1, c2 = ctx.items
     dh = self.norm.bwd(c2, dy)
     return self.conv.bwd(c1, dh, need_dx, need_dw, addend=addend, **conv_kw)
+
+  def dy_sink(self, ctx):
+    """The norm that consumes the gradient handed to bwd(): run_chain_bwd passes it to the stage that produces that gradient."""
+    return self.norm.sink(ctx.items[1])
 
 
 class _Slot(nn.Module):
@@ -385,15 +437,28 @@ class HipResnetBlock(nn.Module):
     y, ctx = self._fwd(x)
     return (y, Ctx(x)) if self.recompute else (y, ctx)
 
-  def bwd(self, ctx, dy, need_dx=True, need_dw=True):
+  accepts_dx_sink = True
+
+  def bwd(self, ctx, dy, need_dx=True, need_dw=True, dx_sink=None):
+    """dx_sink: the InstanceNorm that consumes the returned gradient (the previous stage's, see dy_sink): the sums of its
+    backward are then written by the epilogue of this block's first conv's data gradient; likewise norm1's by the second conv's
+    -- no separate pass over (x, dy) for either (jpdse_conv_dgrad_fused_nsums)."""
     if len(ctx.items) == 1:                     # checkpointed: rebuild the saved tensors from the block input
       _, ctx = self._fwd(ctx.items[0])
     c1, n1, c2, n2 = ctx.items
     d = self.norm2.bwd(n2, dy)
-    d = self.conv_block[5].bwd(c2, d, True, need_dw)
+    d = self.conv_block[5].bwd(c2, d, True, need_dw, sink=self.norm1.sink(n1) if self.fuse_norm_sums else None)
     d = self.norm1.bwd(n1, d)
     # the skip connection's gradient is summed in the data-gradient epilogue of the first conv
-    return self.conv_block[1].bwd(c1, d, need_dx, need_dw, addend=dy if need_dx else None)
+    return self.conv_block[1].bwd(c1, d, need_dx, need_dw, addend=dy if need_dx else None,
+                                  sink=dx_sink if self.fuse_norm_sums else None)
+
+  fuse_norm_sums = True       # False (A/B, tests): every norm backward computes its sums in its own pass
+
+  def dy_sink(self, ctx):
+    if len(ctx.items) == 1:                     # checkpointed block: its saved tensors do not exist yet
+      return None
+    return self.norm2.sink(ctx.items[3])
 
 
 def run_chain_fwd(stages, x):
@@ -407,5 +472,10 @@ def run_chain_fwd(stages, x):
 def run_chain_bwd(stages, ctxs, dy, need_dx=True, need_dw=True):
   """Back-propagate through `stages`; the first stage computes dx only when need_dx."""
   for i in range(len(stages) - 1, -1, -1):
-    dy = stages[i].bwd(ctxs[i], dy, need_dx or i > 0, need_dw)
+    if i > 0 and getattr(stages[i], 'accepts_dx_sink', False) and hasattr(stages[i - 1], 'dy_sink'):
+      # stage i's dx goes straight into the InstanceNorm backward of stage i - 1: let its data-gradient epilogue write that
+      # norm's sums (HipResnetBlock.bwd)
+      dy = stages[i].bwd(ctxs[i], dy, True, need_dw, dx_sink=stages[i - 1].dy_sink(ctxs[i - 1]))
+    else:
+      dy = stages[i].bwd(ctxs[i], dy, need_dx or i > 0, need_dw)
   return dy

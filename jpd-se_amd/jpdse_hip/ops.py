@@ -37,11 +37,14 @@ def _stream():
 
 class Act(object):
   """NHWC activation: `t` has shape [N,H,W,CPAD(C)], padding lanes are zero."""
-  __slots__ = ('t', 'C')
+  __slots__ = ('t', 'C', 'nsums')
 
   def __init__(self, t, C):
     assert t.dim() == 4 and t.shape[3] == cpad(C) and t.is_contiguous(), (tuple(t.shape), C)
     self.t, self.C = t, C
+    # a gradient tensor may carry the per-block sums of the InstanceNorm backward that consumes it, written by the epilogue
+    # of the data-gradient kernel that produced it: (fp32 tensor [N][Cs][slots][2], slots, id of the norm's input tensor)
+    self.nsums = None
 
   N = property(lambda s: s.t.shape[0])
   H = property(lambda s: s.t.shape[1])
@@ -152,6 +155,27 @@ def conv_dgrad(d, dy, dgrad_pack, relu_input=None, addend=None, mask_slope=0.0):
   return dx
 
 
+def conv_dgrad_nsum_slots(d):
+  """Blocks per image whose norm-backward sums the layer's data-gradient kernel can write (0: no such epilogue)."""
+  return int(lib().jpdse_conv_dgrad_nsum_slots(ctypes.byref(d)))
+
+
+def conv_dgrad_nsums(d, dy, dgrad_pack, slots, norm_x, norm_stats, norm_act, norm_slope, relu_input=None, addend=None):
+  """conv_dgrad (+ mask / addend) whose dx feeds the backward of the InstanceNorm with input `norm_x` and statistics
+  `norm_stats`: dx.nsums carries the per-block (sum dz, sum dz * yhat) slots for inorm_bwd (jpdse_conv_dgrad_fused_nsums)."""
+  dx = Act.empty(d.N, d.H, d.W, d.C, d.dtype, dy.t.device)
+  assert tuple(norm_x.t.shape) == tuple(dx.t.shape) and norm_x.dtype == dx.dtype
+  sums = torch.empty((d.N, dx.Cs, slots, 2), dtype=torch.float32, device=dy.t.device)
+  ws, n = _conv_ws(d, dy.t.device)
+  check(lib().jpdse_conv_dgrad_fused_nsums(ctypes.byref(d), _p(dy.t), _p(dgrad_pack),
+                                           _p(relu_input.t if relu_input is not None else None),
+                                           _p(addend.t if addend is not None else None), _p(dx.t), _p(norm_x.t), _p(norm_stats),
+                                           int(norm_act), float(norm_slope), _p(sums), _p(ws), ws.numel(), _stream()),
+        'conv_dgrad_fused_nsums')
+  dx.nsums = (sums, slots, norm_x.t.data_ptr())
+  return dx
+
+
 def conv_wgrad(d, x, dy, dw):
   """dw: fp32 tensor in the KRSC master layout, overwritten."""
   ws, n = _conv_ws(d, x.t.device)
@@ -207,6 +231,12 @@ def inorm_bwd(x, stats, dy, act, slope=0.2, eps=1e-5):
   dx = x.empty_like()
   n = lib().jpdse_inorm_workspace_size(ctypes.byref(d))
   ws = workspace(n, x.t.device)
+  if dy.nsums is not None and dy.nsums[2] == x.t.data_ptr():
+    # the sums were written by the epilogue of the kernel that produced dy, for THIS norm (same input tensor)
+    sums, slots, _ = dy.nsums
+    check(lib().jpdse_inorm_bwd_from_sums(ctypes.byref(d), _p(x.t), _p(stats), _p(dy.t), _p(sums), slots, _p(dx.t), _p(ws),
+                                          ws.numel(), _stream()), 'inorm_bwd_from_sums')
+    return dx
   check(lib().jpdse_inorm_bwd(ctypes.byref(d), _p(x.t), _p(stats), _p(dy.t), _p(dx.t), _p(ws), ws.numel(), _stream()),
         'inorm_bwd')
   return dx

@@ -15,6 +15,7 @@ ap.add_argument('--height', type=int, default=512)
 ap.add_argument('--netG', default='global')
 ap.add_argument('--dtype', default='bf16')
 ap.add_argument('--fast', type=int, default=1)
+ap.add_argument('--no-vgg', action='store_true', help='BASELINE config 2: no VGG loss, VGG not run')
 args = ap.parse_args()
 
 torch.cuda.set_device(0)
@@ -26,7 +27,8 @@ from ctu.utils.synthetic import synthetic_batch, default_opt
 
 jpdse_hip.set_dev_mode(args.fast)
 opt = default_opt(gpu_ids=[0], print_losses=False, compute_dtype=args.dtype, use_compressed=True,
-                  netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch)
+                  netG=args.netG, ngf=64 if args.netG == 'global' else 32, batch_size=args.batch,
+                  **(dict(no_vgg_loss=True, skip_unused_losses=True) if args.no_vgg else {}))
 torch.manual_seed(1234)
 trainer = get_trainer(opt)(opt, 'train')
 xd = synthetic_batch(args.batch, args.height, args.width, seed=1234)

@@ -157,7 +157,7 @@ LAYERS_1024_THIN = [
 def test_1024x512_train_step_vs_oracle(netG, batch):
   """One whole train step at BASELINE.json's headline size (1024x512, global generator ngf 64 -- and config 3's LocalEnhancer
   ngf 32 --, 2-scale PatchGAN, VGG; batch 1 so that the CPU oracle finishes in seconds) against the oracle on the same seeded
-  weights: the six losses of the fp32 HIP path within 1e-3, of the bf16 path within 2e-2, and the post-Adam generator weights of
+  weights: the six losses of the fp32 HIP path within 1e-3, of the bf16 path within 5e-3, and the post-Adam generator weights of
   the fp32 path within the sign-flip bound (hip_step._check_weights' criterion: relative L2 <= 2e-3 per tensor)."""
   kw = dict(use_compressed=True) if netG == 'global' else dict(use_compressed=True, netG='local', ngf=32)
   opt32 = _opts(**kw)
@@ -184,7 +184,7 @@ def test_1024x512_train_step_vs_oracle(netG, batch):
     tr.step(xd)
     torch.cuda.synchronize()
     got[dt] = dict(tr.last_losses)
-    tol = 1e-3 if dt == 'fp32' else 2e-2
+    tol = 1e-3 if dt == 'fp32' else 5e-3          # bf16: ~4x the measured 1.2e-3 (profiles/r03_parity_report.txt)
     worst = 0.0
     for k in omodel.LOSS_NAMES:
       o = float(ora.last_losses[k])
@@ -193,16 +193,16 @@ def test_1024x512_train_step_vs_oracle(netG, batch):
     from hip_util import record
     record('%s %s losses vs oracle, whole step at 1024x512 batch %d (relative)' % (netG, dt, batch), worst, tol)
     if dt == 'bf16':
-      # bf16 has no reference counterpart: at least as close to the fp32 oracle as the bf16-storage emulation, minus 0.03, and
-      # gradient norms within 6 %
+      # bf16 has no reference counterpart: at least as close to the fp32 oracle as the bf16-storage emulation, minus 0.02, and
+      # gradient norms within 3 % (measured round 3: 0.002 global / 0.011 LocalEnhancer, norms 1.7 %)
       for k, p in tr.model.netG.named_parameters():
         if k.endswith('.weight') and p.grad is not None:
           a = p.grad.detach().cpu().double().flatten()
           r, e = oG[k].detach().double().flatten(), eG[k].detach().double().flatten()
-          assert cos(a, r) >= cos(e, r) - 0.03, '%s: bf16 vs fp32 oracle %.4f, emulation vs fp32 oracle %.4f' % (k, cos(a, r), cos(e, r))
-          assert abs(float(a.norm() / r.norm()) - 1.0) < 6e-2, '%s: bf16 gradient norm ratio %.4f' % (k, float(a.norm() / r.norm()))
-          record('%s bf16 weight gradients vs fp32 oracle: (emulation cosine - HIP cosine), worst layer' % netG, cos(e, r) - cos(a, r), 0.03, k)
-          record('%s bf16 weight gradients vs fp32 oracle: |norm ratio - 1|, worst layer' % netG, abs(float(a.norm() / r.norm()) - 1.0), 6e-2, k)
+          assert cos(a, r) >= cos(e, r) - 0.02, '%s: bf16 vs fp32 oracle %.4f, emulation vs fp32 oracle %.4f' % (k, cos(a, r), cos(e, r))
+          assert abs(float(a.norm() / r.norm()) - 1.0) < 3e-2, '%s: bf16 gradient norm ratio %.4f' % (k, float(a.norm() / r.norm()))
+          record('%s bf16 weight gradients vs fp32 oracle: (emulation cosine - HIP cosine), worst layer' % netG, cos(e, r) - cos(a, r), 0.02, k)
+          record('%s bf16 weight gradients vs fp32 oracle: |norm ratio - 1|, worst layer' % netG, abs(float(a.norm() / r.norm()) - 1.0), 3e-2, k)
     if dt == 'fp32':
       # gradients (they are still in .grad after the step): two correct fp32 implementations differ in the sign() gradients of
       # the L1 terms, so by direction and size rather than element-wise
@@ -221,6 +221,74 @@ def test_1024x512_train_step_vs_oracle(netG, batch):
           assert float((a - b).norm() / b.norm()) <= 2e-3, 'post-Adam %s: relative L2 %.3e' % (k, float((a - b).norm() / b.norm()))
     del tr
     torch.cuda.empty_cache()
+
+
+def test_config2_512x256_fp32_train_step_vs_oracle():
+  """BASELINE.json configs[1] as stated: 512x256, GlobalGenerator ngf 64 + 2-scale PatchGAN train step, fp32, no VGG loss
+  (`--no_vgg_loss --skip_unused_losses`: the VGG network is not run at all), batch 1, one MI355X -- the reference's own
+  arithmetic (pix2pixHD_trainer.py:42-85; no working --fp16 there).  Against the oracle on the same seeded weights: the five
+  losses the step computes within 1e-3 (G_VGG is reported as 0 by the skipping path; the sixth is compared through a second
+  forward without the skip), EVERY weight gradient of G and D with cosine >= 1 - 2e-4 and norm within 1.5e-3, post-Adam
+  weights of both networks within the sign-flip criterion (relative L2 <= 2e-3 per tensor, no element beyond 2.05 lr)."""
+  from hip_util import record
+  kw = dict(use_compressed=True, no_vgg_loss=True)
+  torch.manual_seed(2468)
+  ora = omodel.OracleTrainer(omodel.default_opt(**kw))
+  xd = omodel.synthetic_batch(1, 256, 512, seed=41)
+  sdG = {k: v.detach().clone() for k, v in ora.G.items()}
+  sdD = {k: v.detach().clone() for k, v in ora.D.items()}
+  oG, oD = ora.grads_in_dtype(xd, torch.float32)
+  ora.step(xd)
+  opt = _opts(compute_dtype='fp32', skip_unused_losses=True, **kw)
+  tr = get_trainer(opt)(opt, 'train')
+  tr.model.netG.load_state_dict(sdG)
+  tr.model.netD.load_state_dict(sdD)
+  # all six loss values, VGG term included, from a forward WITHOUT the skip (same weights, before the step)
+  opt6 = _opts(compute_dtype='fp32', **kw)
+  tr6 = get_trainer(opt6)(opt6, 'train')
+  tr6.model.netG.load_state_dict(sdG)
+  tr6.model.netD.load_state_dict(sdD)
+  tr.step(xd)
+  torch.cuda.synchronize()
+  worst = 0.0
+  for k in omodel.LOSS_NAMES:
+    o = float(ora.last_losses[k])
+    if k == 'G_VGG':
+      assert tr.last_losses[k] == 0.0, 'skip_unused_losses + no_vgg_loss: VGG must not run'
+      continue
+    worst = max(worst, abs(tr.last_losses[k] - o) / max(abs(o), 1e-3))
+    assert abs(tr.last_losses[k] - o) <= 1e-3 * max(abs(o), 1e-3), ('config 2 fp32 vs oracle', k, tr.last_losses[k], o)
+  record('config 2 (512x256 fp32, G + 2-scale D, no VGG, batch 1): losses vs oracle (relative)', worst, 1e-3)
+  cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
+  nchk = 0
+  for tag, net, ref in (('G', tr.model.netG, oG), ('D', tr.model.netD, oD)):
+    for k, p in net.named_parameters():
+      if k.endswith('.weight') and p.grad is not None and ref.get(k) is not None:
+        a, r = p.grad.detach().cpu().double().flatten(), ref[k].detach().double().flatten()
+        c, nr = cos(a, r), float(a.norm() / r.norm())
+        assert c >= 1.0 - 2e-4 and abs(nr - 1.0) < 1.5e-3, 'config 2 %s %s: cosine %.6f, norm ratio %.5f' % (tag, k, c, nr)
+        record('config 2 fp32 weight gradients vs oracle: 1 - cosine, worst layer', 1.0 - c, 2e-4, tag + ':' + k)
+        record('config 2 fp32 weight gradients vs oracle: |norm ratio - 1|, worst layer', abs(nr - 1.0), 1.5e-3, tag + ':' + k)
+        nchk += 1
+  assert nchk == 28 + 10, nchk                 # every conv of G (1 + 4 + 18 + 4 + 1) and of both PatchGAN scales (2 x 5)
+  for tag, net, ref in (('G', tr.model.netG, ora.G), ('D', tr.model.netD, ora.D)):
+    for k, v in net.state_dict().items():
+      if k.endswith('.weight'):
+        a, b = v.cpu().double(), ref[k].detach().double()
+        l2, el = float((a - b).norm() / b.norm()), float((a - b).abs().max())
+        assert l2 <= 2e-3 and el <= 2.05 * opt.lr, 'config 2 post-Adam %s %s: relative L2 %.3e, worst element %.3e' % (tag, k, l2, el)
+        record('config 2 fp32 post-Adam weights vs oracle: relative L2, worst tensor', l2, 2e-3, tag + ':' + k)
+  # the sixth loss: same weights (before the step), VGG run, against the oracle's forward
+  torch.manual_seed(2468)
+  ora2 = omodel.OracleTrainer(omodel.default_opt(**kw))
+  with torch.no_grad():
+    ref6 = dict(zip(omodel.LOSS_NAMES, [float(v) for v in ora2.train_losses(xd)]))
+  # (both sides build the same seeded He-normal VGG19, seed 20: the ImageNet file is a download, SURVEY 8c)
+  got6 = dict(zip(omodel.LOSS_NAMES, [float(v) for v in tr6.model.get_train_loss(xd)]))
+  for k in omodel.LOSS_NAMES:
+    assert abs(got6[k] - ref6[k]) <= 1e-3 * max(abs(ref6[k]), 1e-3), ('config 2 forward (no skip)', k, got6[k], ref6[k])
+  del tr, tr6
+  torch.cuda.empty_cache()
 
 
 def test_2048x1024_step_vs_oracle():

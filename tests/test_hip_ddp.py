@@ -153,3 +153,114 @@ def test_rccl_world_size_one_step_equals_plain_step(bf16_wire):
     assert worst <= 5e-3, worst
   else:
     assert equal, 'fp32 wire, one rank: the data-parallel step must be bit-identical to the plain step (worst %.3e)' % worst
+
+
+def _overlap_worker(rank, world, port, q, overlap):
+  for p in (ROOT, os.path.join(ROOT, 'jpd-se_amd'), os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    torch.cuda.set_device(0)
+    from ctu.trainers import get_trainer
+    from oracle.ctu_cpu import model as omodel
+    kw = dict(ngf=16, ndf=16, n_blocks_global=2)
+    opt = omodel.default_opt(gpu_ids=[0], print_losses=False, compute_dtype='bf16', ddp_overlap=overlap, **kw)
+    torch.manual_seed(77)
+    tr = get_trainer(opt)(opt, 'train')          # a process group with 2 ranks is up: data parallelism switches itself on
+    m = tr.model
+    assert tr._dp['overlap'] == overlap
+    tr.enable_data_parallel(bucket_bytes=1 << 20, overlap=overlap)      # again, with small buckets: several collectives per network
+    bg, bd = m.grad_buckets['G'], m.grad_buckets['D']
+    assert len(bg.buckets) >= 3 and bg.defer == (overlap == 'd_backward') and not bd.defer
+    m.ddp_timeline = []
+    seen = dict(at_d_bwd=[], at_g_bwd_end=[], at_adam_g=[], at_adam_d=[])
+    started = lambda b: sum(1 for x in b.buckets if x['handle'] is not None)
+    orig_bD, orig_bG = m.backward_D, m.backward_G
+    orig_sG, orig_sD = tr.optimizer_G.step, tr.optimizer_D.step
+
+    def backward_G(*a, **k):
+      r = orig_bG(*a, **k)
+      seen['at_g_bwd_end'].append(started(bg))           # buckets on the wire when G's backward has been enqueued
+      return r
+
+    def backward_D(*a, **k):
+      seen['at_d_bwd'].append(started(bg))               # ... and when D's backward is about to be enqueued
+      return orig_bD(*a, **k)
+
+    def step_G(*a, **k):
+      seen['at_adam_g'].append((dict(bg.stats), started(bg)))     # finish() ran: every handle waited for, then cleared
+      return orig_sG(*a, **k)
+
+    def step_D(*a, **k):
+      seen['at_adam_d'].append((dict(bd.stats), started(bd)))
+      return orig_sD(*a, **k)
+
+    m.backward_G, m.backward_D = backward_G, backward_D
+    tr.optimizer_G.step, tr.optimizer_D.step = step_G, step_D
+    full = omodel.synthetic_batch(2 * world, 128, 256, seed=5)
+    shard = {k: (v[2 * rank: 2 * rank + 2] if torch.is_tensor(v) else v) for k, v in full.items()}
+    for _ in range(3):
+      tr.step(shard)
+    torch.cuda.synchronize()
+    rows = []
+    for t in m.ddp_timeline:
+      el = lambda a, b: t[a].elapsed_time(t[b])
+      rows.append(dict(d_bwd_ms=el('g_bwd_end', 'd_bwd_end'), g_exposed_ms=el('d_bwd_end', 'g_reduced'),
+                       adam_g_ms=el('g_reduced', 'adam_g_end'), d_exposed_ms=el('adam_g_end', 'd_reduced'),
+                       stats_G=t['stats_G'], stats_D=t['stats_D']))
+    flatw = torch.cat([p.detach().float().reshape(-1) for p in m.netG.parameters()]).cpu()
+    gathered = [torch.zeros_like(flatw) for _ in range(world)]
+    dist.all_gather(gathered, flatw)
+    if rank == 0:
+      q.put(('ok', dict(nG=len(bg.buckets), nD=len(bd.buckets), seen=seen, rows=rows,
+                        same=all(torch.equal(gathered[0], g) for g in gathered))))
+  except Exception as e:
+    if rank == 0:
+      q.put(('error', repr(e)))
+    raise
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', ['d_backward', 'layers'])
+def test_two_rank_overlap_schedule_on_the_device_timeline(overlap):
+  """VERDICT r3 item 7a.  2 ranks sharing cuda:0 (gloo carries the collective), timing events on the compute stream
+  (Pix2PixHDModel.ddp_timeline) and the state of the work handles at the points where the schedule promises something:
+    * 'd_backward' (default): NO generator bucket is on the wire while G's backward is being enqueued (the one-workgroup-per-CU
+      ResnetBlock GEMMs keep the chip to themselves), ALL of them are when D's backward starts -- i.e. the all-reduce is issued
+      before D's backward begins, D's backward (d_bwd_ms > 0 on the device timeline) runs beside it;
+    * 'layers': buckets are on the wire before G's backward has finished (fired from the per-layer hooks);
+    * either way Adam(G) is enqueued only after every G handle has been waited for (finish()), Adam(D) after D's;
+    * the replicas end with identical weights.
+  What the test cannot show on one GPU: how long an RCCL reduction takes over xGMI (bench.py --gpus N prints
+  g_allreduce_exposed_ms from the same timeline on the node that has the GPUs)."""
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = 29900 + (os.getpid() % 1000) + (7 if overlap == 'layers' else 0)
+  procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
+  for p in procs:
+    p.start()
+  status, res = q.get(timeout=900)
+  for p in procs:
+    p.join(timeout=120)
+  assert status == 'ok', res
+  nG, nD, seen, rows = res['nG'], res['nD'], res['seen'], res['rows']
+  assert res['same'], 'replicas diverged'
+  assert len(rows) == 3 and nG >= 1 and nD >= 1
+  if overlap == 'd_backward':
+    assert seen['at_g_bwd_end'] == [0, 0, 0], 'a generator bucket was started inside G backward: %r' % (seen['at_g_bwd_end'],)
+    assert seen['at_d_bwd'] == [nG] * 3, "G's all-reduce must be issued before D's backward is enqueued: %r of %d" % (seen['at_d_bwd'], nG)
+  else:
+    assert all(n >= 1 for n in seen['at_g_bwd_end']), 'no bucket fired from the backward hooks: %r' % (seen['at_g_bwd_end'],)
+  for stats, still in seen['at_adam_g']:
+    assert stats['waited'] == nG and stats['buckets'] == nG and still == 0, 'Adam(G) enqueued before every G handle was waited for'
+  for stats, still in seen['at_adam_d']:
+    assert stats['waited'] == nD and still == 0, 'Adam(D) enqueued before every D handle was waited for'
+  for r in rows:
+    assert r['d_bwd_ms'] > 0.0 and r['g_exposed_ms'] >= 0.0 and r['adam_g_ms'] > 0.0
+    if overlap == 'd_backward':
+      assert r['stats_G']['started_before_finish'] == nG          # nothing left for finish() to start
+  print('%s: D backward %.2f ms beside the collective, exposed behind it %.2f ms (gloo through host memory: not RCCL\'s time)'
+        % (overlap, rows[-1]['d_bwd_ms'], rows[-1]['g_exposed_ms']))

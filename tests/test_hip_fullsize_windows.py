@@ -146,6 +146,21 @@ LAYERS_1024 = [
     ('d_layer1',         8, 257, 513,  64,  128, 4, 2, 2, PAD_ZERO,    False),   # odd sizes: ragged tiles
     ('d_layer3',         8, 65,  129,  256, 512, 4, 1, 2, PAD_ZERO,    False),   # 4x4 stride 1
     ('d_layer4',         8, 66,  130,  512, 1,   4, 1, 2, PAD_ZERO,    False),   # one output channel: thin1_dgrad / thin1_wgrad (thin_out1.h)
+    # round 4: the grids the list above left out
+    ('g_down_256_512',   4, 128, 256,  256, 512, 3, 2, 1, PAD_ZERO,    False),   # gemm_fast fwd, gemm_taps two-set dgrad, wgrad_taps
+    ('g_down_512_1024',  4, 64,  128,  512, 1024, 3, 2, 1, PAD_ZERO,   False),
+    ('g_up_convT_1024_512', 4, 32, 64, 1024, 512, 3, 2, 1, PAD_ZERO,   True),    # ConvTranspose forms of the same kernels
+    ('g_up_convT_512_256',  4, 64, 128, 512, 256, 3, 2, 1, PAD_ZERO,   True),
+    ('g_up_convT_256_128',  4, 128, 256, 256, 128, 3, 2, 1, PAD_ZERO,  True),
+    ('d_layer2',         8, 129, 257,  128, 256, 4, 2, 2, PAD_ZERO,    False),   # 4x4 stride 2 on the odd 129 x 257 grid
+    ('d_layer1_scale2',  8, 129, 257,  64,  128, 4, 2, 2, PAD_ZERO,    False),   # second PatchGAN scale (AvgPool'd input)
+    ('vgg_conv4_2',      8, 64,  128,  512, 512, 3, 1, 1, PAD_ZERO,    False),   # batched [fake ; real] VGG pass: halo kernel, 8 slabs
+    ('vgg_conv3_2',      8, 128, 256,  256, 256, 3, 1, 1, PAD_ZERO,    False),
+    # LocalEnhancer-only layers at full resolution (BASELINE config 3; networks.py:160-175)
+    ('local_resblock_64', 4, 256, 512, 64,  64,  3, 1, 1, PAD_REFLECT, False),   # single-slab halo + folded frame, wgrad_taps
+    ('local_down_32_64', 4, 512, 1024, 32,  64,  3, 2, 1, PAD_ZERO,    False),
+    ('local_convT_64_32', 4, 256, 512, 64,  32,  3, 2, 1, PAD_ZERO,    True),
+    ('local_head_32_3',  4, 512, 1024, 32,  3,   7, 1, 3, PAD_REFLECT, False),
 ]
 
 
@@ -182,3 +197,138 @@ LAYERS_2048 = [
 @pytest.mark.parametrize('case', LAYERS_2048, ids=[c[0] for c in LAYERS_2048])
 def test_2048x1024_windows_vs_torch_cpu_bf16(case):
   _check_layer(*case)
+
+
+# ---- round 4: the FUSED variants the bench step actually runs, element by element at the bench shape -------------------------
+# tests/test_hip_ops.py compares jpdse_conv_dgrad_fused / _fused_lrelu / jpdse_conv_fwd_pool / jpdse_conv_fwd_moments with
+# torch-CPU at toy sizes only; at 1024x512 their kernels (conv_rows<1,2,true>, the halo kernel's mask / addend epilogue, the
+# merged-phase fast kernel with the LeakyReLU gather, the pooled halo epilogue, the MOM epilogue) pick other strips and bands.
+def _act_input(name, N, H, W, C, slope):
+  """x = act(z) of a random pre-activation z (ReLU for slope 0, LeakyReLU(slope) otherwise), bf16."""
+  g = torch.Generator(device=DEV).manual_seed(zlib.crc32(name.encode()) % 1000 + 31)
+  x = Act.empty(N, H, W, C, BF16, DEV)
+  x.t.zero_()
+  z = torch.randn((N, H, W, C), generator=g, device=DEV)
+  x.t[..., :C] = (torch.relu(z) if slope == 0.0 else F.leaky_relu(z, slope)).to(torch.bfloat16)
+  return x, g
+
+
+FUSED_DGRAD_1024 = [
+    # name, N, H, W, C, K, k, stride, pad, mode, slope (0 = ReLU mask), addend
+    ('vgg_conv1_2 dgrad_fused',   4, 512, 1024, 64,  64,  3, 1, 1, PAD_ZERO, 0.0, True),    # conv_rows<1,2,true>
+    ('vgg_conv2_2 dgrad_fused',   4, 256, 512,  128, 128, 3, 1, 1, PAD_ZERO, 0.0, True),    # halo kernel epilogue: mask + fan-in addend
+    ('vgg_conv3_2 dgrad_fused',   4, 128, 256,  256, 256, 3, 1, 1, PAD_ZERO, 0.0, False),   # mask only
+    ('d_layer1 dgrad_fused_lrelu', 8, 257, 513, 64,  128, 4, 2, 2, PAD_ZERO, 0.2, False),   # loss_D backward: mask only, batch 8
+    ('d_layer1 dgrad_fused_lrelu+addend', 4, 257, 513, 64, 128, 4, 2, 2, PAD_ZERO, 0.2, True),   # loss_G backward: + feature-matching tap
+    ('d_layer2 dgrad_fused_lrelu+addend', 4, 129, 257, 128, 256, 4, 2, 2, PAD_ZERO, 0.2, True),
+]
+
+
+@pytest.mark.parametrize('case', FUSED_DGRAD_1024, ids=[c[0].replace(' ', '_') for c in FUSED_DGRAD_1024])
+def test_1024x512_fused_dgrad_windows_vs_torch_cpu_bf16(case):
+  """dx = (dgrad(dy) + addend) * act'(x) from ONE call (jpdse_conv_dgrad_fused / jpdse_conv_dgrad_fused_lrelu), compared element
+  by element on full-width row bands with torch-CPU autograd through conv(x) plus the addend and the mask applied in fp32."""
+  name, N, H, W, C, K, k, st, pad, mode, slope, with_addend = case
+  x, g = _act_input(name, N, H, W, C, slope)
+  layer = HipConv2d(C, K, k, st, pad, mode, act=ACT_NONE, apply_bias=False, dtype=BF16, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(torch.randn(layer.weight.shape, generator=g, device=DEV) * (1.0 / (C * k * k) ** 0.5))
+  y, ctx = layer.fwd(x)
+  OH, Ky = y.H, y.C
+  dy = y.empty_like()
+  dy.t.zero_()
+  dy.t[..., :Ky] = torch.randn(tuple(y.t.shape[:3]) + (Ky,), generator=g, device=DEV).to(torch.bfloat16)
+  addend = None
+  if with_addend:
+    addend = x.empty_like()
+    addend.t.zero_()
+    addend.t[..., :C] = torch.randn((N, H, W, C), generator=g, device=DEV).to(torch.bfloat16)
+  dx = layer.bwd(ctx, dy, need_dx=True, need_dw=False, relu_input=True, input_slope=slope, addend=addend)
+  torch.cuda.synchronize()
+  assert (dx.t[..., C:] == 0).all(), 'padding lanes must stay zero'
+  wq = layer.weight.detach().to(torch.bfloat16).float().cpu()
+  tol = RTOL[BF16]
+  nwin = 0
+  for n in sorted({0, N - 1}):
+    for (o0, o1) in _bands(OH):
+      a0, a1 = o0 * st - pad, (o1 - 1) * st - pad + k
+      pt, pb = max(0, -a0), max(0, a1 - H)
+      a0c, a1c = max(0, a0), min(H, a1)
+      xb = _nchw(x.t[n:n + 1, a0c:a1c], C).requires_grad_(True)
+      yb = _conv_band(xb, wq, k, st, pad, mode, pt, pb)
+      yb.backward(_nchw(dy.t[n:n + 1, o0:o1], Ky))
+      lo = 0 if o0 == 0 else a0c + (k - 1)
+      hi = H if o1 == OH else a1c - (k - 1)
+      if hi - lo < 2:
+        continue
+      want = xb.grad[:, :, lo - a0c:hi - a0c]
+      if addend is not None:
+        want = want + _nchw(addend.t[n:n + 1, lo:hi], C)
+      xs = xb.detach()[:, :, lo - a0c:hi - a0c]
+      want = want * torch.where(xs > 0, torch.ones_like(xs), torch.full_like(xs, slope))
+      got = _nchw(dx.t[n:n + 1, lo:hi], C)
+      assert_close(got, want, tol, name + ' band', detail='rows %d..%d image %d' % (lo, hi, n))
+      if slope == 0.0:
+        assert (got[xs <= 0] == 0).all(), name + ': ReLU-masked elements must be exactly zero'
+      nwin += 1
+  assert nwin >= 4
+
+
+FWD_POOL_1024 = [
+    ('vgg_conv2_2 fwd_pool', 8, 256, 512, 128, 128),     # batched [fake ; real] pass: batch 8
+    ('vgg_conv3_4 fwd_pool', 8, 128, 256, 256, 256),
+    ('vgg_conv4_4 fwd_pool', 8, 64,  128, 512, 512),
+]
+
+
+@pytest.mark.parametrize('case', FWD_POOL_1024, ids=[c[0].replace(' ', '_') for c in FWD_POOL_1024])
+def test_1024x512_conv_fwd_pool_windows_vs_torch_cpu_bf16(case):
+  """jpdse_conv_fwd_pool at the batched VGG19 shapes: conv + bias + ReLU on row bands against torch-CPU, and the pooled output
+  against MaxPool2d(2, 2) of the device's own conv output, exactly (max is exact), over the COMPLETE tensor."""
+  from jpdse_hip import ACT_RELU
+  name, N, H, W, C, K = case
+  g = torch.Generator(device=DEV).manual_seed(zlib.crc32(name.encode()) % 1000)
+  layer = HipConv2d(C, K, 3, 1, 1, PAD_ZERO, act=ACT_RELU, dtype=BF16, device=DEV)
+  with torch.no_grad():
+    layer.weight.copy_(torch.randn(layer.weight.shape, generator=g, device=DEV) * (2.0 / (C * 9)) ** 0.5)
+    layer.bias.copy_(torch.randn(K, generator=g, device=DEV) * 0.1)
+  x = Act.empty(N, H, W, C, BF16, DEV)
+  x.t.copy_(torch.relu(torch.randn((N, H, W, C), generator=g, device=DEV)).to(torch.bfloat16))
+  y, yp, ctx = layer.fwd_pool(x)
+  torch.cuda.synchronize()
+  assert tuple(yp.t.shape) == (N, H // 2, W // 2, K)
+  ref = y.t.view(N, H // 2, 2, W // 2, 2, K).amax(dim=(2, 4))
+  assert torch.equal(yp.t, ref), name + ': pooled output is not the 2x2 maximum of the conv output'
+  wq = layer.weight.detach().to(torch.bfloat16).float().cpu()
+  b = layer.bias.detach().float().cpu()
+  for n in (0, N - 1):
+    for (o0, o1) in _bands(H):
+      a0, a1 = o0 - 1, o1 + 1
+      pt, pb = max(0, -a0), max(0, a1 - H)
+      xb = _nchw(x.t[n:n + 1, max(0, a0):min(H, a1)], C)
+      yb = torch.relu(_conv_band(xb, wq, 3, 1, 1, PAD_ZERO, pt, pb) + b.view(1, -1, 1, 1))
+      assert_close(_nchw(y.t[n:n + 1, o0:o1], K), yb, RTOL[BF16], name + ' conv band', detail='rows %d..%d image %d' % (o0, o1, n))
+
+
+def test_1024x512_resblock_fwd_moments_complete_vs_torch_cpu_bf16():
+  """The MOM instantiation of the halo kernel at the ResnetBlock bench shape (jpdse_conv_fwd_moments): the conv output as a
+  complete tensor against torch-CPU, bit-identical to the plain forward launch, and the (mean, rstd) its epilogue slots merge to
+  against an fp64 pass over the stored tensor."""
+  from jpdse_hip.layers import InstNormAct
+  name, N, H, W, C = 'resblock_1024_mom', 4, 32, 64, 1024
+  layer, x, y, dy, dx, wq = _make(name, N, H, W, C, C, 3, 1, 1, PAD_REFLECT, False)
+  fused = layer.fwd_moments(x)
+  assert fused is not None, 'the ResnetBlock conv is expected to take the fused-moment epilogue'
+  y2, _c, mom, slots = fused
+  yn, nctx = InstNormAct(ACT_NONE).fwd_from_moments(y2, mom, slots)
+  torch.cuda.synchronize()
+  assert torch.equal(y2.t, y.t), 'the MOM launch must produce the plain launch\'s output bit for bit'
+  yr = _conv_band(_nchw(x.t, C), wq, 3, 1, 1, PAD_REFLECT, 1, 1)
+  assert_close(_nchw(y2.t, C), yr, RTOL[BF16], name + ' fwd (complete)')
+  stats = nctx.items[1]
+  hf = y2.t[..., :C].double()
+  mean_ref, var_ref = hf.mean(dim=(1, 2)), hf.var(dim=(1, 2), unbiased=False)
+  assert_close(stats[:, :C, 0].cpu(), mean_ref.cpu(), 2e-5, name + ' fused mean vs fp64 of the stored tensor', elementwise=False)
+  assert_close(stats[:, :C, 1].cpu(), (var_ref + 1e-5).rsqrt().cpu(), 5e-5, name + ' fused rstd vs fp64 of the stored tensor')
+  yref = (hf - mean_ref[:, None, None]) * (var_ref + 1e-5).rsqrt()[:, None, None]
+  assert_close(yn.t[..., :C].float().cpu(), yref.float().cpu(), RTOL[BF16], name + ' norm output from the fused moments')

@@ -590,6 +590,83 @@ def test_conv_norm_fused_moments_offset_channels_full_size(name, make, shape):
   assert_close(y.t.float().cpu(), y2.t.float().cpu(), RTOL[BF16], name + ' norm output, fused vs separate moments')
 
 
+# InstanceNorm backward with its two per-channel sums taken from the epilogue of the data-gradient kernel that produced dy
+# (jpdse_conv_dgrad_fused_nsums -> jpdse_inorm_bwd_from_sums; round 4): the ResnetBlock chain on the folded-frame halo kernel.
+@pytest.mark.parametrize('shape', [(2, 128, 8, 128), (1, 256, 16, 64)], ids=['128ch', '256ch'])
+def test_resblock_norm_backward_sums_from_dgrad_epilogue(shape):
+  from jpdse_hip.layers import HipResnetBlock, run_chain_fwd, run_chain_bwd
+  N, C, H, W = shape
+  g = G(C + H)
+  blocks = [HipResnetBlock(C, dtype=BF16, device=DEV) for _ in range(3)]
+  with torch.no_grad():
+    for b in blocks:
+      for i in (1, 5):
+        b.conv_block[i].weight.copy_(torch.randn(b.conv_block[i].weight.shape, generator=g) * (1.0 / (C * 9)) ** 0.5)
+  x = to_act(quantize_like(torch.randn(N, C, H, W, generator=g), BF16), BF16)
+  y, ctxs = run_chain_fwd(blocks, x)
+  gy = to_act(quantize_like(torch.randn(N, C, H, W, generator=g), BF16), BF16)
+  calls = []
+  orig = ops.conv_dgrad_nsums
+  ops.conv_dgrad_nsums = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+  try:
+    dx = run_chain_bwd(blocks, ctxs, gy, True, True)
+  finally:
+    ops.conv_dgrad_nsums = orig
+  torch.cuda.synchronize()
+  # block 2: conv2 -> norm1 sums, conv1 -> block 1's norm2 sums; block 1 likewise; block 0: conv2 only (its dx leaves the chain)
+  assert len(calls) == 5, 'expected 5 data gradients with the norm-backward-sum epilogue, saw %d' % len(calls)
+  dws = [b.conv_block[i].weight.grad.clone() for b in blocks for i in (1, 5)]
+  for b in blocks:
+    b.fuse_norm_sums = False
+  dx2 = run_chain_bwd(blocks, ctxs, gy, True, True)
+  torch.cuda.synchronize()
+  assert_close(to_nchw(dx), to_nchw(dx2), RTOL[BF16], 'ResnetBlock chain dx: norm sums from the dgrad epilogue vs the separate pass')
+  for a, b in zip(dws, [b.conv_block[i].weight.grad for b in blocks for i in (1, 5)]):
+    assert_close(a.cpu(), b.cpu(), RTOL[BF16], 'ResnetBlock chain dw: norm sums from the dgrad epilogue vs the separate pass')
+
+
+def test_dgrad_nsums_slots_vs_fp64():
+  """The slots themselves: sum dz and sum dz * yhat per (image, channel) against an fp64 evaluation from the tensors the
+  kernel stored / read (dy as written, x, stats), ReLU norm and plain norm."""
+  from jpdse_hip.layers import InstNormAct
+  N, C, H, W = 2, 128, 12, 128
+  g = G(91)
+  conv = HipConv2d(C, C, 3, 1, 1, PAD_REFLECT, apply_bias=False, dtype=BF16, device=DEV)
+  with torch.no_grad():
+    conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (1.0 / (C * 9)) ** 0.5)
+  xin = to_act(quantize_like(torch.randn(N, C, H, W, generator=g), BF16), BF16)
+  y, ctx = conv.fwd(xin)
+  gy = to_act(quantize_like(torch.randn(N, C, H, W, generator=g), BF16), BF16)
+  for act in (ACT_RELU, ACT_NONE):
+    norm = InstNormAct(act)
+    nx = to_act(quantize_like(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.5, BF16), BF16)      # the norm's input
+    _, nctx = norm.fwd(nx)
+    other = to_act(quantize_like(torch.randn(N, C, H, W, generator=g), BF16), BF16)
+    dx = conv.bwd(ctx, gy, need_dx=True, need_dw=False, addend=other, sink=norm.sink(nctx))
+    ref = conv.bwd(ctx, gy, need_dx=True, need_dw=False, addend=other)
+    torch.cuda.synchronize()
+    assert dx.nsums is not None and torch.equal(dx.t, ref.t), 'the data gradient itself must not change'
+    sums, slots, _ = dx.nsums
+    assert slots == (H // 4) * (W // 64) and tuple(sums.shape) == (N, C, slots, 2)
+    stats = nctx.items[1].double()
+    xv, dv = nx.t[..., :C].double(), dx.t[..., :C].double()
+    yh = (xv - stats[:, None, None, :C, 0]) * stats[:, None, None, :C, 1]
+    dz = dv * (yh > 0).double() if act == ACT_RELU else dv
+    want = torch.stack([dz.sum(dim=(1, 2)), (dz * yh).sum(dim=(1, 2))], dim=-1)
+    got = sums.double().sum(dim=2)
+    scale = (dz.pow(2).sum(dim=(1, 2)).sqrt()[..., None] * torch.stack([torch.ones_like(want[..., 0]).mul(H * W).sqrt(), yh.pow(2).sum(dim=(1, 2)).sqrt()], dim=-1))
+    err = ((got - want).abs() / scale).max().item()
+    from hip_util import record
+    record('norm-backward sums from the dgrad epilogue vs fp64 (of the Cauchy-Schwarz scale), act %d' % act, err, 2e-6)
+    assert err <= 2e-6, err
+    # and the backward through them equals the separate-pass backward
+    a = norm.bwd(nctx, dx)
+    dx.nsums = None
+    b = norm.bwd(nctx, dx)
+    torch.cuda.synchronize()
+    assert_close(to_nchw(a), to_nchw(b), RTOL[BF16], 'inorm_bwd_from_sums vs inorm_bwd, act %d' % act)
+
+
 # ---- instance norm -----------------------------------------------------------------------------
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('act', [ACT_NONE, ACT_RELU, ACT_LRELU])

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_header_symbols():
   L = jpdse_hip.lib()
-  assert L.jpdse_version() == 1
+  assert L.jpdse_version() == 2
   header = open(os.path.join(ROOT, 'include', 'jpdse.h')).read()
   declared = set(re.findall(r'\b(jpdse_[a-zA-Z0-9_]+)\s*\(', header))
   declared -= {'jpdse_conv_desc', 'jpdse_inorm_desc', 'jpdse_adam_entry'}
