@@ -14,28 +14,27 @@
 extern "C" {
 #endif
 
-/* Developer A/B switch (kernel SELECTION only, results stay correct except for
- * the timing-only ablation codes >= 100): 0 = every convolution on the generic register-staged
- * kernels; 1 (default) = all specialised bf16 kernels; 3 = no halo kernel; 4 = no per-filter-row
- * weight gradient; 5 = heads without the Toeplitz GEMM; 6 = no split-K and no head kernel (same
- * summation order as the generic kernels: bit-comparable); 7 = reflect data gradient on the padded
- * domain; 8 = halo kernel always double buffered; 9 / 10 = long-K-only phase merging / no 128-row
- * tiles; 12 = no all-taps weight gradient; 13 = no tap-sum forward; 14 = no head kernel;
- * 15 / 16 = XCD-aware halo tile orders; 18 = no thin-input forward kernel; 19 = halo kernel on
- * 16x16x32 MFMA fragments; 21 / 22 / 24 = unpipelined loop forms of the nine-tap weight gradient (default:
- * software-pipelined fragment reads); 23 = halo kernel with waves 4..7 issuing their DMA group after the MFMA
- * cluster; 25 = halo kernel with software-pipelined fragment reads; 26 = merged stride-phase data gradient only
- * from 384 tiles on; 27 = InstanceNorm always as three kernels; 28 = InstanceNorm as one kernel with the
- * in-launch exchange; 29 = the 64-channel / thin-input layers on the halo / fast kernels instead of the
- * row-streaming family; 30 = fast kernel with the XCD-aware tile order; 31 = reflect ring strips on 128-row
- * tiles; 32 = no InstanceNorm moments in conv epilogues; 35 = stride-2 data gradients on the merged-phase fast kernel instead
- * of the tap-program halo kernel (gemm_taps.h); 36 = 4x4 stride-1 layers on the fast kernel alone; 38 = 3x3 layers with
- * 32-pixel-wide grids on the split-K fast kernel instead of the nine-tap program; 40 = reflect data gradient as halo kernel +
- * four ring-strip GEMMs + ring_fold_kernel instead of the folded frame (gemm_halo.h VIRT); 41 = the one-output-channel layers
- * backward on the GEMM paths instead of thin_out1.h; 42 = 4x4 stride-2 data gradients on the merged-phase fast kernel only;
- * 43 = the same layers on the tap program + fringe (developer build only: measured slower in the step);
- * 44 / 45 = 3- / 4-stage rings for the 128-row short-K configurations of the fast kernel (measured 25-50 % slower);
- * 46 = 128-row tiles also for the <= 16-tile loops with wide outputs (the shipped build takes 64 x 128 tiles there).  100 + bits = timing-only ablations of the halo loop.
+/* Developer A/B switch (kernel SELECTION only, results stay correct except for the timing-only ablation codes >= 100):
+ * 0 = every convolution on the generic register-staged kernels; 1 (default) = all specialised bf16 kernels; 3 = no halo kernel;
+ * 4 = no all-nine-taps weight gradient; 5 = heads without the Toeplitz GEMM; 6 = no split-K, no head kernel, no tap programs, no
+ * persistent kernel (same summation order as the generic kernels: bit-comparable); 7 = reflect data gradient on the padded domain;
+ * 8 = halo kernel always double buffered; 9 / 10 = long-K-only phase merging / no 128-row tiles; 12 = no all-taps weight gradient;
+ * 13 = no tap-sum forward; 14 = no head kernel; 15 / 16 = XCD-aware halo tile orders; 18 = no thin-input forward kernel;
+ * 19 = halo kernel on 16x16x32 MFMA fragments; 26 = merged stride-phase data gradient only from 384 tiles on; 27 = InstanceNorm
+ * always as three kernels; 28 = InstanceNorm as one kernel with the in-launch exchange; 29 = the 64-channel / thin-input layers on
+ * the halo / fast kernels instead of the row-streaming family; 32 = no InstanceNorm moments in conv epilogues; 35 = stride-2 data
+ * gradients on the merged-phase fast kernel instead of the tap-program halo kernel (gemm_taps.h); 36 = 4x4 stride-1 layers on the
+ * fast kernel alone; 38 = 3x3 layers with 32-pixel-wide grids on the split-K fast kernel instead of the nine-tap program;
+ * 40 = reflect data gradient as halo kernel + four ring-strip GEMMs + ring_fold_kernel instead of the folded frame (gemm_halo.h
+ * VIRT); 41 = the one-output-channel layers backward on the GEMM paths instead of thin_out1.h; 42 = 4x4 stride-2 data gradients on
+ * the merged-phase fast kernel only; 43 = the same layers on the tap program + fringe (measured slower in the step);
+ * 48 = fp32 generic kernel without split-K; 50 = the short-K layers on gemm_fast_kernel instead of the persistent form
+ * (gemm_pers.h); 51 = every fast-kernel layer without split-K on the persistent form; 52 = the persistent form from one tile on
+ * and for any K (tests).  100 + bits = timing-only ablations of the halo loop.
+ * Retired in round 4 with their negative results on record (profiles/r0*_ab.txt; the code paths are gone):
+ * 21 / 22 / 24 (unpipelined loop forms of the nine-tap weight gradient), 23 (halo kernel, staggered DMA issue), 25 (halo kernel,
+ * hand-pipelined fragment reads), 30 (fast kernel, XCD-aware tile order), 31 (ring strips on 128-row tiles), 44 / 45 (3- / 4-stage
+ * rings for the 128-row short-K configurations), 46 (no 64-row tiles for the short loops).
  * Each call resets the others to their defaults. */
 int jpdse_debug_set_fast_path(int32_t enable);
 

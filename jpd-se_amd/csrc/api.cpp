@@ -28,6 +28,7 @@ int check_launch(const char* what) {
 struct HbmProf {
   bool on = false;
   int used = 0;
+  int max_regions = 0;          // of the CURRENT selection: `ev` only ever grows, `bytes` / `cls` are sized to this
   std::vector<hipEvent_t> ev;   // 2 per region
   std::vector<double> bytes;
   std::vector<int> cls;
@@ -35,7 +36,7 @@ struct HbmProf {
 static HbmProf g_hbm;
 
 int hbm_prof_begin(hipStream_t s) {
-  if (!g_hbm.on || (size_t)(2 * g_hbm.used + 2) > g_hbm.ev.size()) return -1;
+  if (!g_hbm.on || g_hbm.used >= g_hbm.max_regions || (size_t)(2 * g_hbm.used + 2) > g_hbm.ev.size()) return -1;
   (void)hipEventRecord(g_hbm.ev[2 * g_hbm.used], s);
   return g_hbm.used++;
 }
@@ -55,6 +56,7 @@ int jpdse_prof_hbm_select(int32_t enable, int32_t max_regions) {
   using jpdse::g_hbm;
   g_hbm.on = false;
   g_hbm.used = 0;
+  g_hbm.max_regions = 0;
   if (!enable) return JPDSE_OK;
   JPDSE_REQUIRE(max_regions > 0, "prof_hbm_select: max_regions must be positive");
   while (g_hbm.ev.size() < (size_t)2 * max_regions) {
@@ -64,6 +66,7 @@ int jpdse_prof_hbm_select(int32_t enable, int32_t max_regions) {
   }
   g_hbm.bytes.assign(max_regions, 0.0);
   g_hbm.cls.assign(max_regions, -1);
+  g_hbm.max_regions = max_regions;
   g_hbm.on = true;
   return JPDSE_OK;
 }

@@ -364,18 +364,18 @@ static int conv_dgrad_t(const jpdse_conv_desc* d, const ConvPlan& p, const void*
       const bf16_t* pk = reinterpret_cast<const bf16_t*>(pack);
       const int Mtb = d->N * (W + 2), Mlr = d->N * H;
       const int nt = (p.Cs + 127) / 128;
-      // the strips have few rows (N (W + 2) and N H); developer mode 31 tries 128-row tiles (two blocks per CU): slower
-      const int bm = g_ring_small ? 128 : 256;
+      // the strips have few rows (N (W + 2) and N H); 128-row tiles (two blocks per CU) measured slower (round-2 mode 31, retired)
+      const int bm = 256;
       const int tiles = 2 * ((Mtb + bm - 1) / bm) * nt + 2 * ((Mlr + bm - 1) / bm) * nt;
       const int kt = 3 * Ks / 64;
-      int sp = (g_ring_small ? 512 : 256) / tiles;
+      int sp = 256 / tiles;
       if (sp > kt / 8) sp = kt / 8;
       if (sp > 8) sp = 8;
       if (sp < 1) sp = 1;
       float* slab = reinterpret_cast<float*>(wsb);
       const size_t tb_elems = (size_t)sp * Mtb * p.Cs, lr_elems = (size_t)sp * Mlr * p.Cs;
       FastBatch rb = {};
-      rb.small_m = g_ring_small;
+      rb.small_m = 0;
       for (int q = 0; q < 4; ++q) {
         FastArgs g = {};
         const bool row_strip = q < 2;         // 0 top, 1 bottom, 2 left, 3 right

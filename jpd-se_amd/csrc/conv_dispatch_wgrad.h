@@ -279,7 +279,6 @@ static size_t wgrad_nine_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
   return a.splits > 1 ? (size_t)a.splits * d->K * 9 * d->C * sizeof(float) : 0;
 }
 
-JPDSE_SWITCH(int, g_nine_sched, 3);
 template <bool REFLECT, int SCHED>
 static int launch_wgrad_nine_cfg(const NineWgArgs& a, hipStream_t s) {
   static bool configured = false;
@@ -320,11 +319,6 @@ static int launch_wgrad_nine(const jpdse_conv_desc* d, const ConvPlan& p, const 
   if (a.splits > 1 && ((long long)d->K * 9 * d->C) % 4 != 0)
     return set_error(JPDSE_EINVAL, "wgrad_nine: K*9*C = %lld is not a multiple of 4", (long long)d->K * 9 * d->C);
   if (d->pad_mode != JPDSE_PAD_REFLECT) return launch_wgrad_nine_cfg<false, 3>(a, s);
-#ifdef JPDSE_DEV
-  if (g_nine_sched == 0) return launch_wgrad_nine_cfg<true, 0>(a, s);
-  if (g_nine_sched == 1) return launch_wgrad_nine_cfg<true, 1>(a, s);
-  if (g_nine_sched == 2) return launch_wgrad_nine_cfg<true, 2>(a, s);
-#endif
   return launch_wgrad_nine_cfg<true, 3>(a, s);
 }
 

@@ -93,6 +93,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "head_fwd.h"
 #include "thin_fwd.h"
 #include "conv_rows.h"
+#include "gemm_pers.h"
 #include "dgrad2_rows.h"
 #include "head_rows.h"
 #include "thin_dgrad2_rows.h"
@@ -162,16 +163,11 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_thin1_enabled = enable != 41 && enable != 6;   // 41: the one-output-channel layers (PatchGAN 512 -> 1) backward on the GEMM paths (A/B)
   g_taps_dgrad4_enabled = enable != 42 && enable != 6;   // 42: 4x4 stride-2 data gradients (PatchGAN layers 1-2) on the merged-phase fast kernel (A/B)
   g_taps_dgrad4_min_tiles = enable == 43 ? 1 : (1 << 30);     // 43: 4x4 stride-2 data gradients on the tap program + fringe (developer build only: slower in the step)
-  g_fast_small_stages = enable == 44 ? 3 : (enable == 45 ? 4 : (enable == 46 ? 64 : 2));   // 46: no 64-row tiles for the <= 16-tile loops (A/B)
-  //   // 44 / 45: 3- / 4-stage rings for the 128-row short-K fast configs (A/B)
-  g_ring_small = enable == 31;       // 31: ring strips of the reflect data gradient on 128-row tiles (A/B)
-  g_fast_xcd = enable == 30;         // 30: fast kernel with the XCD-aware tile order (A/B)
   g_taps9_enabled = enable != 38 && enable != 6;   // 38: 3x3 layers with 32-pixel-wide grids on the split-K fast kernel (A/B)
   g_taps4_enabled = enable != 36 && enable != 6;   // 36: 4x4 stride-1 layers on the fast kernel alone (A/B)
   g_taps_enabled = enable != 35 && enable != 6;   // 35: stride-2 data gradients on the merged-phase fast kernel instead of the tap-program halo kernel (A/B); 6 keeps the generic kernels' summation order (tap outer, slab inner)
   g_rows_enabled = enable != 29 && enable != 3;   // 29: 64-channel 3x3 layers on the halo / fast kernels instead of conv_rows (A/B)
   g_halo_abl = (enable >= 100 && enable < 200) ? enable - 100 : 0;
-  g_nine_sched = enable == 21 ? 0 : (enable == 22 ? 1 : (enable == 24 ? 2 : 3));   // 21 / 22 / 24: unpipelined loop forms of the nine-tap weight gradient (A/B); default 3 = software-pipelined fragment reads   // 21 / 22: DMA issue placement of the nine-tap weight gradient (A/B)
   g_wgrad_nine_enabled = enable != 4;    // 4: wide 3x3 layers on the per-tap fast weight gradient instead of the all-nine-taps one (A/B)
   g_wgrad_taps_enabled = enable != 12;   // 12: fast kernels without the all-taps weight gradient (A/B)
   g_ring_enabled = enable != 7 && enable != 3;   // 7: reflect data gradient on the padded domain + fold (A/B)
@@ -180,15 +176,16 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_merge_min_tiles = enable == 26 ? 384 : 64;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
   g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
-  g_halo_mf16 = enable == 19;
-  g_halo_stag = enable == 23;
-  g_halo_pipe = enable == 25 ? 1 : 0;         // 19: halo kernel on 16x16x32 MFMAs (A/B)
+  g_halo_mf16 = enable == 19;         // 19: halo kernel on 16x16x32 MFMAs (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_head_fwd_enabled = enable != 14 && enable != 6;   // 14: heads on the Toeplitz GEMM (A/B); 6 keeps the generic order
   g_thin_fwd_enabled = enable != 18;  // 18: thin-input forward on the generic kernel (A/B)
   g_tapsum_enabled = enable != 13;    // 13: narrow-output layers without the tap-sum forward (A/B)
   g_thin_out_fast = enable != 13;     // 13: narrow-output long-K layers on the generic kernel (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
+  g_pers_enabled = enable != 50 && enable != 6;   // 50: the short-K layers on gemm_fast_kernel instead of the persistent form (A/B)
+  g_pers_max_kt = (enable == 51 || enable == 52) ? (1 << 20) : 24;
+  g_pers_min_tiles = enable == 52 ? 1 : 256;      // 52: the persistent form from one tile on and for any K (tests)  // 51: every fast-kernel layer without split-K on the persistent form (A/B)
   g_generic_splitk = enable != 48;    // 48: fp32 generic kernel without split-K (A/B; BASELINE config 2)
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
   return JPDSE_OK;

@@ -49,7 +49,7 @@ static int launch_fwd_cfg(const GemmFwdArgs& a_in, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Ks + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * 64;
   // split-K (fp32, few tiles): only with a slab region big enough behind `partial` (the plan sized it with the same function)
-  a.splits = (a.col_mod == 0 && a.partial != nullptr) ? generic_splitk_for((int)sizeof(T), a.M, a.Ks, a.R * a.cpr) : 1;
+  a.splits = (a.col_mod == 0 && a.partial != nullptr) ? generic_splitk_for((int)sizeof(T), a.M, a.Ks, a.R * a.cpr, a.M / (a.OH * a.OW)) : 1;
   if (a.splits > 1 && (size_t)a.splits * a.M * a.Ks * sizeof(float) > a.partial_cap) a.splits = 1;
   const long long kdim = (long long)a.R * a.cpr * (64 / (int)sizeof(T));
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
@@ -129,7 +129,6 @@ static int launch_wgrad(const GemmWgradArgs& a, float* slabs, hipStream_t s) {
   return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, slabs, s);
 }
 
-JPDSE_SWITCH(int, g_fast_xcd, 0);         // 30: N-tiles of an M-tile on one XCD (measured neutral: +5 % on the PatchGAN layer-3 data gradient, -4 % on the 1024 -> 512 ConvTranspose; memory-side fetch is not what bounds these layers)
 template <int WM, int WN, int TM, int TN, int VAR, int STAGES = 3>
 static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -161,7 +160,7 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
         return set_error(JPDSE_EINVAL, "gemm_fast: problem %d addresses element %lld of a %lld-element input", i, last, a.x_extent);
     }
     b.first_tile[i] = total;
-    b.p[i].xcd_map = (g_fast_xcd && a.splits <= 1 && (a.Ks + BN - 1) / BN >= 2 && (a.M + BM - 1) / BM >= 16) ? 1 : 0;
+    b.p[i].xcd_map = 0;       // (the XCD-aware tile order, round-3 developer mode 30, measured neutral and was retired: DESIGN.md 4.1 (xi))
     total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN) * (a.splits > 1 ? a.splits : 1);
     const long long kdim = (long long)a.R * a.S * a.Cs;
     flops += 2.0 * (double)a.M * (double)a.Ks * (double)kdim;
@@ -193,7 +192,65 @@ static bool prefer_320(int M, int Ks) {
   return c320 < c256;
 }
 
-JPDSE_SWITCH(int, g_fast_small_stages, 2);   // 44 / 45: 3- / 4-stage rings for the 128-row short-K configs (A/B)
+// ---- persistent, cross-tile-pipelined form for the short-K layers (gemm_pers.h) -------------------------------------------
+JPDSE_SWITCH(int, g_pers_enabled, 1);     // 50: these layers on gemm_fast_kernel (A/B)
+JPDSE_SWITCH(int, g_pers_max_kt, 24);     // K-tile count up to which the persistent form is taken (51: every fast-kernel layer without split-K, A/B)
+JPDSE_SWITCH(int, g_pers_min_tiles, 256); // 52: from one tile on (tests: ragged tails and multi-problem launches at small sizes)
+static bool pers_ok(const FastBatch& b) {
+  if (!g_pers_enabled || b.n <= 0 || b.small_m) return false;
+  const int Ks = b.p[0].Ks;
+  long long tiles = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const FastArgs& a = b.p[i];
+    const int kt = a.R * a.S * (a.Cs / 64);
+    if (a.splits > 1 || a.no_finish || a.mask != nullptr || a.addend != nullptr || a.bias != nullptr || a.act == JPDSE_ACT_TANH) return false;
+    if (a.Ks != Ks || a.Ks < 64 || a.Ks % 8 != 0 || a.Cs % 64 != 0 || kt < 4 || kt > g_pers_max_kt || a.M <= 0) return false;
+    // 32-bit output offsets in the per-wave epilogue
+    const long long n_img = (a.M + (long long)a.OH * a.OW - 1) / ((long long)a.OH * a.OW);
+    const long long last = a.out_base + (n_img - 1) * a.out_sn + (long long)(a.OH - 1) * a.out_sh + (long long)(a.OW - 1) * a.out_sw + a.Ks;
+    if (a.out_base < 0 || last >= (1LL << 31)) return false;
+    tiles += (long long)((a.M + 255) / 256) * ((a.Ks + (Ks > 64 ? 127 : 63)) / (Ks > 64 ? 128 : 64));
+  }
+  if (g_pers_min_tiles <= 1) return tiles >= 1 && tiles < (1LL << 30);       // developer mode 52 (tests)
+  // Measured per layer in one process (profiles/r04_pers_v2_ab.txt): +8-10 % where the 256-row tiles fill whole rounds of the
+  // 256 CUs (128 <-> 256 channels, 3x3 stride 2: 1024 tiles), -4 % on PatchGAN layer 1 (1037 tiles: a fifth round for 13 of
+  // them), -10 % on layer 2 (526 tiles: 2.05 rounds), neutral at 36 K-tiles.  So: whole rounds only (<= 3 % of idle slots), short loops.
+  const long long rounds = (tiles + 255) / 256;
+  return tiles >= g_pers_min_tiles && tiles < (1LL << 30) && (rounds * 256 - tiles) * 32 <= tiles;
+}
+
+template <int TN>
+static int launch_pers_cfg(FastBatch& b, hipStream_t s) {
+  constexpr int BN = 2 * TN * 32;
+  constexpr int lds = 3 * (256 + BN) * 128;
+  static bool configured = false;
+  static int cus = 256;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<TN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_pers: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    configured = true;
+  }
+  int total = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const FastArgs& a = b.p[i];
+    if (a.Y == nullptr) return set_error(JPDSE_EINVAL, "gemm_pers: problem %d has no output buffer", i);
+    if ((a.x_sh ? a.x_sh : (long long)a.IW * a.Cs) * a.IH >= (1LL << 31))
+      return set_error(JPDSE_EINVAL, "gemm_pers: one image spans >= 2^31 elements (in-image offsets are 32-bit)");
+    b.first_tile[i] = total;
+    total += ((a.M + 255) / 256) * ((a.Ks + BN - 1) / BN);
+  }
+  for (int i = b.n; i < 5; ++i) b.first_tile[i] = total;
+  const int grid = total < cus ? total : cus;
+  hipLaunchKernelGGL((gemm_pers_kernel<TN>), dim3(grid), dim3(512), lds, s, b, total);
+  return check_launch("gemm_pers_kernel");
+}
+
+static int launch_pers(FastBatch& b, hipStream_t s) {
+  return b.p[0].Ks > 64 ? launch_pers_cfg<2>(b, s) : launch_pers_cfg<1>(b, s);
+}
+
 JPDSE_SWITCH(int, g_fast_small, 20);      // K-tile count up to which the 128-row / 2-stage fast configs are used
 static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   if (b.n <= 0) return JPDSE_OK;
@@ -205,6 +262,7 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   }
   for (int i = 0; i < b.n; ++i)
     if (b.n > 1 && !b.p[i].no_finish) b.p[i].splits = 1;
+  if (pers_ok(b)) return launch_pers(b, s);
   if (b.small_m) {
     if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);
     if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);
@@ -217,16 +275,11 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   if (g_fast_small && kt <= g_fast_small && b.p[0].splits <= 1) {
     // short reductions are prologue / epilogue bound: 128-row tiles, 4 waves, 2 stages = 64 (48) KiB of LDS, so two
     // (three) blocks share a CU and overlap each other's fill and store phases
-#ifdef JPDSE_DEV
-    // developer A/B: deeper rings for the same tiles (44: 3 stages, 45: 4 stages) -- more bytes in flight per block, fewer blocks per CU
-    if (g_fast_small_stages == 3) return Ks > 64 ? launch_fast_cfg<2, 2, 2, 2, 0, 3>(b, s) : launch_fast_cfg<2, 2, 2, 1, 0, 3>(b, s);
-    if (g_fast_small_stages == 4) return Ks > 64 ? launch_fast_cfg<2, 2, 2, 2, 0, 4>(b, s) : launch_fast_cfg<2, 2, 2, 1, 0, 4>(b, s);
-#endif
+    // (deeper rings for the same tiles -- round-3 developer modes 44 / 45 -- measured 25-50 % slower: profiles/r03_fast_stages_ab.txt)
     // up to 16 K-tiles and wide outputs: 64 x 128 tiles (48 KiB of LDS, three blocks per CU).  Measured per layer in one process
     // (profiles/r03_fast_tile64_ab.txt): PatchGAN layer 1 forward +7 % / +32 % (first / second scale), layer 2 data gradient
     // +10 % / +24 %; longer loops (18-32 tiles) and the 64-wide outputs (64 x 64 tiles) lose 3-6 % and keep the 128-row tiles.
-    // Developer mode 46 switches this off.
-    if (Ks > 64 && kt <= 16 && g_fast_small_stages != 64) return launch_fast_cfg<2, 2, 1, 2, 0, 2>(b, s);   // 64 x 128
+    if (Ks > 64 && kt <= 16) return launch_fast_cfg<2, 2, 1, 2, 0, 2>(b, s);   // 64 x 128
     if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);   // 128 x 128
     if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);   // 128 x 64
   }
@@ -253,6 +306,7 @@ JPDSE_SWITCH(bool, g_fast_enabled, true);   // jpdse_debug_set_fast_path(0) forc
 static bool prefer_320(int M, int Ks);
 static bool fast_pays(int M, int Ks, int k_tiles) {
   if (!g_fast_enabled) return false;
+  if (g_pers_min_tiles <= 1 && g_pers_enabled && k_tiles >= 4 && Ks >= 64) return true;   // developer mode 52 (tests): small problems reach the persistent form
   if (k_tiles < 8) return false;   // short reductions (stride-2 sub-pixel phases of 2x2 taps x 64 ch) do not fill the 3-stage ring
   if (Ks <= 32) {
     // measured: the generic 256x32 kernel beats the 8-wave 256x32 fast config on short reductions; with a long
@@ -272,22 +326,20 @@ static bool fast_pays(int M, int Ks, int k_tiles) {
 
 JPDSE_SWITCH(int, g_ring_enabled, 1);
 JPDSE_SWITCH(int, g_ring_virt, 1);        // 40: ring strips as four split-K GEMMs + ring_fold_kernel (the round-1..3 form) instead of the folded frame
-JPDSE_SWITCH(int, g_ring_small, 0);       // 31: ring strips on 128-row tiles, two blocks per CU (measured slower: 873 vs 955 TFLOP/s for the whole data gradient)
 JPDSE_SWITCH(int, g_merge_min_kt, 4);
 JPDSE_SWITCH(int, g_merge_min_tiles, 64);    // merged stride-phase data gradient on the fast kernel from this many 256-row tiles on (26: 384 as in round 1, A/B)
 JPDSE_SWITCH(int, g_halo_single, 1);
 JPDSE_SWITCH(int, g_halo_enabled, 1);
 JPDSE_SWITCH(int, g_halo_abl, 0);
 
-template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false,
-          bool VIRT = false, bool NSUM = false>
+template <int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool MOM = false, bool VIRT = false, bool NSUM = false>
 static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   constexpr int BN = 2 * TN * 32;
   constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
   constexpr int lds = (SINGLE ? 1 : 2) * UH * 1024 + 3 * BN * 128;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM, VIRT, NSUM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, MOM, VIRT, NSUM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     configured = true;
@@ -306,7 +358,7 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim &&
                      (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
-  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, STAG, PIPE, MOM, VIRT, NSUM>), dim3(tiles), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_halo_kernel<4, TN, ABL, SINGLE, MF16, MOM, VIRT, NSUM>), dim3(tiles), dim3(512), lds, s, a);
   if (timed) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
     g_prof.flops[g_prof.used] = 2.0 * (double)M * (double)a.Ks * (double)kdim;
@@ -317,8 +369,6 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
 }
 
 JPDSE_SWITCH(int, g_halo_xcd, 0);
-JPDSE_SWITCH(int, g_halo_stag, 0);
-JPDSE_SWITCH(int, g_halo_pipe, 0);      // 25: software-pipelined fragment reads (A/B)      // 23: waves 4..7 issue their DMA group after the MFMA cluster (A/B)
 JPDSE_SWITCH(int, g_halo_mf16, 0);     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
 template <int TN, int ABL = 0>
 static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
@@ -328,26 +378,23 @@ static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
     if constexpr (ABL == 0 && TN == 2) {
       if (a.nsums != nullptr) {           // ... and the sums of the InstanceNorm backward that consumes its output
         if (a.Cs == 64) return set_error(JPDSE_EINVAL, "gemm_halo: norm-backward sums are built for the double-buffered form (>= 128 input channels)");
-        return launch_halo_cfg_impl<TN, 0, false, false, false, false, false, true, true>(a, s);
+        return launch_halo_cfg_impl<TN, 0, false, false, false, true, true>(a, s);
       }
     }
     if (a.nsums != nullptr) return set_error(JPDSE_EINVAL, "gemm_halo: norm-backward sums need the 128-channel tile");
     if constexpr (ABL == 0) {
-      if (a.Cs == 64) return launch_halo_cfg_impl<TN, 0, true, false, false, false, false, true>(a, s);     // one slab: single patch buffer
-      return launch_halo_cfg_impl<TN, 0, false, false, false, false, false, true>(a, s);
+      if (a.Cs == 64) return launch_halo_cfg_impl<TN, 0, true, false, false, true>(a, s);     // one slab: single patch buffer
+      return launch_halo_cfg_impl<TN, 0, false, false, false, true>(a, s);
     }
   }
   if (a.mom != nullptr) {                 // conv -> InstanceNorm with the moments in this kernel's epilogue (double-buffered form)
-    if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, false, false, true>(a, s);
+    if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, true>(a, s);
   }
 #ifdef JPDSE_DEV
   if (ABL == 0 && g_halo_mf16) {
     if (a.Cs == 64 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, true>(a, s);
     return launch_halo_cfg_impl<TN, 0, false, true>(a, s);
   }
-  if (ABL == 0 && g_halo_stag) return launch_halo_cfg_impl<TN, 0, false, false, true>(a, s);
-  if (ABL == 0 && g_halo_pipe == 1 && a.Cs != 64) return launch_halo_cfg_impl<TN, 0, false, false, false, true>(a, s);
-  if (ABL == 0 && g_halo_pipe == 1 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, false, false, true>(a, s);
 #endif
   if (a.Cs == 64 && ABL == 0 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true>(a, s);   // one slab: single patch buffer
   return launch_halo_cfg_impl<TN, ABL, false>(a, s);

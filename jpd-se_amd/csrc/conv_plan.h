@@ -86,14 +86,21 @@ static int splitk_for(int M, int Ks, int k_tiles) {
 // (16 fp32 elements each).  Only when the 128-row tiles alone leave most of the chip idle -- at 512x256 batch 1 (BASELINE
 // config 2) the ResnetBlock GEMM is M = 512: 32 tiles on 256 CUs, 0.88 ms per launch; 16 splits: 512 blocks, three per CU.
 JPDSE_SWITCH(int, g_generic_splitk, 1);   // A/B switch (jpdse_debug_set_fast_path 48 / 49)
-static int generic_splitk_for(int ES, int M, int Ks, int chunks) {
+// The factor is chosen from the rows of ONE image (M / N), not of the batch: the K ranges -- and with them every output value, bit
+// for bit -- then do not depend on the batch size, so a 2-image step still equals the two 1-image steps exactly (the per-image
+// independence test; data-parallel replicas with different local batch sizes agree).  Only when the whole batch would give more
+// than 2048 blocks is the factor cut down (N > 4 at the sizes where it matters).
+static int generic_splitk_for(int ES, int M, int Ks, int chunks, int N) {
   if (!g_generic_splitk || ES != 4 || M <= 0 || chunks < 32) return 1;
+  if (N < 1) N = 1;
   const int bn = Ks > 64 ? 128 : (Ks > 32 ? 64 : 32), bm = Ks > 32 ? 128 : 256;
-  const long long tiles = (long long)((M + bm - 1) / bm) * ((Ks + bn - 1) / bn);
-  if (tiles >= 256) return 1;
-  int sp = (int)((512 + tiles - 1) / tiles);
+  const int nt = (Ks + bn - 1) / bn;
+  const long long tiles_img = (long long)((M / N + bm - 1) / bm) * nt, tiles = (long long)((M + bm - 1) / bm) * nt;
+  if (tiles_img >= 256) return 1;
+  int sp = (int)((512 + tiles_img - 1) / tiles_img);
   if (sp > chunks / 16) sp = chunks / 16;         // >= 16 chunks (one two-level flush) per split
   if (sp > 32) sp = 32;
+  while (sp > 1 && sp * tiles > 2048) sp = (sp + 1) / 2;
   return sp < 2 ? 1 : sp;
 }
 
@@ -169,12 +176,12 @@ static void make_plan(const jpdse_conv_desc* d, ConvPlan* p) {
   } else {
     // generic split-K (fp32): forward and every stride phase of the data gradient (run one after the other: the slabs are reused)
     const int Mf = d->N * p->OH * p->OW;
-    size_t need = (size_t)generic_splitk_for(p->ES, Mf, p->Ks, d->R * (p->Lk_fwd / p->BKE)) * Mf * p->Ks * 4;
+    size_t need = (size_t)generic_splitk_for(p->ES, Mf, p->Ks, d->R * (p->Lk_fwd / p->BKE), d->N) * Mf * p->Ks * 4;
     for (int i = 0; i < p->nph; ++i) {
       const Phase& f = p->ph[i];
       if (f.cnth <= 0 || f.cntw <= 0) continue;
       const int Md = d->N * f.cnth * f.cntw;
-      const size_t b = (size_t)generic_splitk_for(p->ES, Md, p->Cs, f.Uh * (f.Lk / p->BKE)) * Md * p->Cs * 4;
+      const size_t b = (size_t)generic_splitk_for(p->ES, Md, p->Cs, f.Uh * (f.Lk / p->BKE), d->N) * Md * p->Cs * 4;
       need = need > b ? need : b;
     }
     p->splitk_bytes = align_up(need, 256);

@@ -25,13 +25,6 @@ __device__ __forceinline__ s16x8 lds_read128_asm(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
   return v;
 }
-// wait until at most N LDS reads are outstanding; ties the waited fragments to this point
-template <int N, int FN>
-__device__ __forceinline__ void lds_wait_frags(s16x8 (&A)[2], s16x8 (&B)[FN]) {
-  if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0]), "+v"(B[1]) : "n"(N));
-  else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0]) : "n"(N));
-}
-
 struct HaloArgs {
   const bf16_t* X;   // [N][IH][IW][Cs]
   const bf16_t* B;   // panel [b_rows][9*Cs]
@@ -79,8 +72,7 @@ struct HaloArgs {
 // that hold the zero padding otherwise; the reads that must still see that padding (output row 0 at u = 0, ...) go to a zero
 // pixel in the slack of the patch buffer.  Costs an add and a min per fragment address and tap; replaces the four ring-strip
 // GEMMs + ring_fold_kernel.  Needs py = px = 1, IH = OH, IW = OW, OH >= 8.
-template <int TH, int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool STAG = false, bool PIPE = false, bool MOM = false,
-          bool VIRT = false, bool NSUM = false>
+template <int TH, int TN, int ABL = 0, bool SINGLE = false, bool MF16 = false, bool MOM = false, bool VIRT = false, bool NSUM = false>
 __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   constexpr int R = 3, S = 3, TAPS = 9;
   constexpr int NW = 8, WN = 2;                       // waves: TH (=4) x 2
@@ -281,13 +273,10 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
         }
       }
     };
-    // STAG: the two waves of a SIMD (w and w + 4) run the same program in lockstep behind one barrier per tap: both load,
-    // then both compute.  With the stagger the second half (waves 4..7) issues its DMA group AFTER its MFMA cluster, so
-    // that behind the barrier one wave of each SIMD feeds the matrix pipe at once while its partner does the scalar /
-    // address work of the loader (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  The counted vmcnt stays valid: the
-    // group issued at the end of tap t is tile t+2, whose pieces are the newest BU operations at the top of tap t+1 and
-    // covered by the wait at the top of tap t+2; its ring stage / patch buffer were last read in tap t-1 / the previous slab.
-    const bool late = STAG && wid >= 4;
+    // (Tried and removed in round 4, negative results on record in DESIGN.md 4.1: waves 4..7 issuing their DMA group AFTER the MFMA
+    // cluster -- the stagger of MI355X_MICROARCH.md "Two waves per SIMD" item 9 -- cost 8 %, round-2 developer mode 23; fragment
+    // reads as a hand-written software pipeline with counted lgkmcnt were neutral, mode 25: hipcc already interleaves these plain
+    // ds_read_b128.)
     const char* const st = bring + tap_s * B_STAGE;    // tap % 3
     const int tapoff = tap_r * PW + tap_s;
     int a_base[FM], a_sw[FM];
@@ -309,47 +298,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
       a_base[i] = pt << 7;
       a_sw[i] = MF16 ? (pt & 6) << 4 : ((pt >> 1) & 7) << 4;
     }
-    if constexpr (PIPE && !MF16 && ABL == 0) {
-      // Software-pipelined fragment reads: the four ds_read_b128 of k-step ks+1 are issued BEFORE the MFMAs of k-step ks
-      // and waited for with a counted lgkmcnt (LDS operations return in order; no scalar-memory load in the loop shares the
-      // counter).  hipcc's own schedule issues them two MFMAs ahead and then waits for lgkmcnt(0): four partly exposed LDS
-      // round trips per tap and wave.  Two fragment sets in ping-pong (a read issued after an MFMA may overwrite that MFMA's
-      // operands: the MFMA has read them by the time LDS data returns).
-      static_assert(FM == 2 && KS == 4, "pipelined form is written for the 32x32x16 tile");
-      const uint32_t hbase = lds_addr_of(hb), sbase = lds_addr_of(st);
-      s16x8 fa[2][2], fb[2][FN];
-      auto rd = [&](int ks, s16x8 (&A)[2], s16x8 (&B)[FN]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) A[i] = lds_read128_asm(hbase + a_base[i] + (((2 * ks + hsel) << 4) ^ a_sw[i]));
-#pragma unroll
-        for (int j = 0; j < FN; ++j) B[j] = lds_read128_asm(sbase + b_rd[j][ks]);
-      };
-      auto mm = [&](const s16x8 (&A)[2], const s16x8 (&B)[FN]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc[i][j], 0, 0, 0);
-      };
-      constexpr int NR = 2 + FN;                    // reads per k-step
-      rd(0, fa[0], fb[0]);
-      rd(1, fa[1], fb[1]);
-      if (!late) issue_group();                     // loader work under the first reads' latency
-      __builtin_amdgcn_s_setprio(1);
-      lds_wait_frags<NR, FN>(fa[0], fb[0]);
-      mm(fa[0], fb[0]);
-      rd(2, fa[0], fb[0]);
-      lds_wait_frags<NR, FN>(fa[1], fb[1]);
-      mm(fa[1], fb[1]);
-      rd(3, fa[1], fb[1]);
-      lds_wait_frags<NR, FN>(fa[0], fb[0]);
-      mm(fa[0], fb[0]);
-      lds_wait_frags<0, FN>(fa[1], fb[1]);
-      mm(fa[1], fb[1]);
-      __builtin_amdgcn_s_setprio(0);
-      if (late) issue_group();
-      return;
-    }
-    if (!late) issue_group();
+    issue_group();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -369,7 +318,6 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
         }
     }
     __builtin_amdgcn_s_setprio(0);
-    if (late) issue_group();
   };
   if constexpr (SINGLE) {
     // one slab (Cs == 64), nothing to prefetch: the rolled loop keeps the kernel within 128 VGPRs (two blocks per CU)

@@ -280,34 +280,15 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
     }
     const uint32_t boff[3] = {(uint32_t)off0, (uint32_t)(c_slot * B_SLOT), (uint32_t)off2};
     const uint32_t a_addr = a_rd + c_stage * A_STAGE;
-    // SCHED 0: DMA issue right behind the barrier (all 8 waves do scalar / address work while the matrix pipes idle);
-    // 1: between the two k-steps, under the first one's MFMAs; 2: the two waves of a SIMD (pixel halves) take turns --
-    // half 0 computes first and issues last, half 1 issues first: one of them feeds the matrix pipe while the other loads
-    if constexpr (SCHED == 3) {
-      __builtin_amdgcn_s_setprio(1);
-      chunk_pipelined(a_addr, boff, [&]() { if (ph == 1 && more) { issue_dy(); issue_row(); } });
-      __builtin_amdgcn_s_setprio(0);
-      if (ph == 0 && more) { issue_dy(); issue_row(); }
-      c_stage = c_stage == 2 ? 0 : c_stage + 1;
-      c_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
-      c_h = c_h == Hm1 ? 0 : c_h + 1;
-      continue;
-    }
-    if (SCHED == 0 || (SCHED == 2 && ph == 1)) {
-      if (more) { issue_dy(); issue_row(); }
-    }
+    // The six (k-step, filter-row) groups of a chunk run as a software pipeline (chunk_pipelined); the DMA issue of chunk t+2
+    // sits inside it for the second pixel half and behind it for the first.  (The unpipelined loop forms -- DMA issue right
+    // behind the barrier, between the two k-steps, alternating between the two waves of a SIMD: round-2 developer modes
+    // 21 / 22 / 24 -- measured 7-9 % slower and were removed in round 4; A/B record: DESIGN.md 4.1 (vii).)
+    static_assert(SCHED == 3, "only the software-pipelined loop form is built");
     __builtin_amdgcn_s_setprio(1);
-    kstep.template operator()<0>(a_addr, boff);
-    if (SCHED == 1) {
-      __builtin_amdgcn_s_setprio(0);
-      if (more) { issue_dy(); issue_row(); }
-      __builtin_amdgcn_s_setprio(1);
-    }
-    kstep.template operator()<1>(a_addr, boff);
+    chunk_pipelined(a_addr, boff, [&]() { if (ph == 1 && more) { issue_dy(); issue_row(); } });
     __builtin_amdgcn_s_setprio(0);
-    if (SCHED == 2 && ph == 0) {
-      if (more) { issue_dy(); issue_row(); }
-    }
+    if (ph == 0 && more) { issue_dy(); issue_row(); }
     c_stage = c_stage == 2 ? 0 : c_stage + 1;
     c_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
     c_h = c_h == Hm1 ? 0 : c_h + 1;

@@ -443,8 +443,7 @@ class HipResnetBlock(nn.Module):
     """dx_sink: the InstanceNorm that consumes the returned gradient (the previous stage's, see dy_sink): the sums of its
     backward are then written by the epilogue of this block's first conv's data gradient; likewise norm1's by the second conv's
     -- no separate pass over (x, dy) for either (jpdse_conv_dgrad_fused_nsums)."""
-    if len(ctx.items) == 1:                     # checkpointed: rebuild the saved tensors from the block input
-      _, ctx = self._fwd(ctx.items[0])
+    ctx = self.materialize(ctx)
     c1, n1, c2, n2 = ctx.items
     d = self.norm2.bwd(n2, dy)
     d = self.conv_block[5].bwd(c2, d, True, need_dw, sink=self.norm1.sink(n1) if self.fuse_norm_sums else None)
@@ -455,8 +454,16 @@ class HipResnetBlock(nn.Module):
 
   fuse_norm_sums = True       # False (A/B, tests): every norm backward computes its sums in its own pass
 
+  def materialize(self, ctx):
+    """The block's saved tensors: `ctx` itself, or -- checkpointed block (ctx holds only the block input) -- rebuilt by running
+    the block's forward again.  run_chain_bwd calls this one stage early so that the stage above can be told about this block's
+    second norm (dy_sink) in the checkpointed run exactly as in the stored-activation run: same kernels, bit-identical step."""
+    if len(ctx.items) == 1:
+      _, ctx = self._fwd(ctx.items[0])
+    return ctx
+
   def dy_sink(self, ctx):
-    if len(ctx.items) == 1:                     # checkpointed block: its saved tensors do not exist yet
+    if len(ctx.items) == 1:                     # checkpointed and not materialized
       return None
     return self.norm2.sink(ctx.items[3])
 
@@ -471,11 +478,18 @@ def run_chain_fwd(stages, x):
 
 def run_chain_bwd(stages, ctxs, dy, need_dx=True, need_dw=True):
   """Back-propagate through `stages`; the first stage computes dx only when need_dx."""
+  pending = None          # stage i - 1's saved tensors, materialized while stage i runs (the caller's list is left alone)
   for i in range(len(stages) - 1, -1, -1):
+    ctx_i, pending = (pending if pending is not None else ctxs[i]), None
+    below = None
+    if i > 0 and hasattr(stages[i - 1], 'materialize'):
+      below = pending = stages[i - 1].materialize(ctxs[i - 1])   # a checkpointed block's tensors, one stage early (see there)
+    elif i > 0:
+      below = ctxs[i - 1]
     if i > 0 and getattr(stages[i], 'accepts_dx_sink', False) and hasattr(stages[i - 1], 'dy_sink'):
       # stage i's dx goes straight into the InstanceNorm backward of stage i - 1: let its data-gradient epilogue write that
       # norm's sums (HipResnetBlock.bwd)
-      dy = stages[i].bwd(ctxs[i], dy, True, need_dw, dx_sink=stages[i - 1].dy_sink(ctxs[i - 1]))
+      dy = stages[i].bwd(ctx_i, dy, True, need_dw, dx_sink=stages[i - 1].dy_sink(below))
     else:
-      dy = stages[i].bwd(ctxs[i], dy, need_dx or i > 0, need_dw)
+      dy = stages[i].bwd(ctx_i, dy, need_dx or i > 0, need_dw)
   return dy

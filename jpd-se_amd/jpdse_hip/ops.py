@@ -404,20 +404,23 @@ def _loss_ws(device):
 # forward leaves its block partials in its own region of a per-device buffer and ONE launch at the end of the block writes all
 # the slots -- the train step computes 20 loss terms (pix2pixHD_pix2pixHD_model.py:205-221), each of which had its own 5-us final kernel.
 _LOSS_TERMS_MAX = 64
-_loss_defer = None
-_loss_regions = {}
+import threading as _threading
+_loss_tls = _threading.local()     # the open deferral list belongs to the thread that opened it (an eval pass on another
+_loss_regions = {}                 # thread / stream must not share the training step's partial regions or its term list)
+
+
+def _defer_list():
+  return getattr(_loss_tls, 'defer', None)
 
 
 class deferred_loss_finals(object):
   def __enter__(self):
-    global _loss_defer
-    assert _loss_defer is None, 'deferred_loss_finals does not nest'
-    _loss_defer = []
+    assert _defer_list() is None, 'deferred_loss_finals does not nest'
+    _loss_tls.defer = []
     return self
 
   def __exit__(self, et, ev, tb):
-    global _loss_defer
-    terms, _loss_defer = _loss_defer, None
+    terms, _loss_tls.defer = _loss_tls.defer, None
     if et is None and terms:
       from . import LossTerm
       arr = (LossTerm * len(terms))()
@@ -429,17 +432,20 @@ class deferred_loss_finals(object):
 
 def _loss_target(out, device, work_items, count):
   """(ws tensor, out pointer or None): the shared loss workspace and the caller's slot, or -- deferred -- a private region and NULL."""
-  if _loss_defer is None:
+  defer = _defer_list()
+  if defer is None:
     return _loss_ws(device), _p(out)
   per = lib().jpdse_loss_workspace_size(0) // 4
-  buf = _loss_regions.get(device)
+  index = device.index if device.index is not None else torch.cuda.current_device()
+  key = (index, torch.cuda.current_stream(index).cuda_stream)       # one region buffer per (device, stream), as workspace()
+  buf = _loss_regions.get(key)
   if buf is None:
-    buf = _loss_regions[device] = torch.empty(_LOSS_TERMS_MAX * per, dtype=torch.float32, device=device)
-  i = len(_loss_defer)
+    buf = _loss_regions[key] = torch.empty(_LOSS_TERMS_MAX * per, dtype=torch.float32, device=device)
+  i = len(defer)
   if i >= _LOSS_TERMS_MAX:
     return _loss_ws(device), _p(out)                  # more terms than regions: this one finishes on its own
   region = buf[i * per:(i + 1) * per]
-  _loss_defer.append((region.data_ptr(), int(lib().jpdse_loss_partial_count(int(work_items))), 1.0 / float(count), out.data_ptr()))
+  defer.append((region.data_ptr(), int(lib().jpdse_loss_partial_count(int(work_items))), 1.0 / float(count), out.data_ptr()))
   return region, None
 
 

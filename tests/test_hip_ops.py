@@ -590,6 +590,48 @@ def test_conv_norm_fused_moments_offset_channels_full_size(name, make, shape):
   assert_close(y.t.float().cpu(), y2.t.float().cpu(), RTOL[BF16], name + ' norm output, fused vs separate moments')
 
 
+# Persistent, cross-tile-pipelined fast kernel (gemm_pers.h; round 4): forward and merged-phase data gradient of the short-K
+# layers.  At the bench sizes it is what runs (tests/test_hip_fullsize_windows.py); here developer mode 52 sends small problems
+# through it too -- ragged M tails, ragged N tails, tiles that cross image boundaries, blocks with several tiles and blocks
+# with one -- against torch-CPU and against the kernels the default dispatch takes for the same layer (mode 50).
+PERS_CASES = [
+    # name,          N, H,  W,   C,   K,   k, st, pad, mode
+    ('d1_like',      3, 33, 65,  64,  128, 4, 2,  2,   PAD_ZERO),
+    ('d2_like',      2, 17, 33,  128, 256, 4, 2,  2,   PAD_ZERO),
+    ('down_128_256', 2, 24, 40,  128, 256, 3, 2,  1,   PAD_ZERO),
+    ('n_tail_192',   1, 21, 37,  64,  192, 3, 2,  1,   PAD_ZERO),       # N tail: 192 = 128 + 64 channels
+    ('narrow_64',    2, 19, 30,  128, 64,  3, 1,  1,   PAD_ZERO),       # 128 x 64 tiles
+    ('reflect_s1',   1, 18, 26,  64,  128, 3, 1,  1,   PAD_REFLECT),
+    ('many_tiles',   4, 130, 254, 64, 128, 4, 2,  2,   PAD_ZERO),       # 264 tiles on 256 CUs: blocks with one tile and blocks with two
+]
+
+
+@pytest.mark.parametrize('case', PERS_CASES, ids=[c[0] for c in PERS_CASES])
+def test_persistent_fast_kernel(case):
+  name, N, H, W, C, K, k, st, pad, mode = case
+  g = G(zlib.crc32(name.encode()) % 1000 + 3)
+  x = quantize_like(torch.randn(N, C, H, W, generator=g), BF16)
+  w = torch.randn(K, C, k, k, generator=g) * (1.0 / (C * k * k) ** 0.5)
+  xr = x.clone().requires_grad_(True)
+  y_ref = _torch_conv(xr, quantize_like(w, BF16), None, st, pad, mode, ACT_NONE)
+  gy = quantize_like(torch.randn(y_ref.shape, generator=g), BF16)
+  y_ref.backward(gy)
+  out = {}
+  for fm in (52, 50):
+    with jpdse_hip.dev_mode(fm):
+      layer = HipConv2d(C, K, k, st, pad, mode, act=ACT_NONE, apply_bias=False, dtype=BF16, device=DEV)
+      with torch.no_grad():
+        layer.weight.copy_(w)
+      y, ctx = layer.fwd(to_act(x, BF16))
+      dx = layer.bwd(ctx, to_act(gy, BF16), need_dx=True, need_dw=False)
+      torch.cuda.synchronize()
+      out[fm] = (y.t.clone(), dx.t.clone())
+  assert_close(to_nchw(Act(out[52][0], K)), y_ref.detach(), RTOL[BF16], name + ' fwd (persistent kernel)')
+  assert_close(to_nchw(Act(out[52][1], C)), xr.grad, RTOL[BF16], name + ' dgrad (persistent kernel)')
+  assert (out[52][0][..., K:] == 0).all() and (out[52][1][..., C:] == 0).all(), 'padding lanes must stay zero'
+  assert_close(out[52][0].float().cpu(), out[50][0].float().cpu(), RTOL[BF16], name + ' fwd: persistent kernel vs the default dispatch')
+
+
 # InstanceNorm backward with its two per-channel sums taken from the epilogue of the data-gradient kernel that produced dy
 # (jpdse_conv_dgrad_fused_nsums -> jpdse_inorm_bwd_from_sums; round 4): the ResnetBlock chain on the folded-frame halo kernel.
 @pytest.mark.parametrize('shape', [(2, 128, 8, 128), (1, 256, 16, 64)], ids=['128ch', '256ch'])
@@ -665,6 +707,23 @@ def test_dgrad_nsums_slots_vs_fp64():
     b = norm.bwd(nctx, dx)
     torch.cuda.synchronize()
     assert_close(to_nchw(a), to_nchw(b), RTOL[BF16], 'inorm_bwd_from_sums vs inorm_bwd, act %d' % act)
+
+
+def test_prof_hbm_reselect_with_a_smaller_maximum():
+  """jpdse_prof_hbm_select(1, big) then (1, small): the region count must be bounded by the CURRENT maximum (the
+  event vector only grows; the byte / class vectors are re-sized), so no region index runs past them."""
+  import ctypes
+  L = jpdse_hip.lib()
+  x = to_act(torch.randn(1, 16, 8, 8), F32)
+  for cap, calls in ((6, 9), (2, 7), (3, 1)):
+    jpdse_hip.check(L.jpdse_prof_hbm_select(1, cap), 'prof_hbm_select')
+    for _ in range(calls):
+      ops.inorm_fwd(x, ACT_NONE)
+    torch.cuda.synchronize()
+    ms, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    jpdse_hip.check(L.jpdse_prof_hbm_collect(0, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(n)), 'prof_hbm_collect')
+    assert n.value == min(cap, calls) and ms.value > 0.0 and by.value > 0.0, (cap, calls, n.value)
+  jpdse_hip.check(L.jpdse_prof_hbm_select(0, 0), 'prof_hbm_select off')
 
 
 # ---- instance norm -----------------------------------------------------------------------------
