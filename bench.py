@@ -61,6 +61,9 @@ def parse():
                   help='A/B only: read the losses back after the optimizer steps, as round 2 did')
   ap.add_argument('--unfused-d-lrelu', action='store_true',
                   help="A/B only: the PatchGAN layer-0 LeakyReLU backward as its own pass instead of in layer 1's epilogue")
+  ap.add_argument('--unfused-norm-sums', action='store_true',
+                  help='A/B only: every InstanceNorm backward computes its two sums in its own pass instead of taking them from the '
+                       'epilogue of the data-gradient kernel that produced dy (round 4)')
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                   help='collective backend for N > 1: nccl == RCCL over xGMI (the product path); gloo only to rehearse '
                        'the multi-rank schedule on a box with fewer GPUs than ranks (with --share-gpu)')
@@ -267,6 +270,9 @@ def main():
   L = lib()
   if args.late_readback:
     trainer.model.early_loss_readback = False
+  if args.unfused_norm_sums:
+    from jpdse_hip.layers import HipResnetBlock
+    HipResnetBlock.fuse_norm_sums = False
   if args.unfused_d_lrelu:
     for m in trainer.model.netD.modules():
       if hasattr(m, 'fuse_lrelu0'):

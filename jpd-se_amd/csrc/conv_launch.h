@@ -368,6 +368,35 @@ static int launch_halo_cfg_impl(const HaloArgs& a, hipStream_t s) {
   return check_launch("gemm_halo_kernel");
 }
 
+#ifdef JPDSE_DEV
+// developer A/B (mode 53): the plain forward launch of the 128-channel-tile halo kernel on the four-wave form (gemm_halo4.h)
+static int g_halo4 = 0;
+static int launch_halo4(const HaloArgs& a, hipStream_t s) {
+  constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
+  constexpr int lds = 2 * UH * 1024 + 3 * 128 * 128;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo4: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  if (int rc = check_tile_grid("gemm_halo4", a.N, a.OH, a.OW, 4, 64, a.Cs, (long long)a.N * a.IH * a.IW * a.Cs, (long long)a.N * a.OH * a.OW * a.Ks)) return rc;
+  if (a.Cs < 128 || a.Ks % 128 != 0) return set_error(JPDSE_EINVAL, "gemm_halo4: needs >= 128 input channels and 128-channel output tiles");
+  const int tiles = a.N * (a.OH / 4) * (a.OW / 64) * (a.Ks / 128);
+  const long long kdim = 9LL * a.Cs;
+  const bool timed = g_prof.on && a.Ks == g_prof.Ks && kdim == g_prof.kdim && (size_t)(2 * g_prof.used + 2) <= g_prof.ev.size();
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.used], s);
+  hipLaunchKernelGGL(gemm_halo4_kernel, dim3(tiles), dim3(256), lds, s, a);
+  if (timed) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.used + 1], s);
+    g_prof.flops[g_prof.used] = 2.0 * (double)a.N * a.OH * a.OW * (double)a.Ks * (double)kdim;
+    g_prof.cls[g_prof.used] = 0;
+    ++g_prof.used;
+  }
+  return check_launch("gemm_halo4_kernel");
+}
+#endif
+
 JPDSE_SWITCH(int, g_halo_xcd, 0);
 JPDSE_SWITCH(int, g_halo_mf16, 0);     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
 template <int TN, int ABL = 0>
@@ -391,6 +420,8 @@ static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
     if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, true>(a, s);
   }
 #ifdef JPDSE_DEV
+  if (ABL == 0 && TN == 2 && g_halo4 && a.Cs >= 128 && a.Ks % 128 == 0 && a.pool == nullptr && a.mask == nullptr && a.addend == nullptr)
+    return launch_halo4(a, s);
   if (ABL == 0 && g_halo_mf16) {
     if (a.Cs == 64 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, true>(a, s);
     return launch_halo_cfg_impl<TN, 0, false, true>(a, s);
@@ -460,12 +491,16 @@ static int launch_rows(const RowsArgs& a, int stride, hipStream_t s) {
 
 
 // data gradient of the 64 -> 128 3x3 stride-2 conv / forward of the 128 -> 64 ConvTranspose2d at full resolution (dgrad2_rows.h)
+JPDSE_SWITCH(int, g_dgrad2_noconf, 0);    // 54: TIMING-ONLY ablation, conflict-free LDS addresses (developer build)
 static int launch_dgrad2_rows(Dgrad2Args a, hipStream_t s) {
   typedef Dgrad2Geom G;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_rows_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_rows_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+#ifdef JPDSE_DEV
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+#endif
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "dgrad2_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
     configured = true;
   }
@@ -475,7 +510,13 @@ static int launch_dgrad2_rows(Dgrad2Args a, hipStream_t s) {
   a.TH = th;
   a.bands = a.OH / th;
   a.mom_slots = a.bands * a.strips;
-  hipLaunchKernelGGL(dgrad2_rows_kernel, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
+#ifdef JPDSE_DEV
+  if (g_dgrad2_noconf) {      // timing-only ablation (developer mode 54): conflict-free LDS addresses, wrong results
+    hipLaunchKernelGGL(dgrad2_rows_kernel<true>, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
+    return check_launch("dgrad2_rows_kernel<noconf>");
+  }
+#endif
+  hipLaunchKernelGGL(dgrad2_rows_kernel<false>, dim3((unsigned)(a.N * a.bands * a.strips)), dim3(256), G::LDS, s, a);
   return check_launch("dgrad2_rows_kernel");
 }
 

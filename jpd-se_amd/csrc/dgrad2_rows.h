@@ -43,6 +43,10 @@ struct Dgrad2Geom {
   static constexpr int LDS = NR * ROWB + TILE;
 };
 
+// NOCONF (developer build, TIMING ONLY -- the results are wrong): every LDS access that can have a bank conflict is re-pointed at a
+// conflict-free address -- the column-shifted A-fragment reads at the unshifted pixel, the tile reads lane-linear -- to measure what
+// the kernel would gain from a conflict-free layout (profiles/r04_dgrad2_rows_conflicts_ab.txt).
+template <bool NOCONF = false>
 __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
   typedef Dgrad2Geom G;
   constexpr int U0 = G::UNITS / 4, U1 = U0 + 1, EXTRA = G::UNITS % 4;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
       for (int k = 0; k < 8; ++k) {
         const int idx = tid + 256 * k;
         const int pxl = idx >> 3, part = idx & 7;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + pxl * G::PITCH + part * 16);
+        const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + (NOCONF ? idx * 16 : pxl * G::PITCH + part * 16));
         *reinterpret_cast<u32x4*>(a.DX + orow + (long long)(pxl >> 7) * (2 * a.OW) * 64 + (pxl & 127) * 64 + part * 8) = val;
       }
     }
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
       const int mt = u >> 2, ks = u & 3;
       const int c = ks * 4 + kc;
       const uint32_t o0 = (a_px[mt][0] << 8) + (((c ^ a_px[mt][0]) & 15) << 4);
-      const uint32_t o1 = (a_px[mt][1] << 8) + (((c ^ a_px[mt][1]) & 15) << 4);
+      const uint32_t o1 = NOCONF ? o0 : (a_px[mt][1] << 8) + (((c ^ a_px[mt][1]) & 15) << 4);
       f[0] = lds_read128_asm(r0 + o0);
       f[1] = lds_read128_asm(r0 + o1);
       f[2] = lds_read128_asm(r1 + o0);
