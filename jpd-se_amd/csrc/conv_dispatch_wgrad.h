@@ -247,15 +247,22 @@ static int launch_wgrad_taps(const jpdse_conv_desc* d, const ConvPlan& p, int cf
 
 // ---- all-nine-taps weight gradient of the wide 3x3 stride-1 layers (wgrad_nine.h): no atomics, no partial tiles ----
 JPDSE_SWITCH(int, g_wgrad_nine_enabled, 1);
+JPDSE_SWITCH(int, g_wgrad_nine32_enabled, 1);     // 55: 32-pixel-wide images on the per-tap kernel, as before round 4 (A/B)
+// images 32 pixels wide (the LocalEnhancer's 1024-channel trunk at 16 x 32): the row-pair form of the kernel (wgrad_nine.h, W32)
+static bool wgrad_nine32_shape(const jpdse_conv_desc* d, const ConvPlan& p) {
+  return g_wgrad_nine32_enabled && d->W == 32 && p.OW == 32 && d->H % 2 == 0 && d->H >= 4 && d->pad_mode == JPDSE_PAD_REFLECT &&
+         p.Ks >= 256 && p.Cs >= 256;         // wide layers only: 64 k x 64 c tiles must fill the chip
+}
 static bool wgrad_nine_ok(const jpdse_conv_desc* d, const ConvPlan& p) {
   return g_fast_enabled && g_wgrad_nine_enabled && p.ES == 2 && d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1 &&
-         p.OW % 64 == 0 && p.Ks % 64 == 0 && p.Cs % 64 == 0 && d->H >= 2 && d->W >= 8 &&
+         (p.OW % 64 == 0 || wgrad_nine32_shape(d, p)) && p.Ks % 64 == 0 && p.Cs % 64 == 0 && d->H >= 2 && d->W >= 8 &&
          (long long)d->N * d->H * d->W * (p.Ks > p.Cs ? p.Ks : p.Cs) < (1LL << 31);
 }
 
 static void nine_partition(const jpdse_conv_desc* d, const ConvPlan& p, NineWgArgs* a) {
-  a->strips = d->W / 64;
-  a->chunks_total = d->N * a->strips * d->H;
+  const bool w32 = p.OW % 64 != 0;           // wgrad_nine_ok: then the row-pair form (chunk = two image rows)
+  a->strips = w32 ? 1 : d->W / 64;
+  a->chunks_total = w32 ? d->N * (d->H / 2) : d->N * a->strips * d->H;
   a->k_tiles = p.Ks / 64;
   a->c_tiles = p.Cs / 64;
   const int tiles = a->k_tiles * a->c_tiles;
@@ -279,18 +286,20 @@ static size_t wgrad_nine_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
   return a.splits > 1 ? (size_t)a.splits * d->K * 9 * d->C * sizeof(float) : 0;
 }
 
-template <bool REFLECT, int SCHED>
+template <bool REFLECT, int SCHED, bool W32 = false>
 static int launch_wgrad_nine_cfg(const NineWgArgs& a, hipStream_t s) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_nine_kernel<REFLECT, SCHED, 0>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_nine_kernel<REFLECT, SCHED, 0, W32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kNineLds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_nine: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
   const int blocks = a.k_tiles * a.c_tiles * a.splits;
   const int pslot = (a.Ks == g_prof.Ks && 9LL * a.Cs == g_prof.kdim) ? prof_begin(s) : -1;
-  hipLaunchKernelGGL((wgrad_nine_kernel<REFLECT, SCHED, 0>), dim3(blocks), dim3(512), kNineLds, s, a);
+  if (W32 && (a.W != 32 || (a.H & 1) || a.chunks_total != a.N * (a.H / 2)))
+    return set_error(JPDSE_EINVAL, "wgrad_nine: the row-pair form needs 32-pixel-wide images with an even number of rows");
+  hipLaunchKernelGGL((wgrad_nine_kernel<REFLECT, SCHED, 0, W32>), dim3(blocks), dim3(512), kNineLds, s, a);
   if (int rc = check_launch("wgrad_nine_kernel")) return rc;
   if (a.splits > 1) {
     const long long n4 = (long long)a.K * 9 * a.C / 4;
@@ -318,6 +327,7 @@ static int launch_wgrad_nine(const jpdse_conv_desc* d, const ConvPlan& p, const 
   nine_partition(d, p, &a);
   if (a.splits > 1 && ((long long)d->K * 9 * d->C) % 4 != 0)
     return set_error(JPDSE_EINVAL, "wgrad_nine: K*9*C = %lld is not a multiple of 4", (long long)d->K * 9 * d->C);
+  if (p.OW % 64 != 0) return launch_wgrad_nine_cfg<true, 3, true>(a, s);          // wgrad_nine32_shape: reflect, W = 32
   if (d->pad_mode != JPDSE_PAD_REFLECT) return launch_wgrad_nine_cfg<false, 3>(a, s);
   return launch_wgrad_nine_cfg<true, 3>(a, s);
 }

@@ -21,6 +21,14 @@
 // slots, counted vmcnt, one raw barrier per chunk (as wgrad_row.h).  When the filter has fewer tiles than the chip
 // has CUs, the pixel range is cut into `splits` equal parts, each block stores its partial tile into its own fp32
 // slab and wgrad_nine_reduce_kernel adds the slabs in a fixed order.
+//
+// W32 instantiation (round 4): images 32 pixels wide -- the 1024-channel trunk of the LocalEnhancer at 16 x 32 (BASELINE config
+// 3), where the per-tap kernel ran 144 blocks of 256 x 256 on 256 CUs (492 TFLOP/s).  A chunk is a PAIR of image rows (2j, 2j+1):
+// 64 consecutive pixels of dy, so the dy side is unchanged; the wave's pixel half (ph) IS the row of the pair, so tap (r, s) of a
+// wave reads ONE real input row, 2j + ph + r - 1, at pixel offset s: a wave-uniform slot choice as before.  Input rows are staged
+// as 34-pixel rows (40-pixel slots), two new ones per chunk (global rows 2t+1, 2t+2 for chunk t: the stream runs seamlessly
+// across images because H is even), eight slots (row G lives in slot G mod 8).  Reflect padding only: row -1 is row 1 (first
+// pair of an image, ph 0), row H is row H-2 (last pair, ph 1); columns by the loader.
 #pragma once
 #include "common.h"
 #include "gemm_fast.h"
@@ -46,12 +54,16 @@ static constexpr int kNineSlots = 5;
 static constexpr int kNineLoopLds = 3 * kNineStage + (kNineSlots + 1) * kNineSlot;   // + one slot of zeros
 static constexpr int kNineRedLds = 4 * 9 * 16 * 64 * 4;                              // pixel-half reduction
 static constexpr int kNineLds = kNineLoopLds > kNineRedLds ? kNineLoopLds : kNineRedLds;
+static constexpr int kNine32Slot = 40 * 128;          // W32: input row slot, 40 px x 128 B (34 live: columns -1 .. 32)
+static constexpr int kNine32Slots = 8;
+static_assert(3 * kNineStage + kNine32Slots * kNine32Slot <= kNineLds, "the W32 loop fits the same allocation");
 
 // SCHED: where the DMA issue of chunk t+2 sits in iteration t (see the loop).  ABL (timing-only): 1 = no epilogue
-template <bool REFLECT, int SCHED = 3, int ABL = 0>
+template <bool REFLECT, int SCHED = 3, int ABL = 0, bool W32 = false>
 __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
+  static_assert(!W32 || REFLECT, "the 32-pixel-wide form is built for reflect padding");
   constexpr int NW = 8, BKP = 64, ROWB = 128;
-  constexpr int A_STAGE = kNineStage, B_SLOT = kNineSlot, NSLOT = kNineSlots;
+  constexpr int A_STAGE = kNineStage, B_SLOT = W32 ? kNine32Slot : kNineSlot, NSLOT = W32 ? kNine32Slots : kNineSlots;
   constexpr int B_BASE = 3 * A_STAGE, ZERO_OFF = B_BASE + NSLOT * B_SLOT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -97,9 +109,10 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
     const int ch = wk * 32 + cb * 16 + 4 * p;
     a_rd = lds0 + pix * ROWB + ((((ch >> 3) ^ trswz<ROWB>(pix)) << 4) | ((ch & 7) << 1));
     const int chb = wc * 32 + cb * 16 + 4 * p;
+    const int pixb = W32 ? pix - 32 * ph : pix;            // W32: pixel inside the wave's own input row
 #pragma unroll
     for (int s = 0; s < 3; ++s)
-      b_rd[s] = lds0 + B_BASE + (pix + s) * ROWB + ((((chb >> 3) ^ trswz<ROWB>(pix + s)) << 4) | ((chb & 7) << 1));
+      b_rd[s] = lds0 + B_BASE + (pixb + s) * ROWB + ((((chb >> 3) ^ trswz<ROWB>(pixb + s)) << 4) | ((chb & 7) << 1));
   }
 
   f32x16 acc[9];
@@ -189,8 +202,55 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
     r_left -= more ? 1 : 0;
   };
 
+  // ---- W32: chunk t = row pair (2j, 2j+1) of an image; its dy is the t-th run of 64 pixels of the tensor; the row stream brings
+  // global rows (2g+1, 2g+2) as "pair g" (pair -1 = rows (-1, 0): row -1 is never read -- reflect -- and loads row 0 twice).
+  // Units of a pair: 2 rows x 5 units of 8 pixels; wave w takes unit w, waves 0 and 1 also units 8 and 9.
+  long long p_row = 0;       // W32: global row index of the next pair's FIRST row (2g + 1)
+  const long long rows_all = (long long)a.N * a.H;
+  auto issue_pair = [&]() {
+    auto unit = [&](int v) {
+      const int rsel = v >= 5 ? 1 : 0, u = v - 5 * rsel;
+      long long gr = p_row + rsel;
+      gr = gr < 0 ? 0 : (gr > rows_all - 1 ? rows_all - 1 : gr);          // rows outside the tensor are never consumed
+      const int q = u * 8 + pl;
+      int iw = q - 1;
+      iw = iw < 0 ? -iw : iw;
+      iw = iw > Wm1 ? 2 * Wm1 - iw : iw;
+      iw = iw < 0 ? 0 : iw;                                                // pixels 34..39: never consumed
+      const int sw = c0 + ((slot16 ^ trswz<ROWB>(q)) << 3);
+      const int slot = (int)((p_row + rsel) & (NSLOT - 1));
+      glds16(a.X + gr * ((long long)a.W * a.Cs) + (unsigned)(__mul24(iw, a.Cs) + sw), smem + B_BASE + slot * B_SLOT + u * 1024);
+    };
+    unit(wid);
+    if (wid < 2) {
+      int w2 = wid;
+      asm volatile("" : "+s"(w2));
+      unit(8 + w2);
+    }
+    p_row += 2;
+  };
+  auto issue_dy32 = [&]() {
+    glds16(d_ptr + (unsigned)a_loff, smem + d_stage * A_STAGE + wid * 1024);
+    d_stage = d_stage == 2 ? 0 : d_stage + 1;
+    d_ptr += 64LL * a.Ks;
+  };
+
   // ---- pipeline: group G_t = {dy(t), row(t+1)}; prologue G_t0 also carries rows t0-1 and t0 ------------
   __syncthreads();        // zero slot written (no DMA in flight yet)
+  int c_stage = 0;
+  int c_slot = __builtin_amdgcn_readfirstlane(t0 % NSLOT);       // slot of row t
+  int c_h = __builtin_amdgcn_readfirstlane(W32 ? t0 % (a.H >> 1) : t0 % a.H);
+  if constexpr (W32) {
+    d_ptr = a.DY + (long long)t0 * 64 * a.Ks;
+    p_row = 2LL * t0 - 1;
+    issue_pair();           // rows 2 t0 - 1, 2 t0
+    issue_pair();           // rows 2 t0 + 1, 2 t0 + 2
+    issue_dy32();           // dy t0
+    if (t0 + 1 < t1) {
+      issue_dy32();         // G_{t0+1}: dy t0 + 1, rows 2 t0 + 3, 2 t0 + 4
+      issue_pair();
+    }
+  } else {
   if (t0 > 0) issue_row();                                 // row t0 - 1
   else r_slot = r_slot == NSLOT - 1 ? 0 : r_slot + 1;      // there is no row -1: chunk 0 is a first image row
   issue_row();            // row t0
@@ -200,9 +260,7 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
     issue_dy();           // G_{t0+1}
     issue_row();
   }
-  int c_stage = 0;
-  int c_slot = __builtin_amdgcn_readfirstlane(t0 % NSLOT);       // slot of row t
-  int c_h = __builtin_amdgcn_readfirstlane(t0 % a.H);
+  }
 
   auto kstep = [&]<int KS>(uint32_t a_addr, const uint32_t (&boff)[3]) {
     s16x8 af[1], bf[9];
@@ -269,8 +327,19 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
     __builtin_amdgcn_s_barrier();
     const bool more = t + 2 < t1;
     // row slots of the three filter rows
+    int off0, off1, off2;
+    if constexpr (W32) {
+      // this wave's output row is 2t + ph (global row index; slot = index mod 8): filter rows read 2t + ph - 1 .. 2t + ph + 1
+      const int g0 = 2 * t + ph;
+      const bool first = c_h == 0 && ph == 0, last = c_h == (a.H >> 1) - 1 && ph == 1;
+      off0 = (((first ? g0 + 1 : g0 - 1)) & (NSLOT - 1)) * B_SLOT;          // row -1 is row 1
+      off1 = (g0 & (NSLOT - 1)) * B_SLOT;
+      off2 = (((last ? g0 - 1 : g0 + 1)) & (NSLOT - 1)) * B_SLOT;           // row H is row H - 2
+    } else {
     const int s_prev = c_slot == 0 ? NSLOT - 1 : c_slot - 1, s_next = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
-    int off0 = s_prev * B_SLOT, off2 = s_next * B_SLOT;
+    off0 = s_prev * B_SLOT;
+    off1 = c_slot * B_SLOT;
+    off2 = s_next * B_SLOT;
     if constexpr (REFLECT) {
       off0 = c_h == 0 ? off2 : off0;                       // row -1 is row 1
       off2 = c_h == Hm1 ? s_prev * B_SLOT : off2;          // row H is row H - 2
@@ -278,7 +347,8 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
       off0 = c_h == 0 ? NSLOT * B_SLOT : off0;             // the slot of zeros
       off2 = c_h == Hm1 ? NSLOT * B_SLOT : off2;
     }
-    const uint32_t boff[3] = {(uint32_t)off0, (uint32_t)(c_slot * B_SLOT), (uint32_t)off2};
+    }
+    const uint32_t boff[3] = {(uint32_t)off0, (uint32_t)off1, (uint32_t)off2};
     const uint32_t a_addr = a_rd + c_stage * A_STAGE;
     // The six (k-step, filter-row) groups of a chunk run as a software pipeline (chunk_pipelined); the DMA issue of chunk t+2
     // sits inside it for the second pixel half and behind it for the first.  (The unpipelined loop forms -- DMA issue right
@@ -286,12 +356,14 @@ __global__ __launch_bounds__(512) void wgrad_nine_kernel(const NineWgArgs a) {
     // 21 / 22 / 24 -- measured 7-9 % slower and were removed in round 4; A/B record: DESIGN.md 4.1 (vii).)
     static_assert(SCHED == 3, "only the software-pipelined loop form is built");
     __builtin_amdgcn_s_setprio(1);
-    chunk_pipelined(a_addr, boff, [&]() { if (ph == 1 && more) { issue_dy(); issue_row(); } });
+    if constexpr (W32) chunk_pipelined(a_addr, boff, [&]() { if (ph == 1 && more) { issue_dy32(); issue_pair(); } });
+    else chunk_pipelined(a_addr, boff, [&]() { if (ph == 1 && more) { issue_dy(); issue_row(); } });
     __builtin_amdgcn_s_setprio(0);
-    if (ph == 0 && more) { issue_dy(); issue_row(); }
+    if constexpr (W32) { if (ph == 0 && more) { issue_dy32(); issue_pair(); } }
+    else { if (ph == 0 && more) { issue_dy(); issue_row(); } }
     c_stage = c_stage == 2 ? 0 : c_stage + 1;
     c_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
-    c_h = c_h == Hm1 ? 0 : c_h + 1;
+    c_h = W32 ? (c_h == (a.H >> 1) - 1 ? 0 : c_h + 1) : (c_h == Hm1 ? 0 : c_h + 1);
   }
 
   // ---- sum the two pixel halves through LDS (fixed order), store -----------------------------------------------

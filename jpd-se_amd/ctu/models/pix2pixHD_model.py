@@ -519,6 +519,9 @@ class Pix2PixHDModel(BaseModel):
     mark('g_bwd_end')
     if did_G and bg is not None:
       bg.launch_all()                  # no-op for buckets already started from the per-layer hooks (defer=False)
+    # (Measured and not adopted, round 4: Adam(G) + the panel re-pack -- 1.2 ms of HBM-bound streaming -- on a second stream
+    # beside the discriminator's backward: 26.36-26.40 ms per step against 26.15-26.33 serial, profiles/r04_adam_side_stream_ab.txt.
+    # The D backward is itself half HBM-bound passes, and its GEMM launches lose more to the shared CUs than Adam gains.)
     did_D = self.backward_D(state, 0.0 if opt.no_d_gan_loss else 0.5)
     mark('d_bwd_end')
     if did_G:

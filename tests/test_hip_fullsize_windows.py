@@ -184,6 +184,26 @@ def test_1024x512_resblock_complete_tensors_vs_torch_cpu_bf16():
   assert_close(layer.weight.grad.cpu(), wl.grad, tol, name + ' wgrad (complete)')
 
 
+def test_1024x512_local_trunk_complete_tensors_vs_torch_cpu_bf16():
+  """BASELINE config 3's trunk: the 1024-channel ResnetBlock conv of the LocalEnhancer's coarse generator at 16 x 32 pixels,
+  batch 4 -- nine-tap program forward, folded-frame data gradient, and (round 4) the row-pair form of the nine-tap weight
+  gradient (wgrad_nine.h W32) -- as complete tensors against torch-CPU."""
+  name, N, H, W, C = 'local_trunk_1024', 4, 16, 32, 1024
+  layer, x, y, dy, dx, wq = _make(name, N, H, W, C, C, 3, 1, 1, PAD_REFLECT, False)
+  tol = RTOL[BF16]
+  xr = _nchw(x.t, C).requires_grad_(True)
+  wl = wq.clone().requires_grad_(True)
+  yr = _conv_band(xr, wl, 3, 1, 1, PAD_REFLECT, 1, 1)
+  assert_close(_nchw(y.t, C), yr.detach(), tol, name + ' fwd (complete)')
+  yr.backward(_nchw(dy.t, C))
+  assert_close(_nchw(dx.t, C), xr.grad, tol, name + ' dgrad (complete)')
+  assert_close(layer.weight.grad.cpu(), wl.grad, tol, name + ' wgrad (complete)')
+  first = layer.weight.grad.clone()
+  layer.bwd(layer.fwd(x)[1], dy, need_dx=False, need_dw=True)
+  torch.cuda.synchronize()
+  assert torch.equal(first, layer.weight.grad), 'the weight gradient must be bit-reproducible'
+
+
 # 2048x1024 (BASELINE config 5), batch 1: forward / data-gradient windows; the weight gradient from image 0 only would be the
 # same tensor as the device's (batch 1), so it is compared completely as well for the cheaper layers
 LAYERS_2048 = [

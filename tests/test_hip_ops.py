@@ -50,6 +50,11 @@ CONV_CASES = [
     ('g_down_odd',    1, 11, 13, 16,   24,  3, 2,  1,  PAD_ZERO,    ACT_NONE),
     ('resblock1024',  1, 4,  8,  1024, 1024, 3, 1, 1,  PAD_REFLECT, ACT_NONE),
     ('resblock_tail', 3, 5,  9,  72,   136, 3, 1,  1,  PAD_REFLECT, ACT_NONE),
+    # 32-pixel-wide images with wide layers: the row-pair form of the nine-tap weight gradient (wgrad_nine.h W32; round 4) --
+    # split pixel ranges (16 / 20 tiles), ranges that start inside an image, the first / last row pair of an image
+    ('trunk_w32',     2, 6,  32, 256,  256, 3, 1,  1,  PAD_REFLECT, ACT_NONE),
+    ('trunk_w32_b',   3, 4,  32, 320,  256, 3, 1,  1,  PAD_REFLECT, ACT_NONE),
+    ('trunk_w32_c',   1, 16, 32, 256,  320, 3, 1,  1,  PAD_REFLECT, ACT_NONE),
     ('g_last7x7tanh', 1, 10, 18, 64,   3,   7, 1,  3,  PAD_REFLECT, ACT_TANH),
     ('d_layer0',      2, 16, 24, 39,   64,  4, 2,  2,  PAD_ZERO,    ACT_LRELU),
     ('d_layer2',      2, 9,  13, 128,  256, 4, 2,  2,  PAD_ZERO,    ACT_NONE),
