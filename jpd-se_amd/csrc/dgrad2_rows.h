@@ -38,10 +38,18 @@ struct Dgrad2Geom {
   static constexpr int UNITS = (PIX * 256 + 1023) / 1024;   // 1 KiB DMA units: 4 pixels x 256 B
   static constexpr int ROWB = UNITS * 1024;
   static constexpr int LA = 5, NR = LA + 2;            // rows in flight ahead of the two in use
-  static constexpr int PITCH = 128 + 16;               // output tile: [2][128 pixels] x (64 channels bf16 + pad)
+  // output tile: [2][128 pixels] x 64 channels bf16, 128-byte rows whose eight 16-byte parts are XOR-swizzled with bits 1 and 3
+  // of the row index (round 4): the 16-lane groups of the tile's ds_read_b128 (pixel p parts 0-3 / 4-7 beside pixels p+1 .. p+3)
+  // and the 32-lane groups of its ds_write_b32 (rows r, r+2, r+8, r+10 of one channel pair) are then conflict free.  With the
+  // padded 144-byte rows of rounds 2-3 the reads conflicted two ways (SQ_LDS_BANK_CONFLICT 39 % of SQ_LDS_IDX_ACTIVE).
+  static constexpr int PITCH = 128;
   static constexpr int TILE = 2 * 128 * PITCH;
   static constexpr int LDS = NR * ROWB + TILE;
 };
+
+__device__ __forceinline__ int d2_tile_off(int row, int part) {       // byte offset of 16-byte part `part` of tile row `row`
+  return (row << 7) + ((part ^ (((row >> 1) & 1) | (((row >> 3) & 1) << 1))) << 4);
+}
 
 // NOCONF (developer build, TIMING ONLY -- the results are wrong): every LDS access that can have a bank conflict is re-pointed at a
 // conflict-free address -- the column-shifted A-fragment reads at the unshifted pixel, the tile reads lane-linear -- to measure what
@@ -70,7 +78,11 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
     const int lp = u * 4 + (lane >> 4);                // LDS pixel = dy column b0 + lp
     const int bw = b0 + lp;
     const bool ok = u < G::UNITS && lp < G::PIX && bw < a.OW;
-    const int chunk = ((lane & 15) ^ lp) & 15;         // conflict-free for the 16x16x32 A fragment reads (see below)
+    // 16-byte chunk c of pixel p sits in slot c ^ ((p & 7) << 1): conflict-free for the 16x16x32 A-fragment reads at BOTH column
+    // shifts (pixel and pixel + 1) in every 16-lane group of ds_read_b128 -- found by exhaustive search over the XOR-linear maps
+    // (round 4).  Rounds 2-3 used c ^ (p & 15): free of conflicts at shift 0, two colliding lanes per group at shift 1 (SQ_LDS_BANK_CONFLICT
+    // 39 % of SQ_LDS_IDX_ACTIVE together with the output tile; profiles/r04_dgrad2_rows_conflicts_ab.txt).
+    const int chunk = ((lane & 15) ^ ((lp & 7) << 1)) & 15;
     col_off[k] = ok ? bw * 128 + chunk * 8 : -1;
   }
   const bf16_t* const img = a.DY + (long long)n * a.OH * a.OW * 128;
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
   for (int t = 0; t < 36; ++t) asm volatile("" : "+v"(breg[t]));
 
   // A fragment addressing (16x16x32: lane -> pixel lane & 15, 8 k-values at 8 * (lane >> 4)): byte offset inside a ring row
-  // of pixel px, k-step ks: px * 256 + ((ks * 4 + (lane >> 4)) ^ (px & 15)) * 16
+  // of pixel px, k-step ks: px * 256 + ((ks * 4 + (lane >> 4)) ^ ((px & 7) << 1)) * 16
   int a_px[4][2];                                       // [m-tile][column shift]
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
       for (int k = 0; k < 8; ++k) {
         const int idx = tid + 256 * k;
         const int pxl = idx >> 3, part = idx & 7;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + (NOCONF ? idx * 16 : pxl * G::PITCH + part * 16));
+        const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + (NOCONF ? idx * 16 : d2_tile_off(pxl, part)));
         *reinterpret_cast<u32x4*>(a.DX + orow + (long long)(pxl >> 7) * (2 * a.OW) * 64 + (pxl & 127) * 64 + part * 8) = val;
       }
     }
@@ -166,8 +178,8 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
     auto rd = [&](int u, s16x8 (&f)[4]) {               // unit u = mt * 4 + ks
       const int mt = u >> 2, ks = u & 3;
       const int c = ks * 4 + kc;
-      const uint32_t o0 = (a_px[mt][0] << 8) + (((c ^ a_px[mt][0]) & 15) << 4);
-      const uint32_t o1 = NOCONF ? o0 : (a_px[mt][1] << 8) + (((c ^ a_px[mt][1]) & 15) << 4);
+      const uint32_t o0 = (a_px[mt][0] << 8) + (((c ^ ((a_px[mt][0] & 7) << 1)) & 15) << 4);
+      const uint32_t o1 = NOCONF ? o0 : (a_px[mt][1] << 8) + (((c ^ ((a_px[mt][1] & 7) << 1)) & 15) << 4);
       f[0] = lds_read128_asm(r0 + o0);
       f[1] = lds_read128_asm(r0 + o1);
       f[2] = lds_read128_asm(r1 + o0);
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
           const uint32_t word = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
           const int bl = mt * 16 + 4 * (lane >> 4) + 2 * ep + odd;       // dy column inside the strip
           const int ch = wid * 16 + (lane & 15) - odd;
-          lds_store32u(tile0 + (pr * 128 + 2 * bl + pc) * G::PITCH + ch * 2, word);
+          lds_store32u(tile0 + d2_tile_off(pr * 128 + 2 * bl + pc, ch >> 3) + (ch & 7) * 2, word);
         }
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256) void dgrad2_rows_kernel(const Dgrad2Args a) {
     for (int k = 0; k < 8; ++k) {
       const int idx = tid + 256 * k;
       const int pxl = idx >> 3, part = idx & 7;
-      const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + pxl * G::PITCH + part * 16);
+      const u32x4 val = *reinterpret_cast<const u32x4*>(smem + G::NR * G::ROWB + d2_tile_off(pxl, part));
       *reinterpret_cast<u32x4*>(a.DX + orow + (long long)(pxl >> 7) * (2 * a.OW) * 64 + (pxl & 127) * 64 + part * 8) = val;
     }
   }
