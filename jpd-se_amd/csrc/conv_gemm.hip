@@ -87,6 +87,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 #include "gemm_halo.h"
 #ifdef JPDSE_DEV
 #include "gemm_halo4.h"
+#include "gemm_halo16.h"
 #endif
 #include "gemm_taps.h"
 #include "wgrad_fast.h"
@@ -189,7 +190,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_pers_enabled = enable != 50 && enable != 6;   // 50: the short-K layers on gemm_fast_kernel instead of the persistent form (A/B)
   g_pers_max_kt = (enable == 51 || enable == 52) ? (1 << 20) : 24;
   g_pers_min_tiles = enable == 52 ? 1 : 256;      // 52: the persistent form from one tile on and for any K (tests)  // 51: every fast-kernel layer without split-K on the persistent form (A/B)
-  g_halo4 = enable == 53;             // 53: plain halo forward on the four-wave / 128 x 64 wave-tile form (A/B, gemm_halo4.h)
+  g_halo4 = enable == 53 ? 1 : (enable == 56 ? 16 : 0);   // 56: ... on the sixteen-wave / 64 x 32 wave-tile form (A/B, gemm_halo16.h)
+  //             // 53: plain halo forward on the four-wave / 128 x 64 wave-tile form (A/B, gemm_halo4.h)
   g_wgrad_nine32_enabled = enable != 55;     // 55: the 1024-channel trunk at 16 x 32 on the per-tap weight-gradient kernel (A/B)
   g_dgrad2_noconf = enable == 54;     // 54: dgrad2_rows_kernel with conflict-free LDS addresses (timing only, wrong results)
   g_generic_splitk = enable != 48;    // 48: fp32 generic kernel without split-K (A/B; BASELINE config 2)

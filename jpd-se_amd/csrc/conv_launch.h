@@ -397,6 +397,25 @@ static int launch_halo4(const HaloArgs& a, hipStream_t s) {
 }
 #endif
 
+#ifdef JPDSE_DEV
+// developer A/B (mode 56): the same launch on the sixteen-wave form (gemm_halo16.h)
+static int launch_halo16(const HaloArgs& a, hipStream_t s) {
+  constexpr int UH = ((4 + 2) * (64 + 2) + 7) / 8;
+  constexpr int lds = 2 * UH * 1024 + 3 * 128 * 128;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_halo16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "gemm_halo16: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  if (int rc = check_tile_grid("gemm_halo16", a.N, a.OH, a.OW, 4, 64, a.Cs, (long long)a.N * a.IH * a.IW * a.Cs, (long long)a.N * a.OH * a.OW * a.Ks)) return rc;
+  if (a.Cs < 128 || a.Ks % 128 != 0) return set_error(JPDSE_EINVAL, "gemm_halo16: needs >= 128 input channels and 128-channel output tiles");
+  const int tiles = a.N * (a.OH / 4) * (a.OW / 64) * (a.Ks / 128);
+  hipLaunchKernelGGL(gemm_halo16_kernel, dim3(tiles), dim3(1024), lds, s, a);
+  return check_launch("gemm_halo16_kernel");
+}
+#endif
+
 JPDSE_SWITCH(int, g_halo_xcd, 0);
 JPDSE_SWITCH(int, g_halo_mf16, 0);     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
 template <int TN, int ABL = 0>
@@ -420,7 +439,9 @@ static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
     if constexpr (ABL == 0) return launch_halo_cfg_impl<TN, 0, false, false, true>(a, s);
   }
 #ifdef JPDSE_DEV
-  if (ABL == 0 && TN == 2 && g_halo4 && a.Cs >= 128 && a.Ks % 128 == 0 && a.pool == nullptr && a.mask == nullptr && a.addend == nullptr)
+  if (ABL == 0 && TN == 2 && g_halo4 == 16 && a.Cs >= 128 && a.Ks % 128 == 0 && a.pool == nullptr && a.mask == nullptr && a.addend == nullptr)
+    return launch_halo16(a, s);
+  if (ABL == 0 && TN == 2 && g_halo4 == 1 && a.Cs >= 128 && a.Ks % 128 == 0 && a.pool == nullptr && a.mask == nullptr && a.addend == nullptr)
     return launch_halo4(a, s);
   if (ABL == 0 && g_halo_mf16) {
     if (a.Cs == 64 && g_halo_single) return launch_halo_cfg_impl<TN, 0, true, true>(a, s);
