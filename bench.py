@@ -196,6 +196,16 @@ def self_launch(args, timeout_s=1500):
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
   proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+
+  def _forward_kill(signum, frame):           # this launcher is being terminated (an outer `timeout`, the driver): the ranks are in
+    try:                                      # their own session and would outlive it -- take the exact group this launcher started
+      os.killpg(proc.pid, signal.SIGKILL)
+    except OSError:
+      pass
+    sys.exit(128 + signum)
+
+  for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+    signal.signal(sig, _forward_kill)
   try:
     out, _ = proc.communicate(timeout=timeout_s)
   except subprocess.TimeoutExpired:
@@ -252,6 +262,13 @@ def main():
   xd = synthetic_batch(args.batch, args.height, args.width, seed=1234 + rank)
   xd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in xd.items()}
 
+  verbose = os.environ.get('JPDSE_BENCH_VERBOSE') == '1'
+
+  def note(msg):                      # progress on stderr (JPDSE_BENCH_VERBOSE=1): where a multi-rank run stands
+    if verbose:
+      sys.stderr.write('[bench rank %d] %s\n' % (rank, msg))
+      sys.stderr.flush()
+
   def barrier():
     torch.cuda.synchronize()
     if world > 1:
@@ -264,8 +281,12 @@ def main():
   import gc
   gc.collect()
   gc.freeze()
-  for _ in range(args.warmup):
+  note('trainer built, %d warm-up steps' % args.warmup)
+  for i in range(args.warmup):
     trainer.step(xd)
+    if verbose:
+      torch.cuda.synchronize()
+      note('warm-up step %d done' % i)
   # time the ResnetBlock 3x3 GEMM (forward and its data-gradient: same kernel, N=1024, K=9216)
   L = lib()
   if args.late_readback:
@@ -293,11 +314,13 @@ def main():
   if world > 1:
     trainer.model.ddp_timeline = []          # per-step timing events of the data-parallel schedule (7 events per step)
   barrier()
+  note('timed region: %d steps' % args.steps)
   t0 = time.perf_counter()
   for _ in range(args.steps):
     trainer.step(xd)
   barrier()
   elapsed = time.perf_counter() - t0
+  note('timed region done: %.1f ms per step' % (1e3 * elapsed / args.steps))
   ddp_info = None
   if world > 1:
     tl, trainer.model.ddp_timeline = trainer.model.ddp_timeline, None
@@ -313,20 +336,23 @@ def main():
   # N > 1, --grad-reduce auto: the same K steps again on an fp32 wire (twice the xGMI bytes), reported next to the bf16 figure
   fp32_wire = None
   if world > 1 and args.grad_reduce == 'auto' and not args.bf16_reduce:
-    trainer.enable_data_parallel(reduce_dtype=None)
-    for _ in range(max(1, min(2, args.warmup))):
-      trainer.step(xd)
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-      trainer.step(xd)
-    barrier()
-    e2 = time.perf_counter() - t1
-    t = torch.tensor([e2], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    e2 = float(t.item())
-    fp32_wire = dict(value=round(args.batch * world * args.steps / e2, 4), ms_per_step=round(1e3 * e2 / args.steps, 3),
-                     steps=args.steps, note='same process, same weights, gradient all-reduce on an fp32 wire')
+    try:
+      trainer.enable_data_parallel(reduce_dtype=None)
+      for _ in range(max(1, min(2, args.warmup))):
+        trainer.step(xd)
+      barrier()
+      t1 = time.perf_counter()
+      for _ in range(args.steps):
+        trainer.step(xd)
+      barrier()
+      e2 = time.perf_counter() - t1
+      t = torch.tensor([e2], dtype=torch.float64, device=dev)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      e2 = float(t.item())
+      fp32_wire = dict(value=round(args.batch * world * args.steps / e2, 4), ms_per_step=round(1e3 * e2 / args.steps, 3),
+                       steps=args.steps, note='same process, same weights, gradient all-reduce on an fp32 wire')
+    except Exception as e:             # the headline (bf16-wire) figure above must survive a failure of the side measurement
+      fp32_wire = dict(error=repr(e)[:300])
   ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
   extra = {}
   for cls, name in ((1, 'ring'), (2, 'wgrad')):      # the other two regions of the same layer, before the log is reset
