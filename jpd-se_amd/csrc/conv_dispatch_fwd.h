@@ -91,7 +91,7 @@ static int conv_fwd_t(const jpdse_conv_desc* d, const ConvPlan& p, const void* x
       h.slope = d->slope;
       h.tiles_w = (p.OW + 63) / 64;
       h.tiles_h = (p.OH + kHeadTH - 1) / kHeadTH;
-      if (head_rows_ok(h, p.Cs)) return launch_head_rows<7>(h, s);
+      if (head_rows_ok(h, p.Cs)) return p.Cs == 64 ? launch_head_rows<7>(h, s) : launch_head_rows<7, 32>(h, s);
       return p.Cs == 64 ? launch_head_fwd<64>(h, s) : launch_head_fwd<32>(h, s);
     }
     if (tapsum_ok(d, p)) {

@@ -193,6 +193,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_halo4 = enable == 53 ? 1 : (enable == 56 ? 16 : 0);   // 56: ... on the sixteen-wave / 64 x 32 wave-tile form (A/B, gemm_halo16.h)
   //             // 53: plain halo forward on the four-wave / 128 x 64 wave-tile form (A/B, gemm_halo4.h)
   g_wgrad_nine32_enabled = enable != 55;     // 55: the 1024-channel trunk at 16 x 32 on the per-tap weight-gradient kernel (A/B)
+  g_head_rows32 = enable != 57;       // 57: the 32 -> 3 head forward on head_fwd_kernel (A/B)
   g_dgrad2_noconf = enable == 54;     // 54: dgrad2_rows_kernel with conflict-free LDS addresses (timing only, wrong results)
   g_generic_splitk = enable != 48;    // 48: fp32 generic kernel without split-K (A/B; BASELINE config 2)
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)

@@ -543,15 +543,17 @@ static int launch_dgrad2_rows(Dgrad2Args a, hipStream_t s) {
 
 
 // 64 -> <= 3 channel heads (7x7 reflect + Tanh; 3x3 zero-pad data gradient of VGG conv1_1) as a row-streaming pass (head_rows.h)
+JPDSE_SWITCH(int, g_head_rows32, 1);      // 57: the 32-channel head on head_fwd_kernel, as before round 4 (A/B)
 static bool head_rows_ok(const HeadFwdArgs& a, int cin) {
-  return g_rows_enabled && cin == 64 && a.K <= 3 && a.Ks_out == 8 && a.OW % 128 == 0 && a.OH % 8 == 0 && a.OH == a.H && a.OW == a.W;
+  return g_rows_enabled && (cin == 64 || (cin == 32 && g_head_rows32 && a.R == 7)) && a.K <= 3 && a.Ks_out == 8 && a.OW % 128 == 0 &&
+         a.OH % 8 == 0 && a.OH == a.H && a.OW == a.W;
 }
-template <int R>
+template <int R, int CIN = 64>
 static int launch_head_rows(const HeadFwdArgs& a, hipStream_t s) {
-  typedef HeadRowsGeom<R> G;
+  typedef HeadRowsGeom<R, CIN> G;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_rows_kernel<R>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_rows_kernel<R, CIN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "head_rows: hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
     configured = true;
@@ -568,7 +570,7 @@ static int launch_head_rows(const HeadFwdArgs& a, hipStream_t s) {
   if (th == 0 || strips == 0 || a.OW % 128 != 0)
     return set_error(JPDSE_EINVAL, "head_rows: output grid %d x %d does not tile into bands of >= 8 rows x 128-pixel strips", a.OH, a.OW);
   const int bands = a.OH / th;
-  hipLaunchKernelGGL((head_rows_kernel<R>), dim3((unsigned)(a.N * bands * strips)), dim3(256), G::LDS, s, a, th, bands, strips);
+  hipLaunchKernelGGL((head_rows_kernel<R, CIN>), dim3((unsigned)(a.N * bands * strips)), dim3(256), G::LDS, s, a, th, bands, strips);
   return check_launch("head_rows_kernel");
 }
 

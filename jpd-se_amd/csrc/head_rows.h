@@ -22,9 +22,14 @@
 
 namespace jpdse {
 
-template <int R> struct HeadRowsGeom {
+// CIN = 32 (round 4: the 32 -> 3 head of the LocalEnhancer, BASELINE config 3): 64-byte pixels, 16 per DMA unit, two k16-steps per
+// column tap; the four 16-byte slots of a pixel are XOR-swizzled with (pixel >> 2) & 3, which keeps every 16-lane group of the
+// fragment reads conflict free at any tap shift (pixels x, x+12, x+20, x+24 of a group share the bank quarter x & 3 and get the four
+// different slot permutations).
+template <int R, int CIN = 64> struct HeadRowsGeom {
   static constexpr int PIX = 128 + R - 1;
-  static constexpr int UNITS = (PIX + 7) / 8;                 // 1 KiB DMA units per input row (8 pixels x 128 B)
+  static constexpr int PPU = 1024 / (CIN * 2);                // pixels per 1 KiB DMA unit: 8 (128-byte pixels) or 16 (64-byte pixels)
+  static constexpr int UNITS = (PIX + PPU - 1) / PPU;         // 1 KiB DMA units per input row
   static constexpr int ROWB = UNITS * 1024;
   static constexpr int LA = 1, NR = LA + 2;                   // one row in use, LA in flight: 69 KB of LDS, two blocks per CU
   static constexpr int OROWS = R > 4 ? 8 : 4;                 // output rows under construction (power of two >= R)
@@ -37,10 +42,12 @@ __device__ __forceinline__ void lds_add_f32(uint32_t addr, float v) {
   asm volatile("ds_add_f32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-template <int R>
+template <int R, int CIN = 64>
 __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadFwdArgs a, int TH, int bands, int strips) {
-  typedef HeadRowsGeom<R> G;
-  constexpr int S = R, T = S * 4;                             // k16-steps per input row
+  static_assert(CIN == 64 || CIN == 32, "64- or 32-channel inputs");
+  typedef HeadRowsGeom<R, CIN> G;
+  constexpr int KPT = CIN / 16;                               // k16-steps per column tap
+  constexpr int S = R, T = S * KPT;                           // k16-steps per input row
   constexpr int U0 = G::UNITS / 4, U1 = U0 + 1, EXTRA = G::UNITS % 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -65,16 +72,16 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadFwdArgs a, 
 #pragma unroll
   for (int k = 0; k < U1; ++k) {
     const int u = wid + 4 * k;
-    const int lp = u * 8 + (lane >> 3);
+    const int lp = CIN == 64 ? u * 8 + (lane >> 3) : u * 16 + (lane >> 2);
     int iw = ow0 - a.pad + lp;
     bool ok = u < G::UNITS && lp < G::PIX;
     if (a.reflect) iw = iw < 0 ? -iw : (iw >= a.W ? 2 * (a.W - 1) - iw : iw);
     ok = ok && (unsigned)iw < (unsigned)a.W;
-    const int chunk = ((lane & 7) ^ (lp >> 1)) & 7;
-    col_off[k] = ok ? iw * 64 + chunk * 8 : -1;
+    const int chunk = CIN == 64 ? (((lane & 7) ^ (lp >> 1)) & 7) : (((lane & 3) ^ (lp >> 2)) & 3);
+    col_off[k] = ok ? iw * CIN + chunk * 8 : -1;
   }
-  const bf16_t* const ximg = a.X + (long long)n * a.H * a.W * 64;
-  const int row_elems = a.W * 64;
+  const bf16_t* const ximg = a.X + (long long)n * a.H * a.W * CIN;
+  const int row_elems = a.W * CIN;
   auto issue_row = [&](int jr, int slot) {
     int ih = oh0 + jr - a.pad;
     if (a.reflect) ih = ih < 0 ? -ih : (ih >= a.H ? 2 * (a.H - 1) - ih : ih);
@@ -97,9 +104,9 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadFwdArgs a, 
   {
     const int col = lane & 31, r = col >> 2, k = col & 3;
     const bool live = r < R && k < a.K;
-    const bf16_t* const wp = live ? a.Wp + ((long long)(k * R + r) * S) * 64 + (lane >> 5) * 8 : zero;
+    const bf16_t* const wp = live ? a.Wp + ((long long)(k * R + r) * S) * CIN + (lane >> 5) * 8 : zero;
 #pragma unroll
-    for (int t = 0; t < T; ++t) breg[t] = *reinterpret_cast<const s16x8*>(wp + (live ? ((t >> 2) * 64 + (t & 3) * 16) : 0));
+    for (int t = 0; t < T; ++t) breg[t] = *reinterpret_cast<const s16x8*>(wp + (live ? ((t / KPT) * CIN + (t % KPT) * 16) : 0));
   }
 #pragma unroll
   for (int t = 0; t < T; ++t) asm volatile("" : "+v"(breg[t]));
@@ -114,8 +121,8 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadFwdArgs a, 
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int lp = wid * 32 + (lane & 31) + s;
-    a_base[s] = lp << 7;
-    a_sw[s] = ((lp >> 1) & 7) << 4;
+    a_base[s] = CIN == 64 ? lp << 7 : lp << 6;
+    a_sw[s] = CIN == 64 ? ((lp >> 1) & 7) << 4 : ((lp >> 2) & 3) << 4;
   }
   const int hsel = lane >> 5;
   const int my_r = (lane & 31) >> 2, my_k = lane & 3;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadFwdArgs a, 
     constexpr int DEPTH = 3;
     s16x8 fr[DEPTH + 1];
     auto rd = [&](int t) {
-      const int s = t >> 2, ks = t & 3;
+      const int s = t / KPT, ks = t % KPT;
       return lds_read128_asm(rb + a_base[s] + (((2 * ks + hsel) << 4) ^ a_sw[s]));
     };
 #pragma unroll

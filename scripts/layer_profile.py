@@ -73,6 +73,18 @@ def _fwd_moments(d, x, pack, slots, transposed=False):
   records.append((_key('dgrad' if transposed else 'fwd', d), e0, e1, c1 - c0))
   return r
 ops.conv_fwd_moments = _fwd_moments
+# data gradients whose epilogue also writes the sums of the consuming InstanceNorm's backward (round 4)
+_dn = ops.conv_dgrad_nsums
+def _dgrad_nsums(d, *a, **k):
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  c0 = time.perf_counter()
+  r = _dn(d, *a, **k)
+  c1 = time.perf_counter()
+  e1.record()
+  records.append((_key('dgrad', d), e0, e1, c1 - c0))
+  return r
+ops.conv_dgrad_nsums = _dgrad_nsums
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record()
 for _ in range(args.steps):

@@ -56,6 +56,8 @@ CONV_CASES = [
     ('trunk_w32_b',   3, 4,  32, 320,  256, 3, 1,  1,  PAD_REFLECT, ACT_NONE),
     ('trunk_w32_c',   1, 16, 32, 256,  320, 3, 1,  1,  PAD_REFLECT, ACT_NONE),
     ('g_last7x7tanh', 1, 10, 18, 64,   3,   7, 1,  3,  PAD_REFLECT, ACT_TANH),
+    ('head64_rows',   1, 16, 128, 64,  3,   7, 1,  3,  PAD_REFLECT, ACT_TANH),    # head_rows_kernel<7, 64>
+    ('head32_rows',   2, 24, 256, 32,  3,   7, 1,  3,  PAD_REFLECT, ACT_TANH),    # head_rows_kernel<7, 32> (round 4: LocalEnhancer head)
     ('d_layer0',      2, 16, 24, 39,   64,  4, 2,  2,  PAD_ZERO,    ACT_LRELU),
     ('d_layer2',      2, 9,  13, 128,  256, 4, 2,  2,  PAD_ZERO,    ACT_NONE),
     ('d_layer3_s1',   1, 5,  9,  256,  512, 4, 1,  2,  PAD_ZERO,    ACT_NONE),
