@@ -304,7 +304,7 @@ def main():
   # Round 4: the ResnetBlock GEMM regions -- the headline `roofline` fractions -- are sampled on the first
   # THREE timed steps (3 x 72 regions = 432 events = 1.6 ms spread over the timed region: 0.08 ms per step at the driver's 20
   # steps), the HBM regions on the first step (148 events = 0.55 ms); `kernel_timers` in the output says so.
-  timed_steps = 0 if args.no_kernel_timers else min(3, args.steps)
+  timed_steps = 0 if args.no_kernel_timers else (min(3, args.steps) if args.steps >= 12 else min(1, args.steps))   # short runs: one step (0.5 ms of events)
   hbm_steps = 0 if args.no_kernel_timers else min(1, args.steps)
   tsteps = max(timed_steps, 1)
   hsteps = max(hbm_steps, 1)
@@ -456,8 +456,9 @@ def main():
         'roofline_resblock_all_passes': roof_all,
         'roofline_hbm': roof_hbm,
         'kernel_timers': {'steps_covered': timed_steps, 'hbm_steps_covered': hbm_steps, 'of_timed_steps': args.steps,
-                          'note': 'hipEvent pairs inside the timed region: ResnetBlock GEMM regions on the first 3 steps, '
-                                  'norm / Adam regions on the first (each event costs the stream ~3.7 us: ~2.1 ms in all)'},
+                          'note': 'hipEvent pairs inside the timed region: ResnetBlock GEMM regions on the first 3 steps (1 when fewer '
+                                  'than 12 steps are timed), norm / Adam regions on the first (each event costs the stream ~3.7 us: '
+                                  '~2.1 ms in all at 3 steps)'},
         'multi_gpu': ({'ddp': ddp_info, 'fp32_wire': fp32_wire} if world > 1 else
                       'N = 1: no collective ran; the 1/2/4/8-GPU curve needs the driver\'s 8-GPU node (python bench.py --gpus N)'),
     }
