@@ -243,3 +243,33 @@ def test_bench_product_leg_does_not_import_the_oracle():
   src = open(os.path.join(os.path.dirname(__file__), '..', 'bench.py')).read()
   body = src[src.index('def main'):]
   assert 'oracle' not in body.replace('cpu_baseline', ''), 'only bench.py::cpu_baseline may touch oracle/'
+
+
+def test_abi_v2_host_queries_without_a_gpu():
+  """Host-only entry points added with ABI version 2 (include/jpdse.h): the norm-backward-sums slot count of a data-gradient
+  kernel, and the per-phase weight-repack table with its fp32 / bf16 output flag.  None of them launches anything."""
+  L = jpdse_hip.lib()
+  assert L.jpdse_version() == 2
+  assert ctypes.sizeof(jpdse_hip.PackEntry) == 2 * 8 + 16 * 4 + 2 * 8
+  # ResnetBlock conv of the headline configuration (networks.py:246-252): one slot per 4-row x 64-pixel block of an image
+  res = ConvDesc(BF16, 4, 64, 128, 1024, 1024, 3, 3, 1, 1, PAD_REFLECT, 0, 0.2)
+  assert L.jpdse_conv_dgrad_nsum_slots(ctypes.byref(res)) == (64 // 4) * (128 // 64)
+  for other in (ConvDesc(F32, 4, 64, 128, 1024, 1024, 3, 3, 1, 1, PAD_REFLECT, 0, 0.2),      # fp32: generic kernels
+                ConvDesc(BF16, 4, 64, 128, 1024, 1024, 3, 3, 1, 1, PAD_ZERO, 0, 0.2),        # zero pad: not a ResnetBlock conv
+                ConvDesc(BF16, 4, 64, 96, 1024, 1024, 3, 3, 1, 1, PAD_REFLECT, 0, 0.2),      # width not a multiple of 64
+                ConvDesc(BF16, 4, 64, 128, 1024, 1024, 3, 3, 2, 1, PAD_ZERO, 0, 0.2)):       # strided
+    assert L.jpdse_conv_dgrad_nsum_slots(ctypes.byref(other)) == 0
+  # repack table: one entry per stride phase, panel pointers inside the caller's pack, fp32 panels flagged
+  for dt in (F32, BF16):
+    for st, nph in ((1, 1), (2, 4)):
+      d = ConvDesc(dt, 1, 32, 64, 64, 128, 4 if st == 2 else 3, 4 if st == 2 else 3, st, 1, PAD_ZERO, 0, 0.2)
+      ents = (jpdse_hip.PackEntry * 8)()
+      size = L.jpdse_conv_dgrad_pack_size(ctypes.byref(d))
+      base = 0x10000000
+      n = L.jpdse_conv_pack_entries(ctypes.byref(d), ctypes.c_void_p(0x1000), ctypes.c_void_p(base), ents, 8)
+      assert n == nph, (dt, st, n)
+      for e in ents[:n]:
+        assert e.w == 0x1000 and base <= e.out < base + size and e.blocks > 0
+        assert e.out_f32 == (1 if dt == F32 else 0) and (e.K, e.C, e.st) == (128, 64, st)
+      assert len({e.out for e in ents[:n]}) == n
+      assert L.jpdse_conv_pack_entries(ctypes.byref(d), ctypes.c_void_p(0x1000), ctypes.c_void_p(base), ents, nph - 1) == -1
