@@ -14,6 +14,7 @@ ap.add_argument('--batch', type=int, default=4)
 ap.add_argument('--fast', type=str, default='1', help='comma list of fast-path modes to A/B in one process')
 ap.add_argument('--filter', default='')
 ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--fwd-only', action='store_true', help='time the forward launch only (long steady runs for scripts/clock_probe.sh)')
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
 modes = [int(x) for x in args.fast.split(',')]
@@ -66,8 +67,8 @@ def _bench_one(name, layer, H, W, C, K, k, tr):
   ts = []
   for rep in range(2):      # interleaved repeats: take the best of two
     t_f = timeit(lambda: layer.fwd(x), args.iters)
-    t_d = timeit(lambda: layer.bwd(ctx, dy, True, False), args.iters)
-    t_w = timeit(lambda: layer.bwd(ctx, dy, False, True), args.iters)
+    t_d = t_f if args.fwd_only else timeit(lambda: layer.bwd(ctx, dy, True, False), args.iters)
+    t_w = t_f if args.fwd_only else timeit(lambda: layer.bwd(ctx, dy, False, True), args.iters)
     ts.append((t_f, t_d, t_w))
   t_f, t_d, t_w = (min(t[i] for t in ts) for i in range(3))
   print('%-34s %5.0f %5.2f %5.0f %5.2f %5.0f %5.2f' % (name, fl / t_f / 1e9, t_f, fl / t_d / 1e9, t_d, fl / t_w / 1e9, t_w))
