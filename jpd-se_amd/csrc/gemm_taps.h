@@ -84,7 +84,7 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
   constexpr int UPT = (HU + NT - 1) / NT;             // patch units of the NEXT slab issued per tap
   static_assert(NT <= kTapsMax && NT >= 2, "tap program length");
   constexpr int PZ = UH * 8 - 1;                      // VIRT: the last slack pixel of a patch buffer is kept zero
-  static_assert(!VIRT || (T0 == 9 && T1 == 0 && PZ >= NP && PH == TH + 2 && PW == TW + 2), "VIRT: nine taps, one set, a slack pixel");
+  static_assert(!VIRT || (T0 == 9 && T1 == 0 && PZ - 1 >= NP && (PZ & 1) == 1 && (PW & 1) == 0 && PH == TH + 2 && PW == TW + 2), "VIRT: nine taps, one set, two slack pixels");
   // LDS: weight ring first (its stage offsets then fit the 16-bit immediate of ds_read), the two patch buffers behind it
   char* const bring = smem;
   char* const halo0 = smem + 3 * B_STAGE;
@@ -132,8 +132,15 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
       // padding pixels come from the frame: rows [2][IW + 2] (column index iw + 1), then columns [2][IH]; slack pixels are zeros
       if (!ok && !slack) {
         const int fw = a.IW + 2;
-        const int fp = (ih < 0 || ih >= a.IH) ? (ih < 0 ? 0 : fw) + iw + 1 : 2 * fw + (iw < 0 ? 0 : a.IH) + ih;
-        h_off[i] = -2 - ((n * (2 * fw + 2 * a.IH) + fp) * a.Cs + chunk * 8);
+        // frame column pixels take the swizzle class AND pixel parity of the pixel their one reader reads otherwise; tiles that span
+        // the image width swap the two frame columns for that (gemm_halo.h, round 4)
+        const bool both = ow0 == 0 && ow0 + TW == a.IW;
+        const bool colf = iw < 0 || iw >= a.IW;
+        const int iws = (both && colf) ? (iw < 0 ? a.IW : -1) : iw;
+        const int fp = (ih < 0 || ih >= a.IH) ? (ih < 0 ? 0 : fw) + iws + 1 : 2 * fw + (iws < 0 ? 0 : a.IH) + ih;
+        const int cls = iws < 0 ? hr * PW + 3 : (iws >= a.IW ? hr * PW + TW - 2 : swz_p);
+        const int chunk_v = (lslot ^ (cls >> 1)) & 7;
+        h_off[i] = -2 - ((n * (2 * fw + 2 * a.IH) + fp) * a.Cs + chunk_v * 8);
       }
       if (slack) h_off[i] = -1;
     }
@@ -167,8 +174,8 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
     v_bot = oh0 + TH == a.OH;
     const bool left = ow0 == 0, right = ow0 + TW == a.OW;
     const int w = lane & 31;
-    vc0 = (left && w == 0) ? 1000 : ((right && w == TW - 2) ? PW - 1 : w);
-    vc2 = (right && w == TW - 1) ? 1000 : ((left && w == 1) ? 0 : w + 2);
+    vc0 = (left && w == 0) ? 1000 : ((right && w == TW - 2) ? (left ? 0 : PW - 1) : w);
+    vc2 = (right && w == TW - 1) ? 1000 : ((left && w == 1) ? (right ? PW - 1 : 0) : w + 2);
   }
   const int hsel = lane >> 5;                         // k-chunk of this lane inside a k-step
   int b_rd[TN][4];
@@ -244,18 +251,21 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int pt = pb[i] + tapoff;
+      int psw = pt;                                   // pixel whose swizzle class the read uses (gemm_halo.h: redirected lanes keep their bank)
       if constexpr (VIRT) {
         const int tr = TAP / 3, ts = TAP % 3;         // row-major nine-tap program (the launcher sets tap_off = tr * PW + ts); constants after unrolling
         const int j = 2 * wm + i;                     // image row of this fragment block inside the tile
         int vrow = (j + tr) * PW;
         if (tr == 2) vrow = (v_top && j == 1) ? 0 : ((v_bot && j == TH - 1) ? 1000 : vrow);
         if (tr == 0) vrow = (v_bot && j == TH - 2) ? (PH - 1) * PW : ((v_top && j == 0) ? 1000 : vrow);
-        const int col = ts == 0 ? vc0 : (ts == 2 ? vc2 : (lane & 31) + 1);
-        pt = vrow + col;
-        pt = pt < PZ ? pt : PZ;
+        const int ncol = (lane & 31) + ts;
+        const int col = ts == 0 ? vc0 : (ts == 2 ? vc2 : ncol);
+        const int ptv = vrow + col;
+        psw = ptv >= PZ ? pt : vrow + ncol;
+        pt = ptv < PZ ? ptv : PZ - 1 + (pt & 1);
       }
       a_base[i] = pt << 7;
-      a_sw[i] = ((pt >> 1) & 7) << 4;
+      a_sw[i] = ((psw >> 1) & 7) << 4;
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
