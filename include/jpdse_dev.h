@@ -30,7 +30,13 @@ extern "C" {
  * the merged-phase fast kernel only; 43 = the same layers on the tap program + fringe (measured slower in the step);
  * 48 = fp32 generic kernel without split-K; 50 = the short-K layers on gemm_fast_kernel instead of the persistent form
  * (gemm_pers.h); 51 = every fast-kernel layer without split-K on the persistent form; 52 = the persistent form from one tile on
- * and for any K (tests).  100 + bits = timing-only ablations of the halo loop.
+ * and for any K (tests); 53 / 56 = ResnetBlock / VGG forward on the four-wave / sixteen-wave halo kernels (gemm_halo4.h, gemm_halo16.h:
+ * the wave-tile A/B of profiles/r04_halo_wavetile_ab.txt; results identical); 54 = dgrad2_rows with the timing-only conflict-free
+ * addressing of round 4's first experiment (WRONG results); 55 = 32-pixel-wide 1024-channel weight gradients on the per-tap kernel
+ * instead of the row-pair nine-tap form; 57 = the 32 -> 3 head forward on head_fwd_kernel instead of head_rows_kernel<7, 32>;
+ * 58 = all-taps weight gradient (wgrad_taps.h) with the tiles of a pixel range co-located on one XCD (measured slower);
+ * 201 / 202 / 203 = timing-only ablations of that kernel's loop (no DMA after the prologue / no fragment reads and MFMAs / neither).
+ * 100 + bits = timing-only ablations of the halo loop.
  * Retired in round 4 with their negative results on record (profiles/r0*_ab.txt; the code paths are gone):
  * 21 / 22 / 24 (unpipelined loop forms of the nine-tap weight gradient), 23 (halo kernel, staggered DMA issue), 25 (halo kernel,
  * hand-pipelined fragment reads), 30 (fast kernel, XCD-aware tile order), 31 (ring strips on 128-row tiles), 44 / 45 (3- / 4-stage

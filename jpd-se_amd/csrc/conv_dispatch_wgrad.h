@@ -143,6 +143,8 @@ static int launch_wgrad_thin(const ThinWgArgs& a, hipStream_t s) {
 // ---- all-taps weight gradient of the narrow high-resolution layers (wgrad_taps.h) -----------------
 // config id: 0 none; 1: 3x3 s2 K%128 C%64; 2: 3x3 s1 K%64 C%64; 3: 4x4 s2 K%128 C%64; 4: 3x3 s2 K%256 C%128
 JPDSE_SWITCH(int, g_wgrad_taps_enabled, 1);
+JPDSE_SWITCH(int, g_wgrad_taps_abl, 0);           // 200 + bits: timing-only ablations of the all-taps loop (developer build)
+JPDSE_SWITCH(int, g_wgrad_taps_xcd, 0);           // 58: XCD co-location of the tiles of a pixel range (A/B; measured 0-13 % slower)
 static int wgrad_taps_cfg(const jpdse_conv_desc* d, const ConvPlan& p) {
   if (!g_fast_enabled || !g_wgrad_taps_enabled || p.ES != 2 || d->R != d->S) return 0;
   if ((long long)d->N * p.OH * ((p.OW + 63) / 64) < 32) return 0;
@@ -158,29 +160,63 @@ static int wgrad_taps_cfg(const jpdse_conv_desc* d, const ConvPlan& p) {
   return 0;
 }
 
-struct TapsGeom { int BM, BN, T, NROW, lds, blocks_per_cu; };
+struct TapsGeom { int BM, BN, T, NROW, lds, blocks_per_cu, bkp; };
+// LDS of one launch: stages x (dy tile + patch units + one scratch unit), wgrad_taps.h
+static constexpr int taps_lds(int BM, int S, int NROW, int ST, int bkp, int stages) {
+  return stages * (bkp * BM * 2 + ((NROW * ((bkp - 1) * ST + S) + 7) / 8 + 1) * 1024);
+}
 static TapsGeom taps_geom(int cfg) {
   switch (cfg) {
-    case 1: return {128, 64, 9, 3, 2 * (64 * 256 + 49 * 1024), 1};
-    case 2: return {64, 64, 9, 3, 2 * (64 * 128 + 25 * 1024), 2};
-    case 3: return {128, 64, 8, 2, 2 * (64 * 256 + 33 * 1024), 1};
-    default: return {256, 64, 3, 1, 2 * (64 * 512 + 17 * 1024), 1};
+    // (32-pixel chunks through a four-stage ring, two chunks in flight at every wait, measured 5-20 % SLOWER on the stride-2 layers than
+    // 64-pixel chunks / two stages, and three stages of 64-pixel chunks measured equal, profiles/r04_wgrad_taps_ab.txt: the fill
+    // latency is already hidden -- what the DMA costs is the loader's instructions, wgrad_taps.h)
+    case 1: return {128, 64, 9, 3, taps_lds(128, 3, 3, 2, 64, 2), 1, 64};
+    case 2: return {64, 64, 9, 3, taps_lds(64, 3, 3, 1, 64, 2), 2, 64};
+    case 3: return {128, 64, 8, 2, taps_lds(128, 4, 2, 2, 64, 2), 1, 64};
+    default: return {256, 64, 3, 1, taps_lds(256, 3, 1, 2, 64, 2), 1, 64};
   }
 }
 
 static void taps_partition(const jpdse_conv_desc* d, const ConvPlan& p, int cfg, TapsWgArgs* a) {
   const TapsGeom g = taps_geom(cfg);
-  a->chunks_per_row = (p.OW + 63) / 64;
+  a->chunks_per_row = (p.OW + g.bkp - 1) / g.bkp;
   a->chunks_total = d->N * p.OH * a->chunks_per_row;
   a->k_tiles = p.Ks / g.BM;
   a->r_groups = (d->R + g.NROW - 1) / g.NROW;
   a->c_tiles = p.Cs / g.BN;
   const int tiles = a->k_tiles * a->r_groups * a->c_tiles;
+  a->tiles = tiles;
   int bpt = 256 * g.blocks_per_cu / tiles;
   if (bpt < 1) bpt = 1;
+  // XCD co-location (round 4 experiment, developer mode 58, NOT the default; MI355X_MICROARCH.md "XCD placement", block b runs on XCD
+  // b % 8).  The tiles of one pixel range read the same dy chunks (and, per input-channel tile, the same input rows); dealt linearly they
+  // sit on different XCDs and every one of them pulls its own copy through the fabric (memory-side fetch 450-540 MB per launch for
+  // ~100 MB of operands, profiles/r04_hbm_traffic.txt).  A GROUP = all tiles of a pixel range (<= 32 of them), else the tiles of one
+  // (pixel range, k tile) -- the readers of one dy tile; an XCD gets whole groups, as many as its 32 CUs hold.  Measured
+  // (profiles/r04_wgrad_taps_ab.txt): 0-13 % SLOWER -- whole groups per XCD leave CUs idle (24 tiles: 192 blocks instead of 240) and
+  // the loop is not bound by where its operands come from.
+  a->xg_gs = 0;
+  a->xg_gpx = 0;
+  const int cus = 32 * g.blocks_per_cu;
+  const int gs = tiles <= cus ? tiles : a->r_groups * a->c_tiles;
+  if (g_wgrad_taps_xcd && tiles > 1 && gs <= cus && tiles % gs == 0) {
+    const int parts = tiles / gs;                       // groups per pixel range
+    const int gpx = cus / gs;                           // groups one XCD holds at a time
+    const int ranges = 8 * gpx / parts;                 // pixel ranges: 8 * gpx groups in all
+    if (ranges >= 1 && (8 * gpx) % parts == 0 && ranges <= a->chunks_total) {
+      bpt = ranges;
+      a->xg_gs = gs;
+      a->xg_gpx = gpx;
+    }
+  }
   if (bpt > a->chunks_total) bpt = a->chunks_total;
   a->chunks_per_block = (a->chunks_total + bpt - 1) / bpt;
   a->blocks_per_tile = (a->chunks_total + a->chunks_per_block - 1) / a->chunks_per_block;
+  if (a->xg_gs) {
+    const int groups = a->blocks_per_tile * (tiles / a->xg_gs);
+    if (groups % 8 != 0) a->xg_gs = 0;                  // ragged range count: linear order
+    else a->xg_gpx = groups / 8;
+  }
 }
 
 static size_t wgrad_taps_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
@@ -192,18 +228,18 @@ static size_t wgrad_taps_ws_bytes(const jpdse_conv_desc* d, const ConvPlan& p) {
   return (size_t)a.k_tiles * a.r_groups * a.c_tiles * a.blocks_per_tile * g.T * g.BM * g.BN * sizeof(float);
 }
 
-template <int TMW, int WM, int WN, int S, int NROW, int ST>
+template <int TMW, int WM, int WN, int S, int NROW, int ST, int BKP, int NSTG>
 static int launch_wgrad_taps_cfg(const TapsWgArgs& a, int lds, hipStream_t s) {
   constexpr int BM = WM * TMW * 32, BN = WN * 32;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<TMW, WM, WN, S, NROW, ST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_taps_kernel<TMW, WM, WN, S, NROW, ST, BKP, NSTG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(JPDSE_ELAUNCH, "wgrad_taps: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
   const int blocks = a.k_tiles * a.r_groups * a.c_tiles * a.blocks_per_tile;
-  hipLaunchKernelGGL((wgrad_taps_kernel<TMW, WM, WN, S, NROW, ST>), dim3(blocks), dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((wgrad_taps_kernel<TMW, WM, WN, S, NROW, ST, BKP, NSTG>), dim3(blocks), dim3(64 * WM * WN), lds, s, a);
   if (int rc = check_launch("wgrad_taps_kernel")) return rc;
   const long long total = (long long)a.K * a.R * a.S * a.C;
   if (a.C % 4 == 0 && (reinterpret_cast<uintptr_t>(a.DW) & 15) == 0)
@@ -236,12 +272,13 @@ static int launch_wgrad_taps(const jpdse_conv_desc* d, const ConvPlan& p, int cf
   a.pad = d->pad;
   a.reflect = d->pad_mode == JPDSE_PAD_REFLECT;
   taps_partition(d, p, cfg, &a);
+  a.abl = g_wgrad_taps_abl;
   const int lds = taps_geom(cfg).lds;
   switch (cfg) {
-    case 1: return launch_wgrad_taps_cfg<1, 4, 2, 3, 3, 2>(a, lds, s);
-    case 2: return launch_wgrad_taps_cfg<1, 2, 2, 3, 3, 1>(a, lds, s);
-    case 3: return launch_wgrad_taps_cfg<1, 4, 2, 4, 2, 2>(a, lds, s);
-    default: return launch_wgrad_taps_cfg<2, 4, 2, 3, 1, 2>(a, lds, s);
+    case 1: return launch_wgrad_taps_cfg<1, 4, 2, 3, 3, 2, 64, 2>(a, lds, s);
+    case 2: return launch_wgrad_taps_cfg<1, 2, 2, 3, 3, 1, 64, 2>(a, lds, s);
+    case 3: return launch_wgrad_taps_cfg<1, 4, 2, 4, 2, 2, 64, 2>(a, lds, s);
+    default: return launch_wgrad_taps_cfg<2, 4, 2, 3, 1, 2, 64, 2>(a, lds, s);
   }
 }
 

@@ -194,6 +194,8 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   //             // 53: plain halo forward on the four-wave / 128 x 64 wave-tile form (A/B, gemm_halo4.h)
   g_wgrad_nine32_enabled = enable != 55;     // 55: the 1024-channel trunk at 16 x 32 on the per-tap weight-gradient kernel (A/B)
   g_head_rows32 = enable != 57;       // 57: the 32 -> 3 head forward on head_fwd_kernel (A/B)
+  g_wgrad_taps_abl = (enable >= 200 && enable < 204) ? enable - 200 : 0;   // 201 / 202 / 203: all-taps weight gradient without DMA / without MFMAs / neither (timing only)
+  g_wgrad_taps_xcd = enable == 58;    // 58: all-taps weight gradient with the tiles of a pixel range co-located on one XCD (A/B: slower)
   g_dgrad2_noconf = enable == 54;     // 54: dgrad2_rows_kernel with conflict-free LDS addresses (timing only, wrong results)
   g_generic_splitk = enable != 48;    // 48: fp32 generic kernel without split-K (A/B; BASELINE config 2)
   g_splitk_enabled = enable != 6;     // 6: fast kernels, no split-K  // 4: fast kernels but the per-tap weight-gradient kernel (A/B)
