@@ -338,9 +338,13 @@ class Pix2PixHDModel(BaseModel):
     n_vgg = len(networks.VGGLoss.weights)
     if run_vgg:
       # VGG19 on the generated and the real image as ONE pass over [fake ; real] (networks.py:124-139 runs vgg(x), vgg(y)):
-      # the convolutions are per image, so the two halves of every feature map equal the two separate passes bit for bit,
-      # the launch count halves and the deep, small layers (relu5_1: 32x64 pixels) fill the chip.  Backward goes through the
-      # fake half of the saved tensors only (Ctx.slice).
+      # the convolutions are per image, so the two halves of every feature map hold the values of the two separate passes (no
+      # kernel on this path lets one image's arithmetic depend on the batch size: equal bit for bit on this build, which
+      # tests/test_hip_networks.py::test_vgg19_batched_pass_equals_separate_passes checks -- a property of the kernels chosen,
+      # not a contract of the ABI), the launch count halves and the deep, small layers (relu5_1: 32x64 pixels) fill the chip.
+      # Backward goes through the fake half of the saved tensors only (Ctx.slice).  Memory: the real half's activations stay
+      # alive until the pass ends instead of streaming through -- VGG19 to relu5_1 is ~0.33 GB of bf16 activations per
+      # 1024x512 image, so +1.3 GB at batch 4; of no consequence next to 288 GB.
       vgg = self.criterionVGG.vgg
       both = Act.empty(2 * B, H, W, fake.C, self.cdtype, dev)
       ops.copy_(fake.t, both.t[:B])          # two 33 MB device-to-device copies

@@ -160,6 +160,24 @@ def test_vgg19_golden(golden_dir, dtype):
     assert not p.requires_grad
 
 
+@pytest.mark.parametrize('dtype,hw', [(BF16, (512, 1024)), (BF16, (64, 128)), (F32, (64, 128))])
+def test_vgg19_batched_pass_equals_separate_passes(dtype, hw):
+  """Pix2PixHDModel.train_step runs VGG19 once over [fake ; real] instead of twice (networks.py:124-139 calls vgg(x), vgg(y)).
+  The feature maps of the batched pass must be those of the separate passes: compared bit for bit here (every kernel on this path
+  reduces each output pixel in an order that does not depend on the batch), at the bench size and at a small one."""
+  H, W = hw
+  vgg = networks.Vgg19(compute_dtype='bf16' if dtype == BF16 else 'fp32', device=DEV, seed=3)
+  g = torch.Generator().manual_seed(11)
+  a = torch.rand(2, 3, H, W, generator=g) * 2 - 1
+  b = torch.rand(2, 3, H, W, generator=g) * 2 - 1
+  both, _ = vgg.fwd(to_act(torch.cat([a, b]), dtype), save=False)
+  both = [m.t.clone() for m in both]
+  for half, x in ((0, a), (1, b)):
+    maps, _ = vgg.fwd(to_act(x, dtype), save=False)
+    for k, m in enumerate(maps):
+      assert torch.equal(both[k][2 * half:2 * half + 2], m.t), 'relu%d_1, images %d..%d: batched pass differs from the separate pass' % (k + 1, 2 * half, 2 * half + 1)
+
+
 def test_full_width_generator_vs_oracle():
   """The production shapes (ngf=64: 1024-channel ResnetBlocks, K=9216) at 32x64, fp32."""
   _EW[0] = True
