@@ -1,7 +1,7 @@
 #!/bin/bash
-# developer-build A/B of the short-K fast configurations on the layers that use them: usage ab_stages.sh "1,44,45,1,44,45"
+# developer-build A/B of kernel-selection modes on the short-K layers: usage ab_stages.sh "1,50,1,50"  (round 3 used it with the since retired modes 44 / 45 / 46)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-MODES=${1:-1,44,45,1,44,45}
+MODES=${1:-1,50,1,50}
 for f in "layer1" "layer2" "G down 128" "convT 256"; do
 JPDSE_HIP_DEV=1 timeout -k 10 200 python scripts/bench_conv.py --fast $MODES --filter "$f" --iters 30 2>&1 | grep -v "amdgpu\|^layer"
 done
