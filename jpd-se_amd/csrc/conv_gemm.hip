@@ -195,6 +195,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_wgrad_nine32_enabled = enable != 55;     // 55: the 1024-channel trunk at 16 x 32 on the per-tap weight-gradient kernel (A/B)
   g_head_rows32 = enable != 57;       // 57: the 32 -> 3 head forward on head_fwd_kernel (A/B)
   g_wgrad_taps_abl = (enable >= 200 && enable < 204) ? enable - 200 : 0;   // 201 / 202 / 203: all-taps weight gradient without DMA / without MFMAs / neither (timing only)
+  g_fast_fill = enable != 59;         // 59: few-tile medium-K layers on the 256-row tiles as before round 4 (A/B)
   g_wgrad_taps_xcd = enable == 58;    // 58: all-taps weight gradient with the tiles of a pixel range co-located on one XCD (A/B: slower)
   g_dgrad2_noconf = enable == 54;     // 54: dgrad2_rows_kernel with conflict-free LDS addresses (timing only, wrong results)
   g_generic_splitk = enable != 48;    // 48: fp32 generic kernel without split-K (A/B; BASELINE config 2)

@@ -252,6 +252,7 @@ static int launch_pers(FastBatch& b, hipStream_t s) {
 }
 
 JPDSE_SWITCH(int, g_fast_small, 20);      // K-tile count up to which the 128-row / 2-stage fast configs are used
+JPDSE_SWITCH(int, g_fast_fill, 1);                // 59: no small tiles for the few-tile medium-K layers (A/B)
 static int launch_fast_batch(FastBatch& b, hipStream_t s) {
   if (b.n <= 0) return JPDSE_OK;
   const int Ks = b.p[0].Ks;
@@ -282,6 +283,16 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
     if (Ks > 64 && kt <= 16) return launch_fast_cfg<2, 2, 1, 2, 0, 2>(b, s);   // 64 x 128
     if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);   // 128 x 128
     if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);   // 128 x 64
+  }
+  if (g_fast_fill && Ks > 64 && kt <= 64 && b.p[0].splits <= 1) {
+    // Few tiles, medium K (round 4): 256-row tiles of a small layer leave most of the chip idle (PatchGAN layer 2 of the second scale:
+    // 17,160 pixels x 256 channels = 136 tiles for 256 CUs, 279 TFLOP/s).  Smaller tiles of the same loop (same summation order) fill it.
+    long long t256 = 0;
+    for (int i = 0; i < b.n; ++i) t256 += (long long)((b.p[i].M + 255) / 256) * ((Ks + 127) / 128);
+    if (t256 < 224) {
+      if (t256 < 160) return launch_fast_cfg<2, 2, 1, 2, 0, 2>(b, s);   // 64 x 128
+      return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);                    // 128 x 128
+    }
   }
   if (b.n == 1 && prefer_320(b.p[0].M, Ks)) return launch_fast_cfg<2, 4, 5, 1, 0, 2>(b, s);   // 320 x 128, 2 stages
   if (Ks > 64) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // 256 x 128
