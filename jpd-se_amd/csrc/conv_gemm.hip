@@ -179,7 +179,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_norm_fused = enable == 27 ? 0 : (enable == 28 ? 2 : 1);   // 27: InstanceNorm always as three kernels; 28: one-kernel form with the in-launch exchange (A/B)
   g_merge_min_tiles = enable == 26 ? 384 : 64;    // 9: merged stride-phase data gradient only for long K loops (A/B)
   g_fast_small = enable == 10 ? 0 : 20;     // 10: no 128-row / 2-stage configs for short K loops (A/B)   // 9: merged stride-phase data gradient also for short K loops (A/B)
-  g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : 0);   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
+  g_halo_xcd = enable == 15 ? 1 : (enable == 16 ? 2 : (enable == 17 ? 3 : 0));   // 17: 4 N-tiles x 8 patches per XCD (one-round grids)   // 15 / 16: XCD-aware tile orders of the halo kernel (A/B)
   g_halo_mf16 = enable == 19;         // 19: halo kernel on 16x16x32 MFMAs (A/B)
   g_halo_single = enable != 8;        // 8: halo kernel always with two patch buffers (A/B)
   g_head_fwd_enabled = enable != 14 && enable != 6;   // 14: heads on the Toeplitz GEMM (A/B); 6 keeps the generic order
@@ -195,6 +195,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_wgrad_nine32_enabled = enable != 55;     // 55: the 1024-channel trunk at 16 x 32 on the per-tap weight-gradient kernel (A/B)
   g_head_rows32 = enable != 57;       // 57: the 32 -> 3 head forward on head_fwd_kernel (A/B)
   g_wgrad_taps_abl = (enable >= 200 && enable < 204) ? enable - 200 : 0;   // 201 / 202 / 203: all-taps weight gradient without DMA / without MFMAs / neither (timing only)
+  g_halo_xcd_auto = enable != 60;     // 60: halo kernel, block b -> tile b on every grid (no XCD-aware order on the one-round grids, A/B)
   g_fast_fill = enable != 59;         // 59: few-tile medium-K layers on the 256-row tiles as before round 4 (A/B)
   g_wgrad_taps_xcd = enable == 58;    // 58: all-taps weight gradient with the tiles of a pixel range co-located on one XCD (A/B: slower)
   g_dgrad2_noconf = enable == 54;     // 54: dgrad2_rows_kernel with conflict-free LDS addresses (timing only, wrong results)

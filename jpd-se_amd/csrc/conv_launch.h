@@ -428,11 +428,20 @@ static int launch_halo16(const HaloArgs& a, hipStream_t s) {
 #endif
 
 JPDSE_SWITCH(int, g_halo_xcd, 0);
+// One-round grids of the multi-slab form (the ResnetBlock convs: 32 patches x 8 channel tiles on 256 CUs): XCD-aware tile order 2 -- an XCD
+// takes 2 channel tiles x half of the patches instead of every 8th tile, so its L2 pulls a quarter of the filter instead of all of it.
+// Measured (profiles/r04_halo_xcd_ab.txt): memory-side fetch 172 -> 103 MB per launch, time unchanged (1194-1199 TFLOP/s either way);
+// on multi-round and single-slab grids the same order costs 1-4 %, so it is not used there.  60: off (A/B).
+JPDSE_SWITCH(int, g_halo_xcd_auto, 1);
 JPDSE_SWITCH(int, g_halo_mf16, 0);     // measured: 1020 vs 1032 TFLOP/s on the ResnetBlock conv -- the kernel is not MFMA-clock bound
 template <int TN, int ABL = 0>
 static int launch_halo_cfg(const HaloArgs& a0, hipStream_t s) {
   HaloArgs a = a0;
   a.xcd_mode = g_halo_xcd;
+  {
+    const long long blocks = (long long)a.N * (a.OH / 4) * (a.OW / 64) * ((a.Ks + TN * 64 - 1) / (TN * 64));
+    if (g_halo_xcd == 0 && g_halo_xcd_auto && a.Cs > 64 && blocks <= 256 && blocks % 8 == 0) a.xcd_mode = 2;
+  }
   if (a.V != nullptr) {                   // reflect data gradient with the folded frame
     if constexpr (ABL == 0 && TN == 2) {
       if (a.nsums != nullptr) {           // ... and the sums of the InstanceNorm backward that consumes its output

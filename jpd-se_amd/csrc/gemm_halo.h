@@ -39,7 +39,7 @@ struct HaloArgs {
   float slope;
   const bf16_t* mask;   // optional fused ReLU backward (see FastArgs::mask)
   const bf16_t* addend; // optional: Y = result + addend
-  int xcd_mode;         // 0: block b -> tile b; 1: blocks of one XCD (b % 8) take consecutive tiles; 2: 2 N-tiles x half the patches per XCD
+  int xcd_mode;         // 0: block b -> tile b; 1: blocks of one XCD (b % 8) take consecutive tiles; 2: 2 N-tiles x half the patches per XCD; 3: 4 N-tiles x a quarter of the patches (one-round grids of 32 x 8 tiles)
   bf16_t* pool;         // optional: MaxPool2d(2, 2) of Y, [N][OH/2][OW/2][Ks], written from the same epilogue tile (VGG19 conv -> ReLU -> pool)
   const bf16_t* V;      // VIRT instantiation: the folded frame of the input (see ring_frame_kernel), [N][2(IW+2) + 2 IH][Cs]
   float* mom;           // optional (MOM instantiation): InstanceNorm moments of y, one (mean, M2) slot per block and channel
@@ -112,6 +112,14 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
       tile_n = 2 * pair + (within / hm);
       tile_m = half * hm + (within % hm);
     }
+  }
+  if (a.xcd_mode == 3 && nblk == 256 && tiles_m == 32) {
+    // one round of 256 tiles = 32 patches x 8 channel tiles: XCD x = (patch quarter x >> 1, channel half x & 1) takes 8 patches x 4
+    // channel tiles -- the split that minimises what the 8 L2s pull through the fabric together (9.4 MB of filter + 6.5 MB of
+    // patches each: 127 MB per launch instead of 177 MB with block b -> tile b, which gives every XCD the whole filter)
+    const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    tile_n = (x & 1) * 4 + (j >> 3);
+    tile_m = (x >> 1) * 8 + (j & 7);
   }
   const int tw_i = tile_m % tiles_w, t1 = tile_m / tiles_w;
   const int th_i = t1 % tiles_h, n = t1 / tiles_h;
