@@ -129,6 +129,7 @@ static int launch_wgrad(const GemmWgradArgs& a, float* slabs, hipStream_t s) {
   return launch_wgrad_cfg<T, 32, 256, 1, 4>(a, slabs, s);
 }
 
+JPDSE_SWITCH(int, g_fast_abl, 0);                 // 210: timing-only ablation of the fast kernel (activation tiles staged for one tap in four)
 template <int WM, int WN, int TM, int TN, int VAR, int STAGES = 3>
 static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -160,6 +161,7 @@ static int launch_fast_cfg(FastBatch& b, hipStream_t s) {
         return set_error(JPDSE_EINVAL, "gemm_fast: problem %d addresses element %lld of a %lld-element input", i, last, a.x_extent);
     }
     b.first_tile[i] = total;
+    b.p[i].abl = g_fast_abl;
     b.p[i].xcd_map = 0;       // (the XCD-aware tile order, round-3 developer mode 30, measured neutral and was retired: DESIGN.md 4.1 (xi))
     total += ((a.M + BM - 1) / BM) * ((a.Ks + BN - 1) / BN) * (a.splits > 1 ? a.splits : 1);
     const long long kdim = (long long)a.R * a.S * a.Cs;

@@ -51,6 +51,7 @@ struct FastArgs {
   int no_finish;       // split-K: leave the slabs to the caller (no splitk_finish_kernel)
   long long x_extent;  // elements readable from X (0 = not given): the launcher refuses a problem whose last pixel lies beyond
   int xcd_map;         // N-tiles of an M-tile on consecutive slots of one XCD (set by the launcher)
+  int abl;             // developer build, timing only (mode 210): activation tiles are staged for one tap in four only (what a patch staged once would load)
 };
 
 // Up to 4 independent problems in one launch (the stride-2 sub-pixel phases of a data gradient /
@@ -342,9 +343,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   auto issue = [&]() {
     char* const st = smem + istage * STAGE_BYTES;
     if (ic == 0) retap();
+#ifdef JPDSE_DEV
+    const bool skip_a = a.abl != 0 && ((ir * a.S + is) & 3) != 0;      // wrong results; the vmcnt counts then over-wait by AU, never under-wait
+#else
+    constexpr bool skip_a = false;
+#endif
 #pragma unroll
     for (int i = 0; i < AU; ++i) {
-      glds16(a_src[i], st + a_lds[i]);
+      if (!skip_a) glds16(a_src[i], st + a_lds[i]);
       a_src[i] += a_step[i];
     }
     const long long koff = (long long)ir * b_tap_r + is * b_tap_s + ic * 64;
