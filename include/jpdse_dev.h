@@ -37,7 +37,8 @@ extern "C" {
  * 58 = all-taps weight gradient (wgrad_taps.h) with the tiles of a pixel range co-located on one XCD (measured slower);
  * 60 = halo kernel without the XCD-aware tile order on its one-round grids (15 / 16 / 17 force an order on every grid);
  * 59 = the few-tile medium-K layers of the fast kernel on 256-row tiles as before round 4;
- * 201 / 202 / 203 = timing-only ablations of that kernel's loop (no DMA after the prologue / no fragment reads and MFMAs / neither).
+ * 201 / 202 / 203 = timing-only ablations of that kernel's loop (no DMA after the prologue / no fragment reads and MFMAs / neither);
+ * 210 = timing-only ablation of gemm_fast_kernel: activation tiles staged for one tap in four (WRONG results; persistent form off).
  * 100 + bits = timing-only ablations of the halo loop.
  * Retired in round 4 with their negative results on record (profiles/r0*_ab.txt; the code paths are gone):
  * 21 / 22 / 24 (unpipelined loop forms of the nine-tap weight gradient), 23 (halo kernel, staggered DMA issue), 25 (halo kernel,
