@@ -275,7 +275,7 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
     const int k = b.p[i].R * b.p[i].S * (b.p[i].Cs / 64);
     kt = k > kt ? k : kt;
   }
-  if (g_fast_small && kt <= g_fast_small && b.p[0].splits <= 1) {
+  if (g_fast_small && kt <= g_fast_small && b.p[0].splits <= 1 && !g_fast_abl) {
     // short reductions are prologue / epilogue bound: 128-row tiles, 4 waves, 2 stages = 64 (48) KiB of LDS, so two
     // (three) blocks share a CU and overlap each other's fill and store phases
     // (deeper rings for the same tiles -- round-3 developer modes 44 / 45 -- measured 25-50 % slower: profiles/r03_fast_stages_ab.txt)
@@ -286,7 +286,7 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
     if (Ks > 64) return launch_fast_cfg<2, 2, 2, 2, 0, 2>(b, s);   // 128 x 128
     if (Ks > 32) return launch_fast_cfg<2, 2, 2, 1, 0, 2>(b, s);   // 128 x 64
   }
-  if (g_fast_fill && Ks > 64 && kt <= 64 && b.p[0].splits <= 1) {
+  if (g_fast_fill && Ks > 64 && kt <= 64 && b.p[0].splits <= 1 && !g_fast_abl) {
     // Few tiles, medium K (round 4): 256-row tiles of a small layer leave most of the chip idle (PatchGAN layer 2 of the second scale:
     // 17,160 pixels x 256 channels = 136 tiles for 256 CUs, 279 TFLOP/s).  Smaller tiles of the same loop (same summation order) fill it.
     long long t256 = 0;
@@ -297,6 +297,20 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
     }
   }
   if (b.n == 1 && prefer_320(b.p[0].M, Ks)) return launch_fast_cfg<2, 4, 5, 1, 0, 2>(b, s);   // 320 x 128, 2 stages
+#ifdef JPDSE_DEV
+  if (Ks > 64 && g_fast_abl) {
+    switch (g_fast_abl) {
+      case 1: return launch_fast_cfg<4, 2, 2, 2, 1>(b, s);
+      case 2: return launch_fast_cfg<4, 2, 2, 2, 2>(b, s);
+      case 4: return launch_fast_cfg<4, 2, 2, 2, 4>(b, s);
+      case 5: return launch_fast_cfg<4, 2, 2, 2, 5>(b, s);
+      case 8: return launch_fast_cfg<4, 2, 2, 2, 8>(b, s);
+      case 9: return launch_fast_cfg<4, 2, 2, 2, 9>(b, s);
+      case 7: return launch_fast_cfg<4, 2, 2, 2, 7>(b, s);
+      default: return launch_fast_cfg<4, 2, 2, 2, 16>(b, s);
+    }
+  }
+#endif
   if (Ks > 64) return launch_fast_cfg<4, 2, 2, 2, 0>(b, s);   // 256 x 128
   if (Ks > 32) return launch_fast_cfg<4, 2, 2, 1, 0>(b, s);   // 256 x 64
   return launch_fast_cfg<8, 1, 1, 1, 0>(b, s);                // 256 x 32

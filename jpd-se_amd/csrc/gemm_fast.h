@@ -51,7 +51,7 @@ struct FastArgs {
   int no_finish;       // split-K: leave the slabs to the caller (no splitk_finish_kernel)
   long long x_extent;  // elements readable from X (0 = not given): the launcher refuses a problem whose last pixel lies beyond
   int xcd_map;         // N-tiles of an M-tile on consecutive slots of one XCD (set by the launcher)
-  int abl;             // developer build, timing only (mode 210): activation tiles are staged for one tap in four only (what a patch staged once would load)
+  int abl;             // unused by the kernel (the ablations are compile-time VAR bits); kept so that the struct layout does not depend on the build
 };
 
 // Up to 4 independent problems in one launch (the stride-2 sub-pixel phases of a data gradient /
@@ -193,8 +193,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// VAR is kept as an A/B hook (a software-pipelined fragment schedule was measured 2-3 % SLOWER than the
-// plain one in the same process and removed).
+// VAR: 0 in every shipped instantiation; the developer build instantiates timing-only ablations of two configurations
+// (bits documented at the loader; modes 210-219 of jpdse_debug_set_fast_path).  (A software-pipelined fragment schedule was
+// measured 2-3 % SLOWER than the plain one in the same process and removed.)
 // STAGES = 3: ring with one tile in flight across the barrier (counted vmcnt).  STAGES = 2 (used by
 // the 320-row tile, whose 3-stage ring would not fit 160 KiB): next tile issued right after the barrier,
 // vmcnt(0) at the following one.
@@ -340,23 +341,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
       a_step[i] = ok ? 64 : 0;
     }
   };
+  bool primed = false;                   // VAR & 1: set after the prologue issues
   auto issue = [&]() {
     char* const st = smem + istage * STAGE_BYTES;
     if (ic == 0) retap();
-#ifdef JPDSE_DEV
-    const bool skip_a = a.abl != 0 && ((ir * a.S + is) & 3) != 0;      // wrong results; the vmcnt counts then over-wait by AU, never under-wait
-#else
-    constexpr bool skip_a = false;
-#endif
+    // VAR (developer build, timing only, wrong results): 1 = no DMA after the prologue tiles, 2 = no barrier, 4 = fragments read for k-step 0 only,
+    // 8 = no MFMAs (fragment reads kept alive), 16 = activation tile staged for one tap in four (the waits then pass early: optimistic)
+    const bool skip_a = (VAR & 16) != 0 && ((ir * a.S + is) & 3) != 0;
 #pragma unroll
     for (int i = 0; i < AU; ++i) {
-      if (!skip_a) glds16(a_src[i], st + a_lds[i]);
+      if (!skip_a && !((VAR & 1) && primed)) glds16(a_src[i], st + a_lds[i]);
       a_src[i] += a_step[i];
     }
     const long long koff = (long long)ir * b_tap_r + is * b_tap_s + ic * 64;
 #pragma unroll
     for (int j = 0; j < BU; ++j)
-      if (b_on[j]) glds16(b_ptr[j] + koff, st + b_lds[j]);
+      if (b_on[j] && !((VAR & 1) && primed)) glds16(b_ptr[j] + koff, st + b_lds[j]);
     if (++ic == CC) {
       ic = 0;
       if (++is == a.S) { is = 0; ++ir; }
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   if (AHEAD > 1 && T_total > 1) issue();
   if (AHEAD > 2 && T_total > 2) issue();
   int cstage = 0;
+  primed = true;
   for (int t = 0; t < T_total; ++t) {
     if (AHEAD > 2 && t + 2 < T_total) {
       wait_vmcnt<2 * (AU + BU)>();            // tiles t+1 and t+2 stay in flight
@@ -385,22 +386,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     } else {
       wait_vmcnt<0>();
     }
-    __builtin_amdgcn_s_barrier();
+    if (!(VAR & 2)) __builtin_amdgcn_s_barrier();
     const char* const st = smem + cstage * STAGE_BYTES;
     if (t + AHEAD < T_total) issue();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       s16x8 af[TM], bf[TN];
+      const int ks_r = (VAR & 4) ? 0 : ks;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(st + a_rd[i][ks]);
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const s16x8*>(st + a_rd[i][ks_r]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + b_rd[j][ks]);
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const s16x8*>(st + b_rd[j][ks_r]);
+      if constexpr ((VAR & 8) != 0) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af[i]));
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bf[j]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
     cstage = cstage == STAGES - 1 ? 0 : cstage + 1;
