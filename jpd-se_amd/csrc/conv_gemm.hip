@@ -187,7 +187,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_tapsum_enabled = enable != 13;    // 13: narrow-output layers without the tap-sum forward (A/B)
   g_thin_out_fast = enable != 13;     // 13: narrow-output long-K layers on the generic kernel (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
-  g_pers_enabled = enable != 50 && enable != 6 && !(enable >= 210 && enable < 220);   // 50: the short-K layers on gemm_fast_kernel instead of the persistent form (A/B)
+  g_pers_enabled = enable != 50 && enable != 6 && !(enable >= 210 && enable < 226);   // 50: the short-K layers on gemm_fast_kernel instead of the persistent form (A/B)
   g_pers_max_kt = (enable == 51 || enable == 52) ? (1 << 20) : 24;
   g_pers_min_tiles = enable == 52 ? 1 : 256;      // 52: the persistent form from one tile on and for any K (tests)  // 51: every fast-kernel layer without split-K on the persistent form (A/B)
   g_halo4 = enable == 53 ? 1 : (enable == 56 ? 16 : 0);   // 56: ... on the sixteen-wave / 64 x 32 wave-tile form (A/B, gemm_halo16.h)
@@ -195,7 +195,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_wgrad_nine32_enabled = enable != 55;     // 55: the 1024-channel trunk at 16 x 32 on the per-tap weight-gradient kernel (A/B)
   g_head_rows32 = enable != 57;       // 57: the 32 -> 3 head forward on head_fwd_kernel (A/B)
   g_wgrad_taps_abl = (enable >= 200 && enable < 204) ? enable - 200 : 0;   // 201 / 202 / 203: all-taps weight gradient without DMA / without MFMAs / neither (timing only)
-  g_fast_abl = (enable >= 210 && enable < 220) ? (enable == 210 ? 16 : enable - 210) : 0;   // 210-219: timing-only ablations of the 256 x 128 fast configuration (wrong results): 210 = activation tile staged for one tap in four; 210 + bits: 1 no DMA, 2 no barrier, 4 fragments of k-step 0 only, 8 no MFMAs
+  g_fast_abl = (enable >= 210 && enable < 220) ? (enable == 210 ? 16 : enable - 210) : (enable == 220 ? 32 : (enable == 221 ? 64 : (enable == 222 ? 96 : (enable == 223 ? 39 : (enable == 224 ? 192 : (enable == 225 ? 128 : 0))))));   // 224: no K loop, epilogue without its global stores; 225: whole kernel without the global stores of the epilogue   // 220 no epilogue, 221 no K loop, 222 neither (launch + set-up only), 223 MFMA-only loop without epilogue;   // 210-219: timing-only ablations of the 256 x 128 fast configuration (wrong results): 210 = activation tile staged for one tap in four; 210 + bits: 1 no DMA, 2 no barrier, 4 fragments of k-step 0 only, 8 no MFMAs
   g_halo_xcd_auto = enable != 60;     // 60: halo kernel, block b -> tile b on every grid (no XCD-aware order on the one-round grids, A/B)
   g_fast_fill = enable != 59;         // 59: few-tile medium-K layers on the 256-row tiles as before round 4 (A/B)
   g_wgrad_taps_xcd = enable == 58;    // 58: all-taps weight gradient with the tiles of a pixel range co-located on one XCD (A/B: slower)

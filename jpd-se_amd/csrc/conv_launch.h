@@ -307,6 +307,12 @@ static int launch_fast_batch(FastBatch& b, hipStream_t s) {
       case 8: return launch_fast_cfg<4, 2, 2, 2, 8>(b, s);
       case 9: return launch_fast_cfg<4, 2, 2, 2, 9>(b, s);
       case 7: return launch_fast_cfg<4, 2, 2, 2, 7>(b, s);
+      case 32: return launch_fast_cfg<4, 2, 2, 2, 32>(b, s);
+      case 64: return launch_fast_cfg<4, 2, 2, 2, 64>(b, s);
+      case 96: return launch_fast_cfg<4, 2, 2, 2, 96>(b, s);
+      case 39: return launch_fast_cfg<4, 2, 2, 2, 39>(b, s);
+      case 192: return launch_fast_cfg<4, 2, 2, 2, 192>(b, s);
+      case 128: return launch_fast_cfg<4, 2, 2, 2, 128>(b, s);
       default: return launch_fast_cfg<4, 2, 2, 2, 16>(b, s);
     }
   }

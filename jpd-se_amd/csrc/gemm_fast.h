@@ -83,10 +83,24 @@ __device__ __forceinline__ int swz128(int row, int slot) { return (row << 7) + (
 // channel axis (the accumulator layout would give 2-byte stores, 64 B contiguous per 32 lanes).
 // Lane pairs exchange one value per two accumulator rows so that every LDS store is a packed
 // (col, col+1) dword; with the 64-byte pitch skew the even / odd lanes hit disjoint banks.
-template <int TM, int TN>
-__device__ __forceinline__ void acc_tile_to_lds(char* tile, int pitch, int wrow0, int wcol0, int n0, int lane,
-                                                const f32x16 (&acc)[TM][TN], const float* bias, int Kout, int act,
-                                                float slope) {
+// The activation is a COMPILE-TIME parameter of the body and the run-time `act` is dispatched once around it (round 4): with
+// apply_act(v, act, slope) called per value, hipcc kept the four-way choice -- incl. the tanh expansion -- as scalar branches
+// around every one of the 64 values of a wave: ~7,900 instructions and 557 branches behind the last MFMA of the halo kernel,
+// 6-8 us per 256 x 128 tile (timing-only ablations, profiles/r04_fast_astage_ablation.txt).  The lane-pair exchange is a DPP
+// quad permute (no LDS round trip), as in the row-streaming kernels.
+template <int ACT> __device__ __forceinline__ float act_ct(float v, float slope) {
+  if constexpr (ACT == JPDSE_ACT_RELU) return v > 0.f ? v : 0.f;
+  else if constexpr (ACT == JPDSE_ACT_LRELU) return v > 0.f ? v : v * slope;
+  else if constexpr (ACT == JPDSE_ACT_TANH) return tanhf(v);
+  else return v;
+}
+__device__ __forceinline__ float pair_swap(float v) {      // value of lane ^ 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+
+template <int TM, int TN, int ACT>
+__device__ __forceinline__ void acc_tile_to_lds_ct(char* tile, int pitch, int wrow0, int wcol0, int n0, int lane,
+                                                   const f32x16 (&acc)[TM][TN], const float* bias, int Kout, float slope) {
   const int odd = lane & 1;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -99,9 +113,9 @@ __device__ __forceinline__ void acc_tile_to_lds(char* tile, int pitch, int wrow0
 #pragma unroll
       for (int ep = 0; ep < 8; ++ep) {
         const int e = 2 * ep;
-        const float v0 = live ? apply_act(acc[i][j][e] + bv, act, slope) : 0.f;
-        const float v1 = live ? apply_act(acc[i][j][e + 1] + bv, act, slope) : 0.f;
-        const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);
+        const float v0 = live ? act_ct<ACT>(acc[i][j][e] + bv, slope) : 0.f;
+        const float v1 = live ? act_ct<ACT>(acc[i][j][e + 1] + bv, slope) : 0.f;
+        const float recv = pair_swap(odd ? v0 : v1);
         const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
         const uint32_t word = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
         const int row = wrow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) + odd;
@@ -110,12 +124,20 @@ __device__ __forceinline__ void acc_tile_to_lds(char* tile, int pitch, int wrow0
     }
   }
 }
+template <int TM, int TN>
+__device__ __forceinline__ void acc_tile_to_lds(char* tile, int pitch, int wrow0, int wcol0, int n0, int lane,
+                                                const f32x16 (&acc)[TM][TN], const float* bias, int Kout, int act,
+                                                float slope) {
+  if (act == JPDSE_ACT_RELU) acc_tile_to_lds_ct<TM, TN, JPDSE_ACT_RELU>(tile, pitch, wrow0, wcol0, n0, lane, acc, bias, Kout, slope);
+  else if (act == JPDSE_ACT_LRELU) acc_tile_to_lds_ct<TM, TN, JPDSE_ACT_LRELU>(tile, pitch, wrow0, wcol0, n0, lane, acc, bias, Kout, slope);
+  else if (act == JPDSE_ACT_TANH) acc_tile_to_lds_ct<TM, TN, JPDSE_ACT_TANH>(tile, pitch, wrow0, wcol0, n0, lane, acc, bias, Kout, slope);
+  else acc_tile_to_lds_ct<TM, TN, JPDSE_ACT_NONE>(tile, pitch, wrow0, wcol0, n0, lane, acc, bias, Kout, slope);
+}
 
 // Same for 16x16 accumulator blocks (v_mfma_f32_16x16x32_bf16: lane -> column lane & 15, rows 4 * (lane >> 4) + e)
-template <int TM, int TN>
-__device__ __forceinline__ void acc16_tile_to_lds(char* tile, int pitch, int wrow0, int wcol0, int n0, int lane,
-                                                  const f32x4 (&acc)[TM][TN], const float* bias, int Kout, int act,
-                                                  float slope) {
+template <int TM, int TN, int ACT>
+__device__ __forceinline__ void acc16_tile_to_lds_ct(char* tile, int pitch, int wrow0, int wcol0, int n0, int lane,
+                                                     const f32x4 (&acc)[TM][TN], const float* bias, int Kout, float slope) {
   const int odd = lane & 1;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -128,9 +150,9 @@ __device__ __forceinline__ void acc16_tile_to_lds(char* tile, int pitch, int wro
 #pragma unroll
       for (int ep = 0; ep < 2; ++ep) {
         const int e = 2 * ep;
-        const float v0 = live ? apply_act(acc[i][j][e] + bv, act, slope) : 0.f;
-        const float v1 = live ? apply_act(acc[i][j][e + 1] + bv, act, slope) : 0.f;
-        const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);
+        const float v0 = live ? act_ct<ACT>(acc[i][j][e] + bv, slope) : 0.f;
+        const float v1 = live ? act_ct<ACT>(acc[i][j][e + 1] + bv, slope) : 0.f;
+        const float recv = pair_swap(odd ? v0 : v1);
         const float lo = odd ? recv : v0, hi = odd ? v1 : recv;
         const uint32_t word = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
         const int row = wrow0 + i * 16 + 4 * (lane >> 4) + e + odd;
@@ -138,6 +160,15 @@ __device__ __forceinline__ void acc16_tile_to_lds(char* tile, int pitch, int wro
       }
     }
   }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void acc16_tile_to_lds(char* tile, int pitch, int wrow0, int wcol0, int n0, int lane,
+                                                  const f32x4 (&acc)[TM][TN], const float* bias, int Kout, int act,
+                                                  float slope) {
+  if (act == JPDSE_ACT_RELU) acc16_tile_to_lds_ct<TM, TN, JPDSE_ACT_RELU>(tile, pitch, wrow0, wcol0, n0, lane, acc, bias, Kout, slope);
+  else if (act == JPDSE_ACT_LRELU) acc16_tile_to_lds_ct<TM, TN, JPDSE_ACT_LRELU>(tile, pitch, wrow0, wcol0, n0, lane, acc, bias, Kout, slope);
+  else if (act == JPDSE_ACT_TANH) acc16_tile_to_lds_ct<TM, TN, JPDSE_ACT_TANH>(tile, pitch, wrow0, wcol0, n0, lane, acc, bias, Kout, slope);
+  else acc16_tile_to_lds_ct<TM, TN, JPDSE_ACT_NONE>(tile, pitch, wrow0, wcol0, n0, lane, acc, bias, Kout, slope);
 }
 
 // 8 bf16 values: v + w in fp32, rounded once
@@ -346,7 +377,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     char* const st = smem + istage * STAGE_BYTES;
     if (ic == 0) retap();
     // VAR (developer build, timing only, wrong results): 1 = no DMA after the prologue tiles, 2 = no barrier, 4 = fragments read for k-step 0 only,
-    // 8 = no MFMAs (fragment reads kept alive), 16 = activation tile staged for one tap in four (the waits then pass early: optimistic)
+    // 8 = no MFMAs (fragment reads kept alive), 16 = activation tile staged for one tap in four (the waits then pass early: optimistic),
+    // 32 = no epilogue, 64 = no K loop
     const bool skip_a = (VAR & 16) != 0 && ((ir * a.S + is) & 3) != 0;
 #pragma unroll
     for (int i = 0; i < AU; ++i) {
@@ -377,7 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   if (AHEAD > 2 && T_total > 2) issue();
   int cstage = 0;
   primed = true;
-  for (int t = 0; t < T_total; ++t) {
+  for (int t = 0; t < ((VAR & 64) ? 0 : T_total); ++t) {      // VAR & 64 (timing only): no loop at all -- prologue (+ epilogue) alone
     if (AHEAD > 2 && t + 2 < T_total) {
       wait_vmcnt<2 * (AU + BU)>();            // tiles t+1 and t+2 stay in flight
     } else if (AHEAD > 1 && t + 1 < T_total) {
@@ -416,6 +448,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
   }
 
   // ---- epilogue --------------------------------------------------------------------------
+  if constexpr ((VAR & 32) != 0) {        // timing only: no epilogue (one store per thread keeps the accumulators alive)
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) keep += acc[i][j][e];
+    if (keep == 12345.678f) a.Y[0] = 0;
+    return;
+  }
   if (a.splits > 1 || a.no_finish) {
     float* const slab = a.partial + (long long)split * a.M * a.Ks;
 #pragma unroll
@@ -484,6 +527,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
     const int row = idx / VPR, v = idx - row * VPR;
     const long long off = row_off[row];
     if (off < 0 || n0 + v * 8 >= a.Ks) continue;
+    if constexpr ((VAR & 128) != 0) {      // timing only: the staging without the global stores (one conditional store keeps the reads alive)
+      const u32x4 val = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
+      if (val[0] == 0x12345678u && val[3] == 0x9abcdef0u) *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = val;
+      continue;
+    }
     *reinterpret_cast<u32x4*>(a.Y + off + n0 + v * 8) = *reinterpret_cast<const u32x4*>(tile + row * PITCH + v * 16);
   }
 }
