@@ -75,6 +75,13 @@ struct GemmWgradArgs {
 
 __device__ __forceinline__ int swz(int row, int slot) { return (row << 6) + (((slot ^ (row >> 3)) & 3) << 4); }
 
+// activation as a compile-time parameter: epilogues dispatch the run-time `act` ONCE around their value loops (gemm_fast.h, conv_generic.h)
+template <int ACT> __device__ __forceinline__ float act_ct(float v, float slope) {
+  if constexpr (ACT == JPDSE_ACT_RELU) return v > 0.f ? v : 0.f;
+  else if constexpr (ACT == JPDSE_ACT_LRELU) return v > 0.f ? v : v * slope;
+  else if constexpr (ACT == JPDSE_ACT_TANH) return tanhf(v);
+  else return v;
+}
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   if (act == JPDSE_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == JPDSE_ACT_LRELU) return v > 0.f ? v : v * slope;

@@ -2,6 +2,7 @@
 // filter-packing kernels and the fixed-order slab reduction.  Part of conv_gemm.hip (one translation unit): included there, in
 // order, after the kernel-argument structs.  The "row-run" formulation is described at the top of conv_gemm.hip.
 #pragma once
+#include <type_traits>
 
 namespace jpdse {
 
@@ -251,25 +252,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fwd_kernel(const GemmFwdArg
   }
   __syncthreads();
   T* const Y = reinterpret_cast<T*>(a.Y);
+  // the run-time activation is dispatched once around the value loops (round 4: per value it compiled to a four-way scalar branch
+  // incl. the tanh expansion around each of the 64 stores, gemm_fast.h)
+  auto store_tile = [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-    if (col >= a.Ks) continue;
-    const int kk = a.col_mod > 0 ? col % a.col_mod : col;
-    const bool live = a.col_mod > 0 ? kk < a.k_real : col < a.Kout;
-    const float bv = (a.bias != nullptr && live) ? a.bias[kk] : 0.f;
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      if (col >= a.Ks) continue;
+      const int kk = a.col_mod > 0 ? col % a.col_mod : col;
+      const bool live = a.col_mod > 0 ? kk < a.k_real : col < a.Kout;
+      const float bv = (a.bias != nullptr && live) ? a.bias[kk] : 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const long long off = row_off[row];
-        if (off < 0) continue;
-        float v = live ? apply_act(acc[i][j][e] + bv, a.act, a.slope) : 0.f;
-        ElemOps<T>::st(Y + off + col, v);
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const long long off = row_off[row];
+          if (off < 0) continue;
+          const float v = live ? act_ct<ACT>(acc[i][j][e] + bv, a.slope) : 0.f;
+          ElemOps<T>::st(Y + off + col, v);
+        }
       }
     }
-  }
+  };
+  if (a.act == JPDSE_ACT_RELU) store_tile(std::integral_constant<int, JPDSE_ACT_RELU>{});
+  else if (a.act == JPDSE_ACT_LRELU) store_tile(std::integral_constant<int, JPDSE_ACT_LRELU>{});
+  else if (a.act == JPDSE_ACT_TANH) store_tile(std::integral_constant<int, JPDSE_ACT_TANH>{});
+  else store_tile(std::integral_constant<int, JPDSE_ACT_NONE>{});
 }
 
 // Sum of the split-K slabs of gemm_fwd_kernel (index order: deterministic) + bias + activation -> output, 4 columns per

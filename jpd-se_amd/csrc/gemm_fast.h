@@ -88,12 +88,6 @@ __device__ __forceinline__ int swz128(int row, int slot) { return (row << 7) + (
 // around every one of the 64 values of a wave: ~7,900 instructions and 557 branches behind the last MFMA of the halo kernel,
 // 6-8 us per 256 x 128 tile (timing-only ablations, profiles/r04_fast_astage_ablation.txt).  The lane-pair exchange is a DPP
 // quad permute (no LDS round trip), as in the row-streaming kernels.
-template <int ACT> __device__ __forceinline__ float act_ct(float v, float slope) {
-  if constexpr (ACT == JPDSE_ACT_RELU) return v > 0.f ? v : 0.f;
-  else if constexpr (ACT == JPDSE_ACT_LRELU) return v > 0.f ? v : v * slope;
-  else if constexpr (ACT == JPDSE_ACT_TANH) return tanhf(v);
-  else return v;
-}
 __device__ __forceinline__ float pair_swap(float v) {      // value of lane ^ 1
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
@@ -236,7 +230,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
 #pragma unroll
   for (int i = 1; i < 4; ++i)
     if (i < batch.n && (int)blockIdx.x >= batch.first_tile[i]) q = i;
-  const FastArgs& a = batch.p[q];
+  const FastArgs a = batch.p[q];          // a COPY: one block of scalar loads up front (through a reference hipcc fetched the fields one dependent s_load at a time: 23 lgkmcnt(0) waits before the first MFMA)
   const int block_id = (int)blockIdx.x - batch.first_tile[q];
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
