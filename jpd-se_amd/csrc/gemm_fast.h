@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_fast_kernel(const FastBatch
 #pragma unroll
   for (int i = 1; i < 4; ++i)
     if (i < batch.n && (int)blockIdx.x >= batch.first_tile[i]) q = i;
-  const FastArgs a = batch.p[q];          // a COPY: one block of scalar loads up front (through a reference hipcc fetched the fields one dependent s_load at a time: 23 lgkmcnt(0) waits before the first MFMA)
+  const FastArgs& a = batch.p[q];
   const int block_id = (int)blockIdx.x - batch.first_tile[q];
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
