@@ -127,6 +127,29 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
   const int lrow = lane >> 3, lslot = lane & 7;
   const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
+  // ---- weight tile DMA units
+  const bf16_t* b_ptr[BU];
+  int b_lds[BU];
+  bool b_on[BU];
+  const long long ktot = (long long)TAPS * a.Cs;
+#pragma unroll
+  for (int j = 0; j < BU; ++j) {
+    const int u = wid + j * NW;
+    b_on[j] = u < B_UNITS;
+    const int uu = b_on[j] ? u : 0;
+    const int row = uu * 8 + lrow;
+    int br = ((ABL & 16) ? 0 : n0) + row;       // ABL 16: every block streams the SAME weight rows (L2-resident)
+    br = br < a.b_rows ? br : a.b_rows - 1;
+    b_ptr[j] = a.B + (long long)br * ktot + (MF16 ? (lslot ^ (row & 6)) : ((lslot ^ (row >> 1)) & 7)) * 8;
+    b_lds[j] = uu * 1024;
+  }
+  // Prologue order (round 4): weight tile 0 goes on the wire FIRST, each patch unit of slab 0 as soon as its address is known, weight
+  // tile 1 last -- the ~1,000 instructions of address set-up below used to run before the first DMA was issued, with the fill latency
+  // exposed behind them on every tile.  The first wait of the loop (at most BU pieces outstanding) still means "patch and tile 0 have
+  // landed, tile 1 may be in flight".
+#pragma unroll
+  for (int j = 0; j < BU; ++j)
+    if (b_on[j]) glds16(b_ptr[j], bring + b_lds[j]);                                // tile 0: slab 0, tap 0 -> stage 0
   // ---- patch DMA units of this wave: element offset of the lane's 16 bytes (slab 0), or -1 -> zero page
   long long h_off[HU];
   int h_lds[HU];
@@ -174,23 +197,15 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
       if (slack) h_off[i] = -1;
     }
     h_lds[i] = ug * 1024;
+    if (on) {                                           // = issue_patch_unit(i, 0)
+      const bf16_t* src = h_off[i] >= 0 ? a.X + h_off[i] : zero;
+      if constexpr (VIRT) src = h_off[i] < -1 ? a.V + (-2 - h_off[i]) : src;
+      glds16(src, halo0 + h_lds[i]);
+    }
   }
-  // ---- weight tile DMA units
-  const bf16_t* b_ptr[BU];
-  int b_lds[BU];
-  bool b_on[BU];
-  const long long ktot = (long long)TAPS * a.Cs;
 #pragma unroll
-  for (int j = 0; j < BU; ++j) {
-    const int u = wid + j * NW;
-    b_on[j] = u < B_UNITS;
-    const int uu = b_on[j] ? u : 0;
-    const int row = uu * 8 + lrow;
-    int br = ((ABL & 16) ? 0 : n0) + row;       // ABL 16: every block streams the SAME weight rows (L2-resident)
-    br = br < a.b_rows ? br : a.b_rows - 1;
-    b_ptr[j] = a.B + (long long)br * ktot + (MF16 ? (lslot ^ (row & 6)) : ((lslot ^ (row >> 1)) & 7)) * 8;
-    b_lds[j] = uu * 1024;
-  }
+  for (int j = 0; j < BU; ++j)
+    if (b_on[j]) glds16(b_ptr[j] + a.Cs, bring + B_STAGE + b_lds[j]);               // tile 1: slab 0, tap 1 -> stage 1
   int n_b = 0;
 #pragma unroll
   for (int j = 0; j < BU; ++j) n_b += b_on[j] ? 1 : 0;
@@ -253,12 +268,7 @@ __global__ __launch_bounds__(512) void gemm_halo_kernel(const HaloArgs a) {
       if (b_on[j]) glds16(b_ptr[j] + koff, st + b_lds[j]);
   };
 
-  // prologue: whole patch of slab 0, then weight tiles 0 and 1
-#pragma unroll
-  for (int i = 0; i < HU; ++i)
-    if (i < n_hu) issue_patch_unit(i, 0);
-  issue_b(0);
-  issue_b(1);                                         // T_total >= 9
+  // (the prologue DMA -- weight tile 0, the patch of slab 0, weight tile 1 -- was issued above, between the address computations)
 
   // Main loop: slabs outside, the 9 taps unrolled -- the tap offset, the ring stage (tap % 3), the patch unit to
   // prefetch and every end-of-range test but "last slab?" are compile-time constants.  (With a runtime tap the
