@@ -160,6 +160,32 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
     b_lds[j] = u * 1024;
   }
 
+  // (round 4: the prologue DMA is issued HERE, before the fragment addressing and the zeroing of up to 128 accumulator registers, so that the first fill flies under them)
+  const int CC_all = a.Cs >> 6;
+  const int s_begin = a.splits > 1 ? CC_all * split / a.splits : 0;
+  const int CC = a.splits > 1 ? CC_all * (split + 1) / a.splits : CC_all;      // slabs [s_begin, CC)
+
+  auto issue_patch_unit = [&](int i, int slab) {      // i: compile-time after unrolling at the call sites
+    char* const dst = halo0 + (slab & 1) * HALO + h_lds[i];
+    const bf16_t* src = h_off[i] >= 0 ? a.X + (h_off[i] + slab * 64) : zero;
+    if constexpr (VIRT) src = h_off[i] < -1 ? a.V + ((-2 - h_off[i]) + slab * 64) : src;
+    glds16(src, dst);
+  };
+  auto issue_b = [&](const int tap, const int slab, const int stage) {      // tap, stage: compile-time at the call sites
+    const int q = tap < T0 ? 0 : 1;
+    char* const st = bring + stage * B_STAGE;
+    const bf16_t* const base = pr.B[q] + (pr.tap_koff[tap] + slab * 64);      // scalar
+#pragma unroll
+    for (int j = 0; j < BU; ++j) glds16(base + b_off[q][j], st + b_lds[j]);
+  };
+
+  // prologue: whole patch of slab 0, then weight tiles 0 and 1 (NT >= 2)
+#pragma unroll
+  for (int i = 0; i < HU; ++i)
+    if (i < n_hu) issue_patch_unit(i, s_begin);
+  issue_b(0, s_begin, 0);
+  issue_b(1, s_begin, 1);
+
   // ---- fragment addressing
   int pb[2];                                          // patch pixel of this lane's row for tap offset 0, per fragment block
 #pragma unroll
@@ -195,31 +221,6 @@ __device__ __forceinline__ void gemm_taps_body(const TapsArgs& a, const TapsProg
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[q][i][j][e] = 0.f;
-
-  const int CC_all = a.Cs >> 6;
-  const int s_begin = a.splits > 1 ? CC_all * split / a.splits : 0;
-  const int CC = a.splits > 1 ? CC_all * (split + 1) / a.splits : CC_all;      // slabs [s_begin, CC)
-
-  auto issue_patch_unit = [&](int i, int slab) {      // i: compile-time after unrolling at the call sites
-    char* const dst = halo0 + (slab & 1) * HALO + h_lds[i];
-    const bf16_t* src = h_off[i] >= 0 ? a.X + (h_off[i] + slab * 64) : zero;
-    if constexpr (VIRT) src = h_off[i] < -1 ? a.V + ((-2 - h_off[i]) + slab * 64) : src;
-    glds16(src, dst);
-  };
-  auto issue_b = [&](const int tap, const int slab, const int stage) {      // tap, stage: compile-time at the call sites
-    const int q = tap < T0 ? 0 : 1;
-    char* const st = bring + stage * B_STAGE;
-    const bf16_t* const base = pr.B[q] + (pr.tap_koff[tap] + slab * 64);      // scalar
-#pragma unroll
-    for (int j = 0; j < BU; ++j) glds16(base + b_off[q][j], st + b_lds[j]);
-  };
-
-  // prologue: whole patch of slab 0, then weight tiles 0 and 1 (NT >= 2)
-#pragma unroll
-  for (int i = 0; i < HU; ++i)
-    if (i < n_hu) issue_patch_unit(i, s_begin);
-  issue_b(0, s_begin, 0);
-  issue_b(1, s_begin, 1);
 
   // One (slab, tap) step.  SM = slab % 3 and TAP are compile-time: ring stage (SM * NT + TAP) % 3, accumulator set, the
   // patch units of the next slab to prefetch and the tap two steps ahead are constants; `more` (another slab follows) and
