@@ -35,6 +35,7 @@ extern "C" {
  * addressing of round 4's first experiment (WRONG results); 55 = 32-pixel-wide 1024-channel weight gradients on the per-tap kernel
  * instead of the row-pair nine-tap form; 57 = the 32 -> 3 head forward on head_fwd_kernel instead of head_rows_kernel<7, 32>;
  * 58 = all-taps weight gradient (wgrad_taps.h) with the tiles of a pixel range co-located on one XCD (measured slower);
+ * 61 = the short-K whole-round layers on the persistent form (gemm_pers.h), as shipped during round 4 before the epilogue fix (50 is the default again);
  * 60 = halo kernel without the XCD-aware tile order on its one-round grids (15 / 16 / 17 force an order on every grid);
  * 59 = the few-tile medium-K layers of the fast kernel on 256-row tiles as before round 4;
  * 201 / 202 / 203 = timing-only ablations of that kernel's loop (no DMA after the prologue / no fragment reads and MFMAs / neither);

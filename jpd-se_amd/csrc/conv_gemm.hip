@@ -194,7 +194,7 @@ int jpdse_debug_set_fast_path(int32_t enable) {
   g_tapsum_enabled = enable != 13;    // 13: narrow-output layers without the tap-sum forward (A/B)
   g_thin_out_fast = enable != 13;     // 13: narrow-output long-K layers on the generic kernel (A/B)
   g_toep_enabled = enable != 5;       // 5: fast kernels, plain head forward
-  g_pers_enabled = enable != 50 && enable != 6 && !(enable >= 210 && enable < 226);   // 50: the short-K layers on gemm_fast_kernel instead of the persistent form (A/B)
+  g_pers_enabled = enable == 51 || enable == 52 || enable == 61;   // 61: the persistent form on its whole-round grids (the default of round 4 until the epilogue fix made gemm_fast_kernel faster); 50 = 1 now
   g_pers_max_kt = (enable == 51 || enable == 52) ? (1 << 20) : 24;
   g_pers_min_tiles = enable == 52 ? 1 : 256;      // 52: the persistent form from one tile on and for any K (tests)  // 51: every fast-kernel layer without split-K on the persistent form (A/B)
   g_halo4 = enable == 53 ? 1 : (enable == 56 ? 16 : 0);   // 56: ... on the sixteen-wave / 64 x 32 wave-tile form (A/B, gemm_halo16.h)

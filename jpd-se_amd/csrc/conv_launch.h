@@ -195,7 +195,10 @@ static bool prefer_320(int M, int Ks) {
 }
 
 // ---- persistent, cross-tile-pipelined form for the short-K layers (gemm_pers.h) -------------------------------------------
-JPDSE_SWITCH(int, g_pers_enabled, 1);     // 50: these layers on gemm_fast_kernel (A/B)
+// Off since the end of round 4: with the epilogue staging fixed (gemm_fast.h, acc_tile_to_lds) the fast kernel runs the two launches the persistent form
+// was shipped for 5-7 % FASTER than it (697 vs 650, 685 vs 640 TFLOP/s; step 24.93 vs 24.95 ms) -- its +8 % had been the lean epilogue it happened to have.
+// Developer modes 51 / 52 (tests) / 61 (the round-4 rule: whole-round grids, <= 24 K-tiles) still reach it.
+JPDSE_SWITCH(int, g_pers_enabled, 0);
 JPDSE_SWITCH(int, g_pers_max_kt, 24);     // K-tile count up to which the persistent form is taken (51: every fast-kernel layer without split-K, A/B)
 JPDSE_SWITCH(int, g_pers_min_tiles, 256); // 52: from one tile on (tests: ragged tails and multi-problem launches at small sizes)
 static bool pers_ok(const FastBatch& b) {

@@ -598,8 +598,9 @@ def test_conv_norm_fused_moments_offset_channels_full_size(name, make, shape):
 
 
 # Persistent, cross-tile-pipelined fast kernel (gemm_pers.h; round 4): forward and merged-phase data gradient of the short-K
-# layers.  At the bench sizes it is what runs (tests/test_hip_fullsize_windows.py); here developer mode 52 sends small problems
-# through it too -- ragged M tails, ragged N tails, tiles that cross image boundaries, blocks with several tiles and blocks
+# layers.  It is NOT on the default dispatch any more (once the epilogue staging of gemm_fast_kernel was fixed that kernel became
+# the faster one); it stays built and tested: developer mode 52 sends small problems
+# through it -- ragged M tails, ragged N tails, tiles that cross image boundaries, blocks with several tiles and blocks
 # with one -- against torch-CPU and against the kernels the default dispatch takes for the same layer (mode 50).
 PERS_CASES = [
     # name,          N, H,  W,   C,   K,   k, st, pad, mode
