@@ -89,6 +89,14 @@ CONV_CASES = [
     ('thinf_s1_48',    1, 13, 100, 42, 64,  7, 1, 3,  PAD_REFLECT, ACT_NONE),
     # head weight gradient (wgrad_thin.h, transposed roles): 32-channel input (LocalEnhancer), ragged strips
     ('head_local32',   2, 9,  70,  32, 3,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
+    # round 4: the epilogue staging of the tiled kernels is specialised per activation at compile time -- every copy gets a case
+    # on every kernel family (the model itself only asks the wide kernels for none / ReLU)
+    ('halo_tanh',      1, 8,  64,  128, 128, 3, 1, 1,  PAD_ZERO,    ACT_TANH),     # gemm_halo_kernel
+    ('halo_lrelu',     1, 8,  64,  128, 128, 3, 1, 1,  PAD_REFLECT, ACT_LRELU),
+    ('fast_tanh_s2',   2, 16, 48,  128, 128, 3, 2, 1,  PAD_ZERO,    ACT_TANH),     # gemm_fast_kernel (forward), tap program (data gradient)
+    ('fast_relu_4x4',  2, 17, 33,  64,  128, 4, 2, 2,  PAD_ZERO,    ACT_RELU),
+    ('taps4_tanh',     1, 16, 32,  128, 128, 4, 1, 2,  PAD_ZERO,    ACT_TANH),     # 4x4 stride 1: gemm_taps_kernel core + fringe
+    ('thinf_tanh',     1, 16, 64,  39,  64,  7, 1, 3,  PAD_REFLECT, ACT_TANH),     # thin_fwd_kernel
     ('head_3x3_zero',  1, 6,  130, 64, 5,   3, 1, 1,  PAD_ZERO,    ACT_NONE),
     # head forward as a Toeplitz GEMM (4 output pixels x 8 channels per MFMA row): needs OW % 4 == 0
     ('head_toeplitz',  2, 9,  72,  64, 3,   7, 1, 3,  PAD_REFLECT, ACT_TANH),
